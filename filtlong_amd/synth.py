@@ -1,0 +1,66 @@
+"""Deterministic synthetic long-read generator (host side, numpy).
+
+Same integer-only definition as ``oracle/synth.h`` (C) and ``filtlong_amd/csrc/synth.hip``
+(device), so all three produce identical bytes.  It stands in for the
+reference's ``test/make_synthetic_reads.py``, which shells out to PBSIM/wgsim at hard-coded
+paths (reference test/make_synthetic_reads.py:25-26,66-70) and cannot run here.
+
+Only read *lengths* use floating point (gamma(k=4), mean 10 kbp) and are therefore produced
+on the host only and uploaded.
+"""
+import numpy as np
+
+SEED = 20250919
+
+STREAM_LEN, STREAM_MU, STREAM_QUAL, STREAM_BASE = 1, 2, 3, 4
+STREAM_REF, STREAM_START, STREAM_ERATE, STREAM_SUB, STREAM_JUNK = 5, 6, 7, 8, 9
+
+_M = np.uint64
+_C1 = _M(0x9E3779B97F4A7C15)
+_C2 = _M(0xBF58476D1CE4E5B9)
+_C3 = _M(0x94D049BB133111EB)
+
+
+def mix(seed, stream, read, pos):
+    """splitmix64 finaliser over seed ^ stream*C1 ^ read*C2 ^ pos*C3 (vectorised, uint64)."""
+    with np.errstate(over="ignore"):
+        z = (_M(seed) ^ (np.asarray(stream, dtype=np.uint64) * _C1) ^ (np.asarray(read, dtype=np.uint64) * _C2)
+             ^ (np.asarray(pos, dtype=np.uint64) * _C3))
+        z = (z ^ (z >> _M(30))) * _C2
+        z = (z ^ (z >> _M(27))) * _C3
+        return z ^ (z >> _M(31))
+
+
+def lengths(n, first=0, seed=SEED, fixed=None):
+    """Read lengths: clamp(round(2500 * sum_{j<4} -ln u_j), 200, 200000); int32[n]."""
+    if fixed is not None:
+        return np.full(n, fixed, dtype=np.int32)
+    reads = np.arange(first, first + n, dtype=np.uint64)
+    g = np.zeros(n, dtype=np.float64)
+    for j in range(4):
+        h = mix(seed, STREAM_LEN, reads, j)
+        u = ((h >> _M(11)).astype(np.float64) + 0.5) / 9007199254740992.0
+        g += -np.log(u)
+    return np.clip(np.rint(2500.0 * g), 200, 200000).astype(np.int32)
+
+
+def mu(read, seed=SEED):
+    return (8 + (mix(seed, STREAM_MU, read, 0) % _M(18))).astype(np.int64)
+
+
+def qual_read(read, length, seed=SEED):
+    """Phred+33 bytes of one read (uint8[length])."""
+    pos = np.arange(length, dtype=np.uint64)
+    h = mix(seed, STREAM_QUAL, read, pos >> _M(2))
+    f = (h >> (_M(16) * (pos & _M(3)))) & _M(0xFFFF)
+    m = int(mu(np.uint64(read), seed))
+    q = m + (f & _M(0xFF)).astype(np.int64) % 9 - 4 + (f >> _M(8)).astype(np.int64) % 9 - 4
+    return (np.clip(q, 1, 60) + 33).astype(np.uint8)
+
+
+def bases_read(stream, read, start, length, seed=SEED):
+    """Random bases of a stream (uint8[length], ASCII ACGT)."""
+    pos = np.arange(start, start + length, dtype=np.uint64)
+    h = mix(seed, stream, read, pos >> _M(5))
+    idx = (h >> (_M(2) * (pos & _M(31)))) & _M(3)
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[idx.astype(np.int64)]
