@@ -1,0 +1,122 @@
+"""ctypes loader for the C-ABI library (include/filtlong_hip.h).
+
+There is no CPU fallback: if libfiltlong_hip.so is missing, or no gfx950 device is present when a
+context is created, this fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libfiltlong_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+FLX_OK = 0
+STATUS_NAMES = {0: "FLX_OK", 1: "FLX_ERR_INVALID", 2: "FLX_ERR_HIP", 3: "FLX_ERR_NOMEM", 4: "FLX_ERR_STATE",
+                5: "FLX_ERR_CAPACITY", 6: "FLX_ERR_NO_DEVICE"}
+
+# every symbol include/filtlong_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "flx_abi_version", "flx_version", "flx_ctx_create", "flx_ctx_destroy", "flx_last_error", "flx_ctx_set_stream",
+    "flx_ctx_synchronize", "flx_ctx_device_info", "flx_timing_enable", "flx_timing_reset", "flx_timing_get",
+    "flx_plane_layout", "flx_length_order", "flx_score_batch", "flx_score_batch_dev", "flx_rank_and_cut",
+    "flx_rank_and_cut_dev", "flx_kmerset_create", "flx_kmerset_destroy", "flx_kmerset_add_assembly",
+    "flx_kmerset_add_short_reads", "flx_kmerset_finalize", "flx_kmerset_size", "flx_kmerset_contains",
+    "flx_synth_qual_dev",
+]
+
+
+class Params(C.Structure):
+    """flx_params — hot-path fields of the reference's Arguments (src/arguments.h:59-91)."""
+    _fields_ = [
+        ("window_size", C.c_int32),
+        ("min_length_set", C.c_int32), ("min_length", C.c_int32),
+        ("max_length_set", C.c_int32), ("max_length", C.c_int32),
+        ("min_mean_q_set", C.c_int32),
+        ("min_window_q_set", C.c_int32),
+        ("min_mean_q", C.c_double),
+        ("min_window_q", C.c_double),
+        ("trim", C.c_int32),
+        ("split_set", C.c_int32), ("split", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
+class Scores(C.Structure):
+    """flx_scores"""
+    _fields_ = [
+        ("mean_q", C.c_void_p), ("window_q", C.c_void_p), ("passed", C.c_void_p),
+        ("first", C.c_void_p), ("last", C.c_void_p),
+        ("child_offsets", C.c_void_p), ("child_ranges", C.c_void_p), ("child_mean_q", C.c_void_p),
+        ("child_window_q", C.c_void_p), ("child_passed", C.c_void_p),
+        ("child_capacity", C.c_uint64), ("n_children", C.c_uint64),
+    ]
+
+
+class CutReport(C.Structure):
+    """flx_cut_report"""
+    _fields_ = [
+        ("target_bases", C.c_int64), ("kept_bases", C.c_int64), ("outcome", C.c_int32),
+        ("exact_fallback", C.c_int32),
+        ("mean_quality", C.c_double), ("stdev_quality", C.c_double), ("min_z", C.c_double), ("max_z", C.c_double),
+        ("audited", C.c_uint64),
+    ]
+
+
+class FlxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(code, code), msg))
+        self.code = code
+
+
+def build(verbose=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"] + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i64, i32, dbl = C.c_void_p, C.c_uint64, C.c_int64, C.c_int, C.c_double
+    L.flx_abi_version.restype = i32
+    L.flx_version.restype = C.c_char_p
+    L.flx_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.flx_ctx_destroy.argtypes = [vp]
+    L.flx_ctx_destroy.restype = None
+    L.flx_last_error.argtypes = [vp]
+    L.flx_last_error.restype = C.c_char_p
+    L.flx_ctx_set_stream.argtypes = [vp, vp]
+    L.flx_ctx_synchronize.argtypes = [vp]
+    L.flx_ctx_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32), C.POINTER(u64)]
+    L.flx_timing_enable.argtypes = [vp, i32]
+    L.flx_timing_reset.argtypes = [vp]
+    L.flx_timing_get.argtypes = [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(u64)]
+    L.flx_plane_layout.argtypes = [vp, u64, vp, C.POINTER(u64)]
+    L.flx_length_order.argtypes = [vp, u64, vp]
+    L.flx_score_batch.argtypes = [vp, vp, vp, u64, vp, vp, vp, u64, C.POINTER(Params), C.POINTER(Scores)]
+    L.flx_score_batch_dev.argtypes = [vp, vp, vp, u64, vp, vp, vp, u64, C.POINTER(Params), C.POINTER(Scores)]
+    rank_args = [vp, u64, vp, vp, vp, vp, dbl, dbl, dbl, i32, i64, i32, dbl, i64, vp, C.POINTER(CutReport)]
+    L.flx_rank_and_cut.argtypes = rank_args
+    L.flx_rank_and_cut_dev.argtypes = rank_args
+    L.flx_kmerset_create.argtypes = [vp, C.POINTER(vp)]
+    L.flx_kmerset_destroy.argtypes = [vp]
+    L.flx_kmerset_destroy.restype = None
+    L.flx_kmerset_add_assembly.argtypes = [vp, vp, vp, vp, u64]
+    L.flx_kmerset_add_short_reads.argtypes = [vp, vp, vp, vp, u64]
+    L.flx_kmerset_finalize.argtypes = [vp]
+    L.flx_kmerset_size.argtypes = [vp]
+    L.flx_kmerset_size.restype = u64
+    L.flx_kmerset_contains.argtypes = [vp, vp, u64, vp]
+    L.flx_synth_qual_dev.argtypes = [vp, u64, vp, u64, vp, vp, vp, u64]
+    _lib = L
+    return L

@@ -1,0 +1,252 @@
+"""Host-side Python mirror of the reference's interface for the scoring hot path.
+
+Thin layer over the C ABI (include/filtlong_hip.h) used by the tests and bench.py.  Names follow the
+reference: ``Kmers`` (src/kmers.h:28-56), per-read scoring = the batched ``Read::Read``
+(src/read.cpp:25-144), ``rank_and_cut`` = the global stage inlined in ``main`` (src/main.cpp:169-261).
+All compute happens in the HIP library; there is no CPU fallback here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import CutReport, FlxError, Params, Scores
+
+CUT_NONE, CUT_NOT_ENOUGH, CUT_ALREADY_BELOW, CUT_SORTED = 0, 1, 2, 3
+
+
+def make_params(window_size=250, min_length=None, max_length=None, min_mean_q=None, min_window_q=None, trim=False,
+                split=None):
+    """flx_params from keyword arguments named like the reference's CLI flags (src/arguments.cpp:152-205)."""
+    p = Params()
+    p.window_size = int(window_size)
+    p.min_length_set, p.min_length = (1, int(min_length)) if min_length is not None else (0, 0)
+    p.max_length_set, p.max_length = (1, int(max_length)) if max_length is not None else (0, 0)
+    p.min_mean_q_set, p.min_mean_q = (1, float(min_mean_q)) if min_mean_q is not None else (0, 0.0)
+    p.min_window_q_set, p.min_window_q = (1, float(min_window_q)) if min_window_q is not None else (0, 0.0)
+    p.trim = 1 if trim else 0
+    p.split_set, p.split = (1, int(split)) if split is not None else (0, 0)
+    return p
+
+
+def pack_reads(strings):
+    """Pack byte strings into the 16-byte-aligned read plane of flx_score_batch.
+
+    Returns (plane uint8[plane_bytes], offsets uint64[n], lengths int32[n])."""
+    L = _lib.load()
+    n = len(strings)
+    lengths = np.array([len(s) for s in strings], dtype=np.int32)
+    offsets = np.zeros(max(n, 1), dtype=np.uint64)
+    pb = C.c_uint64()
+    rc = L.flx_plane_layout(lengths.ctypes.data, n, offsets.ctypes.data, C.byref(pb))
+    if rc:
+        raise FlxError(rc, "flx_plane_layout")
+    plane = np.zeros(pb.value, dtype=np.uint8)
+    for s, o in zip(strings, offsets):
+        if len(s):
+            plane[int(o):int(o) + len(s)] = np.frombuffer(bytes(s), dtype=np.uint8)
+    return plane, offsets[:n], lengths
+
+
+def length_order(lengths):
+    """Processing order: read indices by descending length (flx_length_order)."""
+    L = _lib.load()
+    lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+    order = np.zeros(max(len(lengths), 1), dtype=np.uint32)
+    rc = L.flx_length_order(lengths.ctypes.data, len(lengths), order.ctypes.data)
+    if rc:
+        raise FlxError(rc, "flx_length_order")
+    return order[:len(lengths)]
+
+
+class Context:
+    """One flx_ctx (one GPU).  Fails loudly without a gfx950 device."""
+
+    def __init__(self, device=0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        rc = self.L.flx_ctx_create(int(device), C.byref(h))
+        if rc:
+            raise FlxError(rc, self.L.flx_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.flx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise FlxError(rc, self.L.flx_last_error(self.h).decode())
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        ncu, mem = C.c_int(), C.c_uint64()
+        self._check(self.L.flx_ctx_device_info(self.h, name, 256, C.byref(ncu), C.byref(mem)))
+        return {"name": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": mem.value}
+
+    def set_stream(self, stream_ptr):
+        self._check(self.L.flx_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._check(self.L.flx_ctx_synchronize(self.h))
+
+    # ---- timing ------------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._check(self.L.flx_timing_enable(self.h, 1 if on else 0))
+
+    def timing_reset(self):
+        self._check(self.L.flx_timing_reset(self.h))
+
+    def timing_get(self, prefix=""):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self.L.flx_timing_get(self.h, prefix.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- seam 2: per-read scoring (host buffers) -----------------------------------------------
+    def score_reads(self, plane, offsets, lengths, params, kmers=None, order=None, child_capacity=None):
+        """Batched Read::Read.  Returns a dict of numpy arrays in input order."""
+        n = len(lengths)
+        plane = np.ascontiguousarray(plane, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        out = {
+            "mean_q": np.zeros(n, dtype=np.float64), "window_q": np.zeros(n, dtype=np.float64),
+            "passed": np.zeros(n, dtype=np.uint8), "first": np.full(n, -1, dtype=np.int32),
+            "last": np.full(n, -1, dtype=np.int32), "child_offsets": np.zeros(n + 1, dtype=np.uint64),
+        }
+        if child_capacity is None:
+            child_capacity = max(16, 4 * n)
+        ordp = None
+        if order is not None:
+            order = np.ascontiguousarray(order, dtype=np.uint32)
+            ordp = order.ctypes.data
+        while True:
+            cr = np.zeros(2 * child_capacity, dtype=np.int32)
+            cm = np.zeros(child_capacity, dtype=np.float64)
+            cw = np.zeros(child_capacity, dtype=np.float64)
+            cp = np.zeros(child_capacity, dtype=np.uint8)
+            s = Scores()
+            s.mean_q, s.window_q, s.passed = out["mean_q"].ctypes.data, out["window_q"].ctypes.data, out["passed"].ctypes.data
+            s.first, s.last = out["first"].ctypes.data, out["last"].ctypes.data
+            s.child_offsets = out["child_offsets"].ctypes.data
+            s.child_ranges, s.child_mean_q, s.child_window_q, s.child_passed = (cr.ctypes.data, cm.ctypes.data,
+                                                                              cw.ctypes.data, cp.ctypes.data)
+            s.child_capacity = child_capacity
+            rc = self.L.flx_score_batch(self.h, kmers.h if kmers is not None else None, plane.ctypes.data,
+                                        plane.nbytes, offsets.ctypes.data, lengths.ctypes.data, ordp, n,
+                                        C.byref(params), C.byref(s))
+            if rc == 5 and s.n_children > child_capacity:  # FLX_ERR_CAPACITY: retry with the reported size
+                child_capacity = int(s.n_children)
+                continue
+            self._check(rc)
+            break
+        nc = int(s.n_children)
+        out["child_ranges"] = cr[:2 * nc].reshape(-1, 2)
+        out["child_mean_q"], out["child_window_q"], out["child_passed"] = cm[:nc], cw[:nc], cp[:nc]
+        return out
+
+    # ---- seam 2, device-resident ---------------------------------------------------------------
+    def score_reads_dev(self, d_plane, plane_bytes, d_offsets, d_lengths, d_order, n, params, d_mean_q, d_window_q,
+                        d_passed, kmers=None):
+        s = Scores()
+        s.mean_q, s.window_q, s.passed = d_mean_q, d_window_q, d_passed
+        self._check(self.L.flx_score_batch_dev(self.h, kmers.h if kmers is not None else None, d_plane, plane_bytes,
+                                               d_offsets, d_lengths, d_order, n, C.byref(params), C.byref(s)))
+
+    # ---- seam 3: rank + cut --------------------------------------------------------------------
+    def rank_and_cut(self, mean_q, window_q, length, passed, length_weight=1.0, mean_q_weight=1.0,
+                     window_q_weight=1.0, target_bases=None, keep_percent=None, total_bases=None,
+                     want_scores=True):
+        n = len(mean_q)
+        mq = np.ascontiguousarray(mean_q, dtype=np.float64)
+        wq = np.ascontiguousarray(window_q, dtype=np.float64)
+        ln = np.ascontiguousarray(length, dtype=np.int32)
+        ps = np.array(passed, dtype=np.uint8)
+        fs = np.zeros(n, dtype=np.float64) if want_scores else None
+        if total_bases is None:
+            total_bases = int(ln.astype(np.int64).sum())
+        rep = CutReport()
+        self._check(self.L.flx_rank_and_cut(self.h, n, mq.ctypes.data, wq.ctypes.data, ln.ctypes.data, ps.ctypes.data,
+                                            length_weight, mean_q_weight, window_q_weight,
+                                            1 if target_bases is not None else 0, int(target_bases or 0),
+                                            1 if keep_percent is not None else 0, float(keep_percent or 0.0),
+                                            int(total_bases), fs.ctypes.data if want_scores else None, C.byref(rep)))
+        return {"passed": ps, "final_score": fs, "report": rep}
+
+    def rank_and_cut_dev(self, n, d_mean_q, d_window_q, d_length, d_passed, length_weight=1.0, mean_q_weight=1.0,
+                         window_q_weight=1.0, target_bases=None, keep_percent=None, total_bases=0,
+                         d_final_score=None):
+        rep = CutReport()
+        self._check(self.L.flx_rank_and_cut_dev(self.h, n, d_mean_q, d_window_q, d_length, d_passed, length_weight,
+                                                mean_q_weight, window_q_weight,
+                                                1 if target_bases is not None else 0, int(target_bases or 0),
+                                                1 if keep_percent is not None else 0, float(keep_percent or 0.0),
+                                                int(total_bases), d_final_score, C.byref(rep)))
+        return rep
+
+    def synth_qual_dev(self, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n):
+        self._check(self.L.flx_synth_qual_dev(self.h, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n))
+
+
+class Kmers:
+    """Reference 16-mer set on the device — mirrors the reference's Kmers (src/kmers.h:28-56)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(ctx.L.flx_kmerset_create(ctx.h, C.byref(h)))
+        self.h = h
+        self._final = False
+
+    def _add(self, fn, seqs):
+        seqs = [bytes(s) for s in seqs]
+        n = len(seqs)
+        lengths = np.array([len(s) for s in seqs], dtype=np.int64)
+        offsets = np.zeros(max(n, 1), dtype=np.uint64)
+        if n:
+            offsets[1:n] = np.cumsum(lengths[:-1])
+        bases = np.frombuffer(b"".join(seqs) or b"\0", dtype=np.uint8)
+        self.ctx._check(fn(self.h, bases.ctypes.data, offsets.ctypes.data, lengths.ctypes.data, n))
+
+    def add_assembly_fasta(self, seqs):
+        """Kmers::add_assembly_fasta (src/kmers.cpp:61-72) on already-parsed contig sequences."""
+        self._add(self.ctx.L.flx_kmerset_add_assembly, seqs)
+
+    def add_read_fastqs(self, files_of_seqs):
+        """Kmers::add_read_fastqs (src/kmers.cpp:50-58): one list of read sequences per file, -1 then -2."""
+        for seqs in files_of_seqs:
+            self._add(self.ctx.L.flx_kmerset_add_short_reads, seqs)
+
+    def finalize(self):
+        self.ctx._check(self.ctx.L.flx_kmerset_finalize(self.h))
+        self._final = True
+
+    def __len__(self):
+        return int(self.ctx.L.flx_kmerset_size(self.h))
+
+    def empty(self):
+        return len(self) == 0
+
+    def is_kmer_present(self, kmers):
+        k = np.ascontiguousarray(kmers, dtype=np.uint32)
+        out = np.zeros(len(k), dtype=np.uint8)
+        self.ctx._check(self.ctx.L.flx_kmerset_contains(self.h, k.ctypes.data, len(k), out.ctypes.data))
+        return out.astype(bool)
+
+    def close(self):
+        if self.h:
+            self.ctx.L.flx_kmerset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

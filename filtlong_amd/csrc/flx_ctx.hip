@@ -1,0 +1,224 @@
+// flx_ctx.hip — context, error handling, timing, layout helpers of libfiltlong_hip.so.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "flx_internal.h"
+
+static std::string g_create_error;
+
+int flx_fail(flx_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+extern "C" int flx_abi_version(void) { return FLX_ABI_VERSION; }
+extern "C" const char *flx_version(void) { return "filtlong-amd 0.1 (hot path of Filtlong v0.3.1; gfx950)"; }
+
+extern "C" const char *flx_last_error(const flx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+// Phred byte -> quality, reference src/read.cpp:270-273.  Evaluated on the HOST with the host libm so
+// that the table is bit-identical to what the CPU reference computes on the same box (glibc pow is
+// not correctly rounded).  The call goes through a volatile pointer so the compiler
+// cannot rewrite pow(10, x) into exp10(x).
+static void build_phred_lut(double *lut257) {
+    double (*volatile powfn)(double, double) = pow;
+    for (int b = 0; b < 256; ++b) {
+        int q = (int)(signed char)(unsigned char)b - 33;
+        lut257[b] = 1.0 - powfn(10.0, -q / 10.0);
+    }
+    lut257[256] = 0.0;
+}
+
+extern "C" int flx_ctx_create(int device_ordinal, flx_ctx **out) {
+    if (!out) return flx_fail(nullptr, FLX_ERR_INVALID, "flx_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return flx_fail(nullptr, FLX_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                        e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return flx_fail(nullptr, FLX_ERR_INVALID, "device ordinal %d out of range (have %d)", device_ordinal, n);
+    flx_ctx *ctx = new flx_ctx();
+    ctx->device = device_ordinal;
+    FLX_HIP(nullptr, hipSetDevice(device_ordinal));
+    FLX_HIP(nullptr, hipGetDeviceProperties(&ctx->prop, device_ordinal));
+    if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string arch = ctx->prop.gcnArchName;
+        delete ctx;
+        return flx_fail(nullptr, FLX_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                        device_ordinal, arch.c_str());
+    }
+    FLX_HIP(nullptr, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    build_phred_lut(ctx->h_lut_q);
+    FLX_HIP(nullptr, hipMalloc((void **)&ctx->d_lut_q, 257 * sizeof(double)));
+    FLX_HIP(nullptr, hipMalloc((void **)&ctx->d_lut_d, 257 * sizeof(double)));
+    FLX_HIP(nullptr, hipMemcpy(ctx->d_lut_q, ctx->h_lut_q, 257 * sizeof(double), hipMemcpyHostToDevice));
+    *out = ctx;
+    return FLX_OK;
+}
+
+extern "C" void flx_ctx_destroy(flx_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->timed) {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    if (ctx->d_lut_q) (void)hipFree(ctx->d_lut_q);
+    if (ctx->d_lut_d) (void)hipFree(ctx->d_lut_d);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int flx_ctx_set_stream(flx_ctx *ctx, void *hip_stream) {
+    if (!ctx) return FLX_ERR_INVALID;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return FLX_OK;
+}
+
+extern "C" int flx_ctx_synchronize(flx_ctx *ctx) {
+    if (!ctx) return FLX_ERR_INVALID;
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FLX_OK;
+}
+
+extern "C" int flx_ctx_device_info(const flx_ctx *ctx, char *name, size_t name_cap, int *n_cu, uint64_t *hbm_bytes) {
+    if (!ctx) return FLX_ERR_INVALID;
+    if (name && name_cap) {
+        snprintf(name, name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    }
+    if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = ctx->prop.totalGlobalMem;
+    return FLX_OK;
+}
+
+// The division table D[c] = Q[c] / double(window_size): IEEE division, done once per window size on
+// the host (exact, identical to the per-step `qualities[i] / window_size` of src/read.cpp:228-229,
+// where window_size is a size_t converted to double).
+int flx_ensure_lut_d(flx_ctx *ctx, int window_size) {
+    if (ctx->lut_d_ws == window_size) return FLX_OK;
+    double d[257];
+    volatile double ws = (double)(size_t)window_size;
+    for (int b = 0; b < 257; ++b) d[b] = ctx->h_lut_q[b] / ws;
+    FLX_HIP(ctx, hipMemcpyAsync(ctx->d_lut_d, d, sizeof d, hipMemcpyHostToDevice, ctx->stream));
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->lut_d_ws = window_size;
+    return FLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ timing
+static hipEvent_t take_event(flx_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void flx_time_begin(flx_ctx *ctx, const char *name) {
+    if (!ctx->timing) return;
+    flx_timed_launch t;
+    t.name = name;
+    t.start = take_event(ctx);
+    t.stop = take_event(ctx);
+    (void)hipEventRecord(t.start, ctx->stream);
+    ctx->timed.push_back(t);
+}
+
+void flx_time_end(flx_ctx *ctx) {
+    if (!ctx->timing || ctx->timed.empty()) return;
+    (void)hipEventRecord(ctx->timed.back().stop, ctx->stream);
+}
+
+extern "C" int flx_timing_enable(flx_ctx *ctx, int on) {
+    if (!ctx) return FLX_ERR_INVALID;
+    ctx->timing = on != 0;
+    return FLX_OK;
+}
+
+extern "C" int flx_timing_reset(flx_ctx *ctx) {
+    if (!ctx) return FLX_ERR_INVALID;
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &t : ctx->timed) {
+        ctx->event_pool.push_back(t.start);
+        ctx->event_pool.push_back(t.stop);
+    }
+    ctx->timed.clear();
+    return FLX_OK;
+}
+
+extern "C" int flx_timing_get(flx_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches) {
+    if (!ctx) return FLX_ERR_INVALID;
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    uint64_t n = 0;
+    size_t pl = prefix ? strlen(prefix) : 0;
+    for (auto &t : ctx->timed) {
+        if (pl && strncmp(t.name, prefix, pl) != 0) continue;
+        float ms = 0.f;
+        FLX_HIP(ctx, hipEventElapsedTime(&ms, t.start, t.stop));
+        tot += ms;
+        ++n;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return FLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ memory
+int flx_scratch(flx_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->scratch_bytes) {
+        FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) (void)hipFree(ctx->scratch);
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        size_t want = bytes + bytes / 8 + 4096;
+        hipError_t e = hipMalloc(&ctx->scratch, want);
+        if (e != hipSuccess) return flx_fail(ctx, FLX_ERR_NOMEM, "device scratch of %zu bytes: %s", want, hipGetErrorString(e));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return FLX_OK;
+}
+
+int flx_dalloc(flx_ctx *ctx, flx_dbuf &b, size_t bytes) {
+    hipError_t e = hipMalloc(&b.p, bytes ? bytes : 16);
+    if (e != hipSuccess) return flx_fail(ctx, FLX_ERR_NOMEM, "device allocation of %zu bytes: %s", bytes, hipGetErrorString(e));
+    return FLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ layout
+extern "C" int flx_plane_layout(const int32_t *lengths, uint64_t n_reads, uint64_t *offsets, uint64_t *plane_bytes) {
+    if ((!lengths && n_reads) || !plane_bytes) return FLX_ERR_INVALID;
+    uint64_t off = 0;
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        if (lengths[i] < 0) return FLX_ERR_INVALID;
+        if (offsets) offsets[i] = off;
+        off += ((uint64_t)lengths[i] + 15u) & ~(uint64_t)15u;
+    }
+    *plane_bytes = off ? off : 16;
+    return FLX_OK;
+}
+
+extern "C" int flx_length_order(const int32_t *lengths, uint64_t n_reads, uint32_t *order) {
+    if ((!lengths || !order) && n_reads) return FLX_ERR_INVALID;
+    if (n_reads > 0xffffffffull) return FLX_ERR_INVALID;
+    std::iota(order, order + n_reads, 0u);
+    std::stable_sort(order, order + n_reads, [lengths](uint32_t a, uint32_t b) { return lengths[a] > lengths[b]; });
+    return FLX_OK;
+}

@@ -1,0 +1,91 @@
+// flx_internal.h — shared internals of libfiltlong_hip.so (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/filtlong_hip.h"
+
+struct flx_timed_launch {
+    const char *name;
+    hipEvent_t start, stop;
+};
+
+struct flx_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    std::string err;
+
+    // Phred LUTs: lut_q[c] = 1 - 10^(-(c-33)/10) for the signed-char value of byte c, built on the
+    // host with the host libm (the same one the CPU reference uses); lut_d = lut_q / window_size.
+    // Entry 256 is the "no base" entry (0.0): adding it is an exact no-op.
+    double h_lut_q[257];
+    double *d_lut_q = nullptr;  // [257]
+    double *d_lut_d = nullptr;  // [257], rebuilt when window_size changes
+    int lut_d_ws = -1;
+
+    // timing
+    bool timing = false;
+    std::vector<flx_timed_launch> timed;
+    std::vector<hipEvent_t> event_pool;
+
+    // reusable device scratch (grown on demand)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+int flx_fail(flx_ctx *ctx, int code, const char *fmt, ...);
+
+#define FLX_HIP(ctx, call)                                                                         \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return flx_fail((ctx), FLX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                            __FILE__, __LINE__);                                                   \
+    } while (0)
+
+#define FLX_CHECK(expr)            \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != FLX_OK) return rc__; \
+    } while (0)
+
+// RAII-free timing helpers: call begin before a launch and end right after it.
+void flx_time_begin(flx_ctx *ctx, const char *name);
+void flx_time_end(flx_ctx *ctx);
+
+// grow-only scratch on the device
+int flx_scratch(flx_ctx *ctx, size_t bytes, void **out);
+
+// simple device buffer owned by a call (freed in destructor)
+struct flx_dbuf {
+    void *p = nullptr;
+    ~flx_dbuf() {
+        if (p) (void)hipFree(p);
+    }
+    template <typename T>
+    T *as() { return (T *)p; }
+};
+int flx_dalloc(flx_ctx *ctx, flx_dbuf &b, size_t bytes);
+
+// internal launchers -------------------------------------------------------------------------
+struct flx_score_out_dev {  // device pointers
+    double *mean_q;
+    double *window_q;
+    uint8_t *passed;
+};
+
+int flx_ensure_lut_d(flx_ctx *ctx, int window_size);
+
+int flx_launch_score_phred(flx_ctx *ctx, const uint8_t *d_plane, uint64_t plane_bytes, const uint64_t *d_offsets,
+                           const int32_t *d_lengths, const uint32_t *d_order, uint64_t n_reads,
+                           const flx_params *p, flx_score_out_dev out);

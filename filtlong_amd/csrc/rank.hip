@@ -1,0 +1,425 @@
+// rank.hip — seam 3: global statistics, normalisation, final score, device radix sort and the
+// --target_bases / --keep_percent cut.  Replaces reference src/main.cpp:169-261 and
+// Read::set_final_score (src/read.cpp:249-267).
+//
+// Exactness plan (DESIGN.md "global stage"):
+//   * min / max / mean / stdev of the mean qualities: the reference folds them serially in reads2
+//     order (main.cpp:173-185, FP non-associative).  flx_exact_stats reproduces those two folds
+//     bit-for-bit (see stats.hip).
+//   * normalise (main.cpp:202-208): IEEE div/mul/sub only -> identical on the device
+//     (-ffp-contract=off, correctly rounded FP64 division).
+//   * set_final_score calls glibc pow three times (read.cpp:252,254); glibc pow is not correctly
+//     rounded, so the device's pow may differ in the last ulp.  Final scores are therefore used on the
+//     device only to ORDER reads; the reads whose device score lies within a relative band of the
+//     cut score are re-scored on the host with the host libm ("boundary audit") and the cut is
+//     re-decided among them.  An exact tie straddling the cut falls back to the reference's own
+//     std::sort tie order (host path, rare; report->exact_fallback = 1).
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+
+#include "flx_internal.h"
+#include "rank_internal.h"
+
+namespace {
+
+struct NormArgs {
+    double qmean, qstd, zmin, zspan;
+    double lw, mw, ww;
+};
+
+// a8, src/read.cpp:241-244
+__device__ __host__ inline double length_score(int length) {
+    const double half = 5000.0;
+    return 100.0 * (1.0 + (-half / (length + half)));
+}
+
+// order-preserving map double -> uint64 (ascending), NaN sorts above +inf
+__device__ __host__ inline uint64_t key_ascending(double v) {
+    uint64_t b;
+    memcpy(&b, &v, 8);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+template <typename PowFn>
+__device__ __host__ inline double final_score_with(PowFn powfn, int length, double mean_raw, double window_raw,
+                                                   const NormArgs &s) {
+    // main.cpp:203-208
+    double ratio = window_raw / mean_raw;
+    if (ratio > 1.0) ratio = 1.0;
+    const double z = (mean_raw - s.qmean) / s.qstd;
+    const double mq = 100.0 * (z - s.zmin) / s.zspan;
+    const double wq = mq * ratio;
+    // read.cpp:249-267
+    const double product = powfn(length_score(length), s.lw) * powfn(mq, s.mw);
+    double total = s.lw + s.mw;
+    const double gm = powfn(product, 1.0 / total);
+    double scale;
+    if (mq > 0.0) {
+        scale = wq / mq;
+        if (!(scale < 1.0)) scale = 1.0;  // std::min(x, 1.0): returns 1.0 unless x < 1.0 (NaN -> 1.0 as b<a is false)
+    } else
+        scale = 1.0;
+    total = s.lw + s.mw + s.ww;
+    const double wfrac = s.ww / total;
+    const double nfrac = 1.0 - wfrac;
+    scale = nfrac + (scale * wfrac);
+    return gm * scale;
+}
+
+struct DevPow {
+    __device__ double operator()(double x, double y) const { return pow(x, y); }
+};
+
+__global__ void k_final_score(uint64_t n, const double *mean_q, const double *window_q, const int32_t *length,
+                              NormArgs s, double *final_score, uint64_t *keys, uint32_t *vals) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double f = final_score_with(DevPow(), length[i], mean_q[i], window_q[i], s);
+    if (final_score) final_score[i] = f;
+    if (keys) {
+        keys[i] = ~key_ascending(f);  // descending score == ascending key
+        vals[i] = (uint32_t)i;
+    }
+}
+
+__global__ void k_passed_bases(uint64_t n, const int32_t *length, const uint8_t *passed,
+                               unsigned long long *out) {
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        if (passed[i]) acc += (unsigned long long)length[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+// weights in sorted order: bases a read contributes to the walk (main.cpp:251-257)
+__global__ void k_cut_weights(uint64_t n, const uint32_t *sorted_idx, const int32_t *length, const uint8_t *passed,
+                              int64_t *w, uint8_t *pre_sorted) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = sorted_idx[i];
+    const uint8_t ok = passed[r];
+    pre_sorted[i] = ok;  // pass flag before the cut, in sorted order (the audit needs it)
+    w[i] = ok ? (int64_t)length[r] : 0;
+}
+
+// keep iff passed && bases_so_far(before) < target; everything else fails.  Also records the sorted
+// position of the last kept read and the kept base total.
+__global__ void k_cut_apply(uint64_t n, const uint32_t *sorted_idx, const int64_t *excl, const int64_t *w,
+                            int64_t target, uint8_t *passed, unsigned long long *kept_bases,
+                            unsigned long long *last_kept_pos_plus1) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = sorted_idx[i];
+    const bool keep = passed[r] && excl[i] < target;
+    if (!keep) passed[r] = 0;
+    else {
+        atomicAdd(kept_bases, (unsigned long long)w[i]);
+        atomicMax(last_kept_pos_plus1, (unsigned long long)(i + 1));
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host-exact pieces (used by the boundary audit and the tie fallback)
+// ------------------------------------------------------------------------------------------------
+struct HostPow {
+    double operator()(double x, double y) const {
+        static double (*volatile fn)(double, double) = pow;
+        return fn(x, y);
+    }
+};
+
+static double host_final_score(int length, double mean_raw, double window_raw, const NormArgs &s) {
+    return final_score_with(HostPow(), length, mean_raw, window_raw, s);
+}
+
+static int64_t compute_target(int target_bases_set, int64_t target_bases, int keep_percent_set, double keep_percent,
+                              int64_t total_bases) {
+    // main.cpp:229-237
+    long long target = target_bases_set ? (long long)target_bases : std::numeric_limits<long long>::max();
+    if (keep_percent_set) {
+        volatile double kp = keep_percent;
+        long long keep = (long long)((kp / 100.0) * total_bases);
+        target = std::min(target, keep);
+    }
+    return target;
+}
+
+// Tie fallback: the reference's own order (libstdc++ std::sort on reads2 order, main.cpp:247-248) with
+// host-libm scores for every read.  Only reached when equal scores straddle the cut.
+static int exact_host_cut(flx_ctx *ctx, uint64_t n, const double *d_mean, const double *d_window,
+                          const int32_t *d_length, uint8_t *d_passed, const uint32_t *d_sorted_idx,
+                          const uint8_t *d_pre_sorted, const NormArgs &s, int64_t target, flx_cut_report *rep) {
+    std::vector<double> mean(n), window(n), fs(n);
+    std::vector<int32_t> len(n);
+    std::vector<uint8_t> passed(n), pre(n);
+    std::vector<uint32_t> sidx(n);
+    FLX_HIP(ctx, hipMemcpy(pre.data(), d_pre_sorted, n, hipMemcpyDeviceToHost));
+    FLX_HIP(ctx, hipMemcpy(sidx.data(), d_sorted_idx, n * 4, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) passed[sidx[i]] = pre[i];  // pass flags as they were before the cut
+    FLX_HIP(ctx, hipMemcpy(mean.data(), d_mean, n * 8, hipMemcpyDeviceToHost));
+    FLX_HIP(ctx, hipMemcpy(window.data(), d_window, n * 8, hipMemcpyDeviceToHost));
+    FLX_HIP(ctx, hipMemcpy(len.data(), d_length, n * 4, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) fs[i] = host_final_score(len[i], mean[i], window[i], s);
+    std::vector<uint64_t> order(n);
+    std::iota(order.begin(), order.end(), 0ull);
+    const double *f = fs.data();
+    std::sort(order.begin(), order.end(), [f](uint64_t a, uint64_t b) { return f[a] > f[b]; });
+    long long so_far = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+        const uint64_t i = order[k];
+        if (passed[i] && so_far < target) so_far += len[i];
+        else passed[i] = 0;
+    }
+    FLX_HIP(ctx, hipMemcpy(d_passed, passed.data(), n, hipMemcpyHostToDevice));
+    rep->kept_bases = so_far;
+    rep->exact_fallback = 1;
+    rep->audited = n;
+    return FLX_OK;
+}
+
+extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean_q, const void *d_window_q,
+                                    const void *d_length, void *d_passed, double lw, double mw, double ww,
+                                    int target_bases_set, int64_t target_bases, int keep_percent_set,
+                                    double keep_percent, int64_t total_bases, void *d_final_score,
+                                    flx_cut_report *rep) {
+    if (!ctx) return FLX_ERR_INVALID;
+    if (!rep) return flx_fail(ctx, FLX_ERR_INVALID, "report must not be NULL");
+    memset(rep, 0, sizeof *rep);
+    if (n > 0xffffffffull) return flx_fail(ctx, FLX_ERR_INVALID, "at most 2^32-1 reads");
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    const double *mean = (const double *)d_mean_q;
+    const double *window = (const double *)d_window_q;
+    const int32_t *length = (const int32_t *)d_length;
+    uint8_t *passed = (uint8_t *)d_passed;
+    hipStream_t st = ctx->stream;
+    const bool cutting = target_bases_set || keep_percent_set;
+
+    // ---- a20: statistics (exact serial folds) -------------------------------------------------
+    flx_stats stats;
+    FLX_CHECK(flx_exact_stats(ctx, n, mean, &stats));
+    NormArgs s;
+    s.qmean = stats.mean;
+    s.qstd = stats.stdev;
+    if (stats.stdev > 0.0) {  // main.cpp:188-195
+        s.zmin = (stats.min - stats.mean) / stats.stdev;
+        const double zmax = (stats.max - stats.mean) / stats.stdev;
+        s.zspan = zmax - s.zmin;
+        rep->max_z = zmax;
+    } else {
+        s.zmin = 1.0;
+        s.zspan = 1.0 - 1.0;
+        rep->max_z = 1.0;
+    }
+    s.lw = lw; s.mw = mw; s.ww = ww;
+    rep->mean_quality = stats.mean;
+    rep->stdev_quality = stats.stdev;
+    rep->min_z = s.zmin;
+
+    // ---- early outs that need no sort ----------------------------------------------------------
+    int64_t target = 0;
+    bool need_sort = false;
+    if (cutting && n) {
+        void *scr;
+        FLX_CHECK(flx_scratch(ctx, 64, &scr));
+        unsigned long long *d_acc = (unsigned long long *)scr;
+        FLX_HIP(ctx, hipMemsetAsync(d_acc, 0, 8, st));
+        flx_time_begin(ctx, "flx_rank_passed_bases");
+        hipLaunchKernelGGL(k_passed_bases, dim3(1024), dim3(256), 0, st, n, length, passed, d_acc);
+        flx_time_end(ctx);
+        unsigned long long passed_bases = 0;
+        FLX_HIP(ctx, hipMemcpyAsync(&passed_bases, d_acc, 8, hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+        target = compute_target(target_bases_set, target_bases, keep_percent_set, keep_percent, total_bases);
+        rep->target_bases = target;
+        if (target >= total_bases) rep->outcome = FLX_CUT_NOT_ENOUGH;
+        else if (target >= (int64_t)passed_bases) rep->outcome = FLX_CUT_ALREADY_BELOW;
+        else { rep->outcome = FLX_CUT_SORTED; need_sort = true; }
+    } else if (cutting) {
+        target = compute_target(target_bases_set, target_bases, keep_percent_set, keep_percent, total_bases);
+        rep->target_bases = target;
+        rep->outcome = target >= total_bases ? FLX_CUT_NOT_ENOUGH : FLX_CUT_ALREADY_BELOW;
+    }
+    if (n == 0) return FLX_OK;
+
+    // ---- a21/a22: normalise + final score (+ sort keys) ---------------------------------------
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (!need_sort) {
+        if (d_final_score) {
+            flx_time_begin(ctx, "flx_rank_final_score");
+            hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s,
+                               (double *)d_final_score, (uint64_t *)nullptr, (uint32_t *)nullptr);
+            flx_time_end(ctx);
+            FLX_HIP(ctx, hipStreamSynchronize(st));
+        }
+        return FLX_OK;
+    }
+
+    // scratch layout: keys[2][n] u64 | vals[2][n] u32 | weights[n] i64 | excl[n] i64 | sort workspace
+    const size_t sort_ws = flx_radix_sort_workspace(n);
+    const size_t bytes = n * (16 + 8 + 8 + 8) + ((n + 255) & ~(size_t)255) + 256 + sort_ws;
+    void *scr;
+    FLX_CHECK(flx_scratch(ctx, bytes, &scr));
+    char *p = (char *)scr;
+    uint64_t *keys0 = (uint64_t *)p; p += n * 8;
+    uint64_t *keys1 = (uint64_t *)p; p += n * 8;
+    int64_t *wts = (int64_t *)p; p += n * 8;
+    int64_t *excl = (int64_t *)p; p += n * 8;
+    uint32_t *vals0 = (uint32_t *)p; p += n * 4;
+    uint32_t *vals1 = (uint32_t *)p; p += n * 4;
+    uint8_t *pre_sorted = (uint8_t *)p; p += (n + 255) & ~(size_t)255;
+    unsigned long long *d_acc = (unsigned long long *)p; p += 256;
+    void *sort_tmp = p;
+
+    flx_time_begin(ctx, "flx_rank_final_score");
+    hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s,
+                       (double *)d_final_score, keys0, vals0);
+    flx_time_end(ctx);
+
+    // ---- a24: device radix sort (stable, descending score) -------------------------------------
+    uint64_t *skeys = nullptr;
+    uint32_t *svals = nullptr;
+    FLX_CHECK(flx_radix_sort_pairs(ctx, n, keys0, keys1, vals0, vals1, sort_tmp, sort_ws, &skeys, &svals));
+
+    // ---- a25: cut walk as an exclusive scan ------------------------------------------------------
+    flx_time_begin(ctx, "flx_rank_cut");
+    hipLaunchKernelGGL(k_cut_weights, dim3(nb), dim3(256), 0, st, n, svals, length, passed, wts, pre_sorted);
+    FLX_CHECK(flx_exclusive_scan_i64(ctx, n, wts, excl, sort_tmp, sort_ws));
+    FLX_HIP(ctx, hipMemsetAsync(d_acc, 0, 16, st));
+
+    hipLaunchKernelGGL(k_cut_apply, dim3(nb), dim3(256), 0, st, n, svals, excl, wts, target, passed, d_acc, d_acc + 1);
+    flx_time_end(ctx);
+    unsigned long long h_acc[2] = {0, 0};
+    FLX_HIP(ctx, hipMemcpyAsync(h_acc, d_acc, 16, hipMemcpyDeviceToHost, st));
+    FLX_HIP(ctx, hipStreamSynchronize(st));
+    rep->kept_bases = (int64_t)h_acc[0];
+
+    // ---- boundary audit ------------------------------------------------------------------------
+    // p = sorted position of the read that crossed the target.  Every read whose DEVICE score is within
+    // a relative band of score[p] could be ordered differently by the reference (host libm pow); re-score
+    // those with the host libm and re-decide the cut among them.
+    if (h_acc[1] == 0) return FLX_OK;  // nothing kept (cannot happen when target > 0 and passed_bases > target)
+    const uint64_t pstar = h_acc[1] - 1;
+    const double kBand = 1e-11;  // relative; device pow is good to a few ulp (1e-16), so this is generous
+    const uint64_t W = 256;
+    uint64_t lo = pstar > W ? pstar - W : 0, hi = std::min<uint64_t>(n, pstar + W + 1);
+    for (;;) {
+        const uint64_t m = hi - lo;
+        std::vector<uint64_t> hk(m);
+        std::vector<uint32_t> hv(m);
+        std::vector<int64_t> hex(m);
+        FLX_HIP(ctx, hipMemcpy(hk.data(), skeys + lo, m * 8, hipMemcpyDeviceToHost));
+        FLX_HIP(ctx, hipMemcpy(hv.data(), svals + lo, m * 4, hipMemcpyDeviceToHost));
+        FLX_HIP(ctx, hipMemcpy(hex.data(), excl + lo, m * 8, hipMemcpyDeviceToHost));
+        auto key_to_score = [](uint64_t k) {
+            uint64_t a = ~k;  // ascending key
+            uint64_t b = (a >> 63) ? (a & 0x7fffffffffffffffull) : ~a;
+            double v;
+            memcpy(&v, &b, 8);
+            return v;
+        };
+        const double sp = key_to_score(hk[pstar - lo]);
+        if (std::isnan(sp)) {
+            // NaN scores (stdev == 0, main.cpp:192-195 then 0/0): every comparison is false, the order is the
+            // reference's tie order -> host path.
+            return exact_host_cut(ctx, n, mean, window, length, passed, svals, pre_sorted, s, target, rep);
+        }
+        const double band = std::fabs(sp) * kBand + 1e-300;
+        // band limits inside the window
+        uint64_t a = pstar - lo, b = pstar - lo;
+        while (a > 0 && std::fabs(key_to_score(hk[a - 1]) - sp) <= band) --a;
+        while (b + 1 < m && std::fabs(key_to_score(hk[b + 1]) - sp) <= band) ++b;
+        const bool open_lo = (a == 0 && lo > 0), open_hi = (b + 1 == m && hi < n);
+        if (open_lo || open_hi) {  // band reaches the window edge: widen and retry
+            const uint64_t grow = (hi - lo) * 4;
+            lo = lo > grow ? lo - grow : 0;
+            hi = std::min<uint64_t>(n, hi + grow);
+            continue;
+        }
+        const uint64_t nb_band = b - a + 1;
+        rep->audited = nb_band;
+        if (nb_band == 1) return FLX_OK;  // only the crossing read itself: nothing can reorder
+
+        // gather the band's inputs, re-score with the host libm
+        struct Cand { uint32_t idx; double score; int32_t len; uint8_t was_passed; uint64_t pos; };
+        std::vector<Cand> cand(nb_band);
+        for (uint64_t i = 0; i < nb_band; ++i) {
+            Cand &c = cand[i];
+            c.idx = hv[a + i];
+            c.pos = lo + a + i;
+            double mq, wq;
+            FLX_HIP(ctx, hipMemcpy(&mq, mean + c.idx, 8, hipMemcpyDeviceToHost));
+            FLX_HIP(ctx, hipMemcpy(&wq, window + c.idx, 8, hipMemcpyDeviceToHost));
+            FLX_HIP(ctx, hipMemcpy(&c.len, length + c.idx, 4, hipMemcpyDeviceToHost));
+            FLX_HIP(ctx, hipMemcpy(&c.was_passed, pre_sorted + c.pos, 1, hipMemcpyDeviceToHost));
+            c.score = host_final_score(c.len, mq, wq, s);
+        }
+        // exact order inside the band: descending exact score; equal exact scores keep... the reference's
+        // std::sort tie order, which only the full host path can reproduce.
+        std::vector<uint64_t> ord(nb_band);
+        std::iota(ord.begin(), ord.end(), 0ull);
+        std::stable_sort(ord.begin(), ord.end(), [&](uint64_t x, uint64_t y) { return cand[x].score > cand[y].score; });
+        // walk
+        long long so_far = hex[a];
+        std::vector<uint8_t> keep(nb_band, 0);
+        for (uint64_t k = 0; k < nb_band; ++k) {
+            Cand &c = cand[ord[k]];
+            if (c.was_passed && so_far < target) { so_far += c.len; keep[ord[k]] = 1; }
+        }
+        // tie check: a group of equal exact scores whose passed members got different decisions -> only the
+        // reference's own std::sort tie order can say which of them crossed the target
+        bool tie_straddle = false;
+        for (uint64_t k = 0; k < nb_band;) {
+            uint64_t e = k;
+            int kept_n = 0, passed_n = 0;
+            while (e < nb_band && cand[ord[e]].score == cand[ord[k]].score) {
+                if (cand[ord[e]].was_passed) { ++passed_n; kept_n += keep[ord[e]]; }
+                ++e;
+            }
+            if (kept_n != 0 && kept_n != passed_n) tie_straddle = true;
+            k = e;
+        }
+        if (tie_straddle)
+            return exact_host_cut(ctx, n, mean, window, length, passed, svals, pre_sorted, s, target, rep);
+        // patch flags of the band; reads after the band all fail, reads before it are unchanged
+        for (uint64_t i = 0; i < nb_band; ++i) {
+            const uint8_t v = keep[i];
+            FLX_HIP(ctx, hipMemcpy(passed + cand[i].idx, &v, 1, hipMemcpyHostToDevice));
+        }
+        rep->kept_bases = so_far;
+        return FLX_OK;
+    }
+}
+
+extern "C" int flx_rank_and_cut(flx_ctx *ctx, uint64_t n, const double *mean_q, const double *window_q,
+                                const int32_t *length, uint8_t *passed, double lw, double mw, double ww,
+                                int target_bases_set, int64_t target_bases, int keep_percent_set, double keep_percent,
+                                int64_t total_bases, double *final_score, flx_cut_report *rep) {
+    if (!ctx) return FLX_ERR_INVALID;
+    if (n && (!mean_q || !window_q || !length || !passed)) return flx_fail(ctx, FLX_ERR_INVALID, "NULL input array");
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    flx_dbuf d_mean, d_win, d_len, d_pass, d_fs;
+    FLX_CHECK(flx_dalloc(ctx, d_mean, n * 8));
+    FLX_CHECK(flx_dalloc(ctx, d_win, n * 8));
+    FLX_CHECK(flx_dalloc(ctx, d_len, n * 4));
+    FLX_CHECK(flx_dalloc(ctx, d_pass, n));
+    if (final_score) FLX_CHECK(flx_dalloc(ctx, d_fs, n * 8));
+    if (n) {
+        FLX_HIP(ctx, hipMemcpyAsync(d_mean.p, mean_q, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        FLX_HIP(ctx, hipMemcpyAsync(d_win.p, window_q, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        FLX_HIP(ctx, hipMemcpyAsync(d_len.p, length, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        FLX_HIP(ctx, hipMemcpyAsync(d_pass.p, passed, n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    FLX_CHECK(flx_rank_and_cut_dev(ctx, n, d_mean.p, d_win.p, d_len.p, d_pass.p, lw, mw, ww, target_bases_set,
+                                   target_bases, keep_percent_set, keep_percent, total_bases,
+                                   final_score ? d_fs.p : nullptr, rep));
+    if (n) {
+        FLX_HIP(ctx, hipMemcpyAsync(passed, d_pass.p, n, hipMemcpyDeviceToHost, ctx->stream));
+        if (final_score) FLX_HIP(ctx, hipMemcpyAsync(final_score, d_fs.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FLX_OK;
+}

@@ -1,0 +1,23 @@
+// rank_internal.h — building blocks of the global stage (seam 3), internal to the library.
+#pragma once
+#include "flx_internal.h"
+
+// a20: min / max / mean / stdev of the mean qualities exactly as the reference's serial FP64 folds
+// compute them (src/main.cpp:170-186).
+struct flx_stats {
+    double min, max, sum, mean, sq_sum, stdev;
+};
+int flx_exact_stats(flx_ctx *ctx, uint64_t n, const double *d_mean_q, flx_stats *out);
+
+// Stable LSD radix sort of (u64 key, u32 value) pairs, ascending by key.  keys0/vals0 hold the input;
+// keys1/vals1 are the ping-pong buffers; *sorted_keys / *sorted_vals point at whichever buffer holds
+// the result.  Runs on ctx->stream (asynchronous).
+size_t flx_radix_sort_workspace(uint64_t n);
+int flx_radix_sort_pairs(flx_ctx *ctx, uint64_t n, uint64_t *keys0, uint64_t *keys1, uint32_t *vals0, uint32_t *vals1,
+                         void *workspace, size_t workspace_bytes, uint64_t **sorted_keys, uint32_t **sorted_vals);
+
+// out[i] = sum_{j<i} in[j]   (int64, exact).  workspace >= flx_radix_sort_workspace(n) suffices.
+int flx_exclusive_scan_i64(flx_ctx *ctx, uint64_t n, const int64_t *in, int64_t *out, void *workspace,
+                           size_t workspace_bytes);
+int flx_exclusive_scan_u32(flx_ctx *ctx, uint64_t n, const uint32_t *in, uint32_t *out, void *workspace,
+                           size_t workspace_bytes);

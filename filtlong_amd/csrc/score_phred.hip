@@ -1,0 +1,379 @@
+// score_phred.hip — Phred-only per-read scoring on gfx950.
+//
+// Replaces, for a whole batch of reads, the Phred branch of the reference's Read::Read
+// (src/read.cpp:35-39), get_mean_quality (208-213), get_window_quality (216-236) and the hard
+// cut-offs (64-73).  Results are bit-identical to the reference: the two FP64 recurrences are
+// order-dependent (the drift is part of the result), so each read is folded strictly
+// left to right by ONE lane; the parallelism is across reads (64 reads per wavefront).
+//
+// Data movement (HBM-bound part): the packed quality plane is read exactly once, with 16-byte
+// loads.  A wavefront serves 64 reads; per round it fetches CH contiguous bytes of each of its reads
+// (lane -> (read, 16-byte piece) mapping, so every load instruction covers 16 reads x 64 B) and
+// transposes them through a per-read LDS ring so that each lane can then stream its own read.  The
+// ring also keeps the last `window_size` bytes of every read, which is what the trailing edge of the
+// sliding window re-reads — the plane is never fetched twice.
+//
+// Arithmetic: per base one 8-byte LDS lookup of Q[c] = 1 - 10^(-(c-33)/10) and two of D[c] = Q[c]/ws
+// (tables built on the host with the host libm; see flx_ctx.hip) and four dependent FP64 ops
+// (sum += Q; w -= D_old; w += D_new; min).  No pow, no division, no 8 B/base quality vector.
+#include "flx_internal.h"
+
+namespace {
+
+constexpr int CH = 64;        // bytes staged per read per round
+constexpr int PPR = CH / 16;  // 16-byte pieces per read per round (= loads per lane per round)
+constexpr int LUT_PAD = 264;  // doubles per table in LDS (257 used)
+
+struct PhredArgs {
+    const uint8_t *plane;
+    const uint64_t *offsets;
+    const int32_t *lengths;
+    const uint32_t *order;
+    uint64_t n_reads;
+    const double *lut_q;
+    const double *lut_d;
+    int ws;
+    int n_slots;  // ring slots of CH bytes: ceil(ws / CH) + 1
+    int stride;   // bytes per read row in the ring (odd multiple of 16: conflict-free b128 rows)
+    double ws_d;
+    double clamp;  // 0.5 / ws   (src/read.cpp:233)
+    flx_params p;
+    double *mean_q;
+    double *window_q;
+    uint8_t *passed;
+};
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+__device__ __forceinline__ uint32_t byte_of(const uint4 &v, int i) {
+    const uint32_t d = (i >> 2) == 0 ? v.x : (i >> 2) == 1 ? v.y : (i >> 2) == 2 ? v.z : v.w;
+    return (d >> (8 * (i & 3))) & 0xffu;
+}
+
+// hard cut-offs, src/read.cpp:64-73 (pre-normalisation 0-100 values; NaN compares false)
+__device__ __forceinline__ uint8_t hard_cutoffs(const flx_params &p, int L, double mean, double window) {
+    bool ok = true;
+    if (p.min_length_set && L < p.min_length) ok = false;
+    else if (p.max_length_set && L > p.max_length) ok = false;
+    else if (p.min_mean_q_set && mean < p.min_mean_q) ok = false;
+    else if (p.min_window_q_set && window < p.min_window_q) ok = false;
+    return ok ? 1 : 0;
+}
+
+__device__ __forceinline__ void finish_read(const PhredArgs &a, uint32_t rid, int L, double s, double mn) {
+    const double mean = 100.0 * s / (double)L;  // (100*s)/n, src/read.cpp:212; L == 0 -> NaN
+    double window;
+    if (L <= a.ws) window = mean;               // src/read.cpp:217-218
+    else {
+        if (mn < a.clamp) mn = 0.0;             // src/read.cpp:233-234
+        window = 100.0 * mn;
+    }
+    a.mean_q[rid] = mean;
+    a.window_q[rid] = window;
+    a.passed[rid] = hard_cutoffs(a.p, L, mean, window);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ring kernel: the fast path (window_size small enough for the LDS ring)
+// ---------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *lq = reinterpret_cast<double *>(smem);
+    double *ld = lq + LUT_PAD;
+    unsigned char *rings = smem + 2 * LUT_PAD * sizeof(double);
+
+    for (int i = threadIdx.x; i < 257; i += WAVES * 64) {
+        lq[i] = a.lut_q[i];
+        ld[i] = a.lut_d[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int stride = a.stride;
+    const int NS = a.n_slots;
+    const int ws = a.ws;
+    unsigned char *ring = rings + (size_t)wave * 64 * stride;
+    unsigned char *my_row = ring + lane * stride;
+
+    const uint64_t slot = ((uint64_t)blockIdx.x * WAVES + wave) * 64 + lane;
+    const bool live = slot < a.n_reads;
+    uint32_t rid = 0;
+    int L = 0;
+    uint64_t base = 0;
+    if (live) {
+        rid = a.order ? a.order[slot] : (uint32_t)slot;
+        L = a.lengths[rid];
+        base = a.offsets[rid];
+    }
+    const int Lmax = wave_max(L);
+    const int Lmin = wave_min(L);
+    if (Lmax == 0) {
+        if (live) finish_read(a, rid, L, 0.0, 0.0);
+        return;
+    }
+
+    // staging map: load m of this lane fetches piece k of read r
+    const int k = lane & (PPR - 1);
+    uint64_t src_base[PPR];
+    int src_l16[PPR];
+    int dst_off[PPR];
+#pragma unroll
+    for (int m = 0; m < PPR; ++m) {
+        const int r = m * (64 / PPR) + (lane / PPR);
+        const uint32_t lo = __shfl((uint32_t)base, r, 64);
+        const uint32_t hi = __shfl((uint32_t)(base >> 32), r, 64);
+        src_base[m] = (((uint64_t)hi << 32) | lo) + (uint64_t)(k * 16);
+        src_l16[m] = ((__shfl(L, r, 64) + 15) & ~15) - k * 16;  // piece valid at round offset o iff o < src_l16
+        dst_off[m] = r * stride + k * 16;
+    }
+
+    uint4 pre[PPR];
+    auto issue_loads = [&](int t) {
+#pragma unroll
+        for (int m = 0; m < PPR; ++m) {
+            const int o = t * CH;
+            if (o < src_l16[m]) pre[m] = *reinterpret_cast<const uint4 *>(a.plane + src_base[m] + (uint64_t)o);
+            else pre[m] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto write_ring = [&](int ring_slot) {
+#pragma unroll
+        for (int m = 0; m < PPR; ++m) *reinterpret_cast<uint4 *>(ring + dst_off[m] + ring_slot * CH) = pre[m];
+    };
+    // ring byte offset of stream position p (wave-uniform, p >= 0)
+    auto ring_off = [&](int p) { return ((p / CH) % NS) * CH + (p % CH); };
+
+    double s = 0.0, w = 0.0, mn = 0.0;
+    const int n_rounds = (Lmax + CH - 1) / CH;
+    const int tshift = (16 - (ws & 15)) & 15;  // byte offset of the trailing stream inside its aligned piece
+
+    issue_loads(0);
+    write_ring(0);
+    __builtin_amdgcn_wave_barrier();
+
+    int lslot = 0;       // ring slot of the current round
+    int carry_pos = -1;  // aligned stream position whose 16 bytes are held in `carry`
+    uint4 carry = make_uint4(0, 0, 0, 0);
+
+    for (int t = 0; t < n_rounds; ++t) {
+        const bool more = t + 1 < n_rounds;
+        if (more) issue_loads(t + 1);
+
+#pragma unroll 1
+        for (int kk = 0; kk < PPR; ++kk) {
+            const int j0 = t * CH + kk * 16;
+            if (j0 >= Lmax) break;
+            const uint4 lead = *reinterpret_cast<const uint4 *>(my_row + lslot * CH + kk * 16);
+            const uint32_t lw[4] = {lead.x, lead.y, lead.z, lead.w};
+
+            if (j0 + 16 <= Lmin && j0 + 16 <= ws) {
+                // ---- pure head: only the running sum ----
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t cj = (lw[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                    s += lq[cj];
+                }
+                if (j0 + 16 == ws) {
+                    w = s / a.ws_d;  // src/read.cpp:223
+                    mn = w;
+                }
+            } else if (j0 + 16 <= Lmin && j0 >= ws) {
+                // ---- pure body: all 16 positions valid in every lane ----
+                const int ta = (j0 - ws) & ~15;
+                if (carry_pos != ta) {
+                    carry = *reinterpret_cast<const uint4 *>(my_row + ring_off(ta));
+                    carry_pos = ta;
+                }
+                uint32_t tw[4];
+                if (tshift == 0) {
+                    tw[0] = carry.x; tw[1] = carry.y; tw[2] = carry.z; tw[3] = carry.w;
+                    // next piece's trailing data starts at ta + 16
+                    carry_pos = -1;
+                } else {
+                    const uint4 nxt = *reinterpret_cast<const uint4 *>(my_row + ring_off(ta + 16));
+                    const uint32_t x[8] = {carry.x, carry.y, carry.z, carry.w, nxt.x, nxt.y, nxt.z, nxt.w};
+                    const int dsh = tshift >> 2;         // wave-uniform dword shift 0..3
+                    const uint32_t bsh = tshift & 3;     // byte shift inside the dword
+                    uint32_t y[5];
+                    switch (dsh) {
+                        case 0: y[0] = x[0]; y[1] = x[1]; y[2] = x[2]; y[3] = x[3]; y[4] = x[4]; break;
+                        case 1: y[0] = x[1]; y[1] = x[2]; y[2] = x[3]; y[3] = x[4]; y[4] = x[5]; break;
+                        case 2: y[0] = x[2]; y[1] = x[3]; y[2] = x[4]; y[3] = x[5]; y[4] = x[6]; break;
+                        default: y[0] = x[3]; y[1] = x[4]; y[2] = x[5]; y[3] = x[6]; y[4] = x[7]; break;
+                    }
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) tw[d] = __builtin_amdgcn_alignbyte(y[d + 1], y[d], bsh);
+                    carry = nxt;
+                    carry_pos = ta + 16;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t cj = (lw[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                    const uint32_t ci = (tw[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                    const double qj = lq[cj];
+                    const double dj = ld[cj];
+                    const double di = ld[ci];
+                    s += qj;
+                    w -= di;  // src/read.cpp:228
+                    w += dj;  // src/read.cpp:229
+                    if (w < mn) mn = w;
+                }
+            } else {
+                // ---- generic piece: straddles window_size or the end of some read in this wave ----
+#pragma unroll 1
+                for (int i = 0; i < 16; ++i) {
+                    const int j = j0 + i;
+                    if (j >= Lmax) break;
+                    const bool act = j < L;
+                    const uint32_t cj = act ? byte_of(lead, i) : 256u;
+                    s += lq[cj];
+                    if (j == ws - 1) {
+                        w = s / a.ws_d;
+                        mn = w;
+                    }
+                    if (j >= ws) {
+                        const uint32_t tb = my_row[ring_off(j - ws)];
+                        const uint32_t ci = act ? tb : 256u;
+                        w -= ld[ci];
+                        w += ld[cj];
+                        if (w < mn) mn = w;
+                    }
+                }
+            }
+        }
+
+        if (more) {
+            lslot = (lslot + 1 == NS) ? 0 : lslot + 1;
+            write_ring(lslot);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (live) finish_read(a, rid, L, s, mn);
+}
+
+// ---------------------------------------------------------------------------------------------
+// direct kernel: any window size, one lane per read straight from global memory.  Used when the
+// window does not fit the LDS ring (window_size > ~2000) and as an independent second
+// implementation in the tests.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) flx_score_phred_direct(const PhredArgs a) {
+    __shared__ double lq[LUT_PAD];
+    __shared__ double ld[LUT_PAD];
+    for (int i = threadIdx.x; i < 257; i += 256) {
+        lq[i] = a.lut_q[i];
+        ld[i] = a.lut_d[i];
+    }
+    __syncthreads();
+    const uint64_t slot = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= a.n_reads) return;
+    const uint32_t rid = a.order ? a.order[slot] : (uint32_t)slot;
+    const int L = a.lengths[rid];
+    const uint8_t *q = a.plane + a.offsets[rid];
+    const int ws = a.ws;
+    double s = 0.0, w = 0.0, mn = 0.0;
+    const int head = L < ws ? L : ws;
+    for (int i = 0; i < head; ++i) s += lq[q[i]];
+    if (L > ws) {
+        w = s / a.ws_d;
+        mn = w;
+        for (int j = ws; j < L; ++j) {
+            const uint32_t cj = q[j], ci = q[j - ws];
+            s += lq[cj];
+            w -= ld[ci];
+            w += ld[cj];
+            if (w < mn) mn = w;
+        }
+    }
+    finish_read(a, rid, L, s, mn);
+}
+
+}  // namespace
+
+// LDS budget: one workgroup per CU, as many independent waves as fit (each wave owns a ring).
+static constexpr size_t kLdsBudget = 160 * 1024;
+static constexpr size_t kLutBytes = 2 * LUT_PAD * sizeof(double);
+
+int flx_launch_score_phred(flx_ctx *ctx, const uint8_t *d_plane, uint64_t plane_bytes, const uint64_t *d_offsets,
+                           const int32_t *d_lengths, const uint32_t *d_order, uint64_t n_reads,
+                           const flx_params *p, flx_score_out_dev out) {
+    (void)plane_bytes;
+    if (n_reads == 0) return FLX_OK;
+    if (p->window_size <= 0) return flx_fail(ctx, FLX_ERR_INVALID, "window_size must be positive");
+    FLX_CHECK(flx_ensure_lut_d(ctx, p->window_size));
+
+    PhredArgs a;
+    a.plane = d_plane;
+    a.offsets = d_offsets;
+    a.lengths = d_lengths;
+    a.order = d_order;
+    a.n_reads = n_reads;
+    a.lut_q = ctx->d_lut_q;
+    a.lut_d = ctx->d_lut_d;
+    a.ws = p->window_size;
+    a.ws_d = (double)(size_t)p->window_size;
+    {
+        volatile double half = 0.5, wsd = a.ws_d;
+        a.clamp = half / wsd;
+    }
+    a.p = *p;
+    a.mean_q = out.mean_q;
+    a.window_q = out.window_q;
+    a.passed = out.passed;
+
+    const long long n_slots = ((long long)p->window_size + CH - 1) / CH + 1;
+    long long slots16 = n_slots * CH / 16;
+    if ((slots16 & 1) == 0) slots16 += 1;  // odd number of 16-byte slots per row: b128 rows never collide
+    const size_t ring_bytes = (size_t)64 * slots16 * 16;
+
+    const uint64_t n_waves = (n_reads + 63) / 64;
+    int waves = (int)((kLdsBudget - kLutBytes) / ring_bytes);
+    const char *env = getenv("FLX_PHRED_KERNEL");  // test hook: "direct" forces the fallback kernel
+    const bool force_direct = env && strcmp(env, "direct") == 0;
+
+    if (waves >= 1 && !force_direct) {
+        if (waves > 7) waves = 7;
+        a.n_slots = (int)n_slots;
+        a.stride = (int)(slots16 * 16);
+        const size_t lds = kLutBytes + (size_t)waves * ring_bytes;
+        const unsigned grid = (unsigned)((n_waves + waves - 1) / waves);
+#define FLX_LAUNCH_RING(W)                                                                                    \
+    case W: {                                                                                                 \
+        FLX_HIP(ctx, hipFuncSetAttribute((const void *)flx_score_phred_ring<W>,                               \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+        flx_time_begin(ctx, "flx_score_phred_ring");                                                          \
+        hipLaunchKernelGGL(flx_score_phred_ring<W>, dim3(grid), dim3(W * 64), lds, ctx->stream, a);           \
+        flx_time_end(ctx);                                                                                    \
+    } break;
+        switch (waves) {
+            FLX_LAUNCH_RING(1)
+            FLX_LAUNCH_RING(2)
+            FLX_LAUNCH_RING(3)
+            FLX_LAUNCH_RING(4)
+            FLX_LAUNCH_RING(5)
+            FLX_LAUNCH_RING(6)
+            FLX_LAUNCH_RING(7)
+        }
+#undef FLX_LAUNCH_RING
+    } else {
+        a.n_slots = 0;
+        a.stride = 0;
+        const unsigned grid = (unsigned)((n_reads + 255) / 256);
+        flx_time_begin(ctx, "flx_score_phred_direct");
+        hipLaunchKernelGGL(flx_score_phred_direct, dim3(grid), dim3(256), 0, ctx->stream, a);
+        flx_time_end(ctx);
+    }
+    FLX_HIP(ctx, hipGetLastError());
+    return FLX_OK;
+}

@@ -1,0 +1,61 @@
+// synth.hip — deterministic synthetic Phred planes generated directly in HBM (bench / test support).
+// Same integer-only definition as filtlong_amd/synth.py and oracle/synth.h; stands in
+// for the reference's test/make_synthetic_reads.py, which needs PBSIM/wgsim.
+#include "flx_internal.h"
+
+namespace {
+
+__device__ __forceinline__ uint64_t mix(uint64_t seed, uint64_t stream, uint64_t read, uint64_t pos) {
+    uint64_t z = seed ^ (stream * 0x9E3779B97F4A7C15ULL) ^ (read * 0xBF58476D1CE4E5B9ULL) ^ (pos * 0x94D049BB133111EBULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// one block per read-chunk: grid.x walks reads, each thread writes 16 bytes (4 hashes) per step
+__global__ void __launch_bounds__(256) k_synth_qual(uint64_t seed, uint8_t *plane, const uint64_t *offsets,
+                                                    const int32_t *lengths, const uint64_t *read_ids, uint64_t n) {
+    for (uint64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const uint64_t gid = read_ids ? read_ids[r] : r;
+        const int L = lengths[r];
+        const int mu = 8 + (int)(mix(seed, 2, gid, 0) % 18);
+        uint8_t *dst = plane + offsets[r];
+        const int L16 = (L + 15) & ~15;
+        for (int p0 = threadIdx.x * 16; p0 < L16; p0 += 256 * 16) {
+            uint32_t w[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint64_t h = mix(seed, 3, gid, (uint64_t)(p0 >> 2) + g);
+                uint32_t packed = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t f = (uint32_t)(h >> (16 * b)) & 0xffffu;
+                    int q = mu + (int)((f & 0xff) % 9) - 4 + (int)((f >> 8) % 9) - 4;
+                    q = q < 1 ? 1 : (q > 60 ? 60 : q);
+                    const int pos = p0 + g * 4 + b;
+                    const uint32_t byte = pos < L ? (uint32_t)(q + 33) : 0u;  // padding bytes are zero
+                    packed |= byte << (8 * b);
+                }
+                w[g] = packed;
+            }
+            *reinterpret_cast<uint4 *>(dst + p0) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int flx_synth_qual_dev(flx_ctx *ctx, uint64_t seed, void *d_plane, uint64_t plane_bytes,
+                                  const void *d_offsets, const void *d_lengths, const void *d_read_ids,
+                                  uint64_t n_reads) {
+    if (!ctx) return FLX_ERR_INVALID;
+    (void)plane_bytes;
+    if (n_reads == 0) return FLX_OK;
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_reads, 65535ull * 16);
+    hipLaunchKernelGGL(k_synth_qual, dim3(grid), dim3(256), 0, ctx->stream, seed, (uint8_t *)d_plane,
+                       (const uint64_t *)d_offsets, (const int32_t *)d_lengths, (const uint64_t *)d_read_ids, n_reads);
+    FLX_HIP(ctx, hipGetLastError());
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FLX_OK;
+}

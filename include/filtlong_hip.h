@@ -1,0 +1,208 @@
+/* filtlong_hip.h — C ABI of the MI355X-native Filtlong scoring hot path.
+ *
+ * This is the drop-in boundary: a C-ABI shared library (libfiltlong_hip.so, gfx950) whose entry
+ * points replace, in batched form, the in-process seams of the reference (rrwick/Filtlong v0.3.1;
+ * paths below are relative to the reference root):
+ *
+ *   seam 1  reference 16-mer set build      Kmers::Kmers / add_assembly_fasta / add_read_fastqs /
+ *                                           is_kmer_present / empty        src/kmers.h:31-44
+ *   seam 2  per-read scoring                Read::Read(name, seq, qscores, length, Kmers*, Arguments*)
+ *                                           and its public result fields   src/read.h:32-56
+ *   seam 3  global rank + cut               the statistics / normalise / set_final_score /
+ *                                           std::sort / cut walk inlined in main()
+ *                                                                          src/main.cpp:169-261
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types cross the boundary;
+ *   - every function returns an int status (FLX_OK == 0); no exceptions cross the boundary;
+ *     flx_last_error(ctx) gives the message (the CLI prints it as "Error: ..." and exits 1,
+ *     mirroring src/main.cpp:80-116);
+ *   - one flx_ctx per process / rank / GPU; not thread-safe; calls are synchronous on return
+ *     unless the name ends in _async;
+ *   - `*_dev` variants take DEVICE pointers (HBM-resident data, e.g. a torch tensor's data_ptr())
+ *     and run on the context's stream; the plain variants take HOST pointers and stage through
+ *     the context's own device buffers;
+ *   - there is NO CPU fallback: if the HIP runtime or a gfx950 device is missing,
+ *     flx_ctx_create fails.
+ */
+#ifndef FILTLONG_HIP_H
+#define FILTLONG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLX_ABI_VERSION 1
+
+enum flx_status {
+    FLX_OK = 0,
+    FLX_ERR_INVALID = 1,     /* bad argument                                  */
+    FLX_ERR_HIP = 2,         /* HIP runtime error (message has the hipError)   */
+    FLX_ERR_NOMEM = 3,       /* host or device allocation failed              */
+    FLX_ERR_STATE = 4,       /* call order violated (e.g. set not finalized)  */
+    FLX_ERR_CAPACITY = 5,    /* caller-provided output capacity too small     */
+    FLX_ERR_NO_DEVICE = 6    /* no usable gfx950 device                       */
+};
+
+typedef struct flx_ctx flx_ctx;
+typedef struct flx_kmerset flx_kmerset;
+
+/* Hot-path parameters: the fields of the reference's Arguments that Read::Read consults
+ * (src/arguments.h:59-91; read in src/read.cpp:61-73,86-117).  *_set mirrors the reference's
+ * paired bools. */
+typedef struct flx_params {
+    int32_t window_size;                  /* --window_size, default 250 (src/arguments.cpp:205)   */
+    int32_t min_length_set, min_length;   /* --min_length                                          */
+    int32_t max_length_set, max_length;   /* --max_length                                          */
+    int32_t min_mean_q_set;               /* --min_mean_q                                          */
+    int32_t min_window_q_set;             /* --min_window_q                                        */
+    double min_mean_q;
+    double min_window_q;
+    int32_t trim;                         /* --trim                                                */
+    int32_t split_set, split;             /* --split                                               */
+    int32_t _pad;
+} flx_params;
+
+/* ------------------------------------------------------------------------------------------
+ * context
+ * ---------------------------------------------------------------------------------------- */
+int flx_abi_version(void);
+const char *flx_version(void);
+int flx_ctx_create(int device_ordinal, flx_ctx **out);
+void flx_ctx_destroy(flx_ctx *ctx);
+const char *flx_last_error(const flx_ctx *ctx); /* ctx may be NULL: last create error */
+/* Run all subsequent work of this context on the caller's hipStream_t (NULL = context's own). */
+int flx_ctx_set_stream(flx_ctx *ctx, void *hip_stream);
+int flx_ctx_synchronize(flx_ctx *ctx);
+/* Device properties the host side reports (name is copied, NUL-terminated). */
+int flx_ctx_device_info(const flx_ctx *ctx, char *name, size_t name_cap, int *n_cu, uint64_t *hbm_bytes);
+
+/* Per-kernel timing with HIP events on the context's stream (for bench.py's roofline line).
+ * While enabled, every launch of a hot kernel is bracketed by events; flx_timing_get drains them
+ * (synchronising) and returns total milliseconds and launch count for kernels whose name starts
+ * with `prefix` ("" = all). */
+int flx_timing_enable(flx_ctx *ctx, int on);
+int flx_timing_reset(flx_ctx *ctx);
+int flx_timing_get(flx_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches);
+
+/* ------------------------------------------------------------------------------------------
+ * seam 2 — per-read scoring      (replaces Read::Read, src/read.cpp:25-144)
+ *
+ * Packed input ("read plane"): one byte plane + per-read start offsets + lengths.
+ *   - Phred mode (set == NULL or empty): plane holds the QUALITY strings (the reference never
+ *     touches seq in this mode, src/read.cpp:35-39);
+ *   - k-mer mode: plane holds the SEQUENCE strings (qual is never touched, src/read.cpp:43-58).
+ *   - offsets[i] must be a multiple of 16 and plane_bytes a multiple of 16 covering
+ *     offsets[i] + round_up(lengths[i], 16) for every read (flx_plane_layout computes both).
+ *   - `order` (optional, may be NULL) is a permutation of [0, n): the processing order; pass the
+ *     reads sorted by DESCENDING length (flx_length_order) so that the 64 reads sharing a wavefront
+ *     finish together.  Results are always written in input order (index i = read i).
+ *
+ * Outputs per read i: mean_q, window_q (the 0-100 pre-normalisation values of m_mean_quality /
+ * m_window_quality), passed (m_passed after the hard cut-offs, src/read.cpp:64-73), and in k-mer
+ * mode first/last (m_first_base_in_kmer / m_last_base_in_kmer, src/read.cpp:75-84) plus the child
+ * reads produced by --trim/--split (src/read.cpp:86-141) in CSR form: children of read i are
+ * child_offsets[i] .. child_offsets[i+1]-1, each with its half-open 0-based (start,end) range and
+ * its own mean_q / window_q / passed.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct flx_scores {
+    double *mean_q;          /* [n]                                   */
+    double *window_q;        /* [n]                                   */
+    uint8_t *passed;         /* [n]                                   */
+    int32_t *first;          /* [n] or NULL (k-mer mode only)         */
+    int32_t *last;           /* [n] or NULL                           */
+    uint64_t *child_offsets; /* [n+1] or NULL (trim/split only)       */
+    int32_t *child_ranges;   /* [2*child_capacity] (start,end) pairs  */
+    double *child_mean_q;    /* [child_capacity]                      */
+    double *child_window_q;  /* [child_capacity]                      */
+    uint8_t *child_passed;   /* [child_capacity]                      */
+    uint64_t child_capacity; /* in: capacity of the child arrays      */
+    uint64_t n_children;     /* out: total children written           */
+} flx_scores;
+
+/* Layout helper: offsets[i] (16-byte aligned starts) and the padded plane size for given lengths. */
+int flx_plane_layout(const int32_t *lengths, uint64_t n_reads, uint64_t *offsets, uint64_t *plane_bytes);
+/* Processing order: indices sorted by descending length (stable). Host arrays. */
+int flx_length_order(const int32_t *lengths, uint64_t n_reads, uint32_t *order);
+
+int flx_score_batch(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *plane, uint64_t plane_bytes,
+                    const uint64_t *offsets, const int32_t *lengths, const uint32_t *order, uint64_t n_reads,
+                    const flx_params *params, flx_scores *out);
+
+/* Device-resident variant: every pointer (including those inside `out`) is a device pointer. */
+int flx_score_batch_dev(flx_ctx *ctx, const flx_kmerset *set, const void *d_plane, uint64_t plane_bytes,
+                        const void *d_offsets, const void *d_lengths, const void *d_order, uint64_t n_reads,
+                        const flx_params *params, flx_scores *out_dev);
+
+/* ------------------------------------------------------------------------------------------
+ * seam 3 — global rank + cut     (replaces src/main.cpp:169-261 + Read::set_final_score,
+ *                                 src/read.cpp:249-267)
+ *
+ * Arrays are in "reads2" order: file order with each trimmed/split parent replaced in place by
+ * its children (src/main.cpp:138-147).  `passed` is in/out: on return it holds the final pass
+ * flags after the --target_bases / --keep_percent cut.  total_bases counts ORIGINAL read lengths
+ * (src/main.cpp:89).  final_score (optional) receives the device-computed scores (the reference
+ * prints them only under --verbose, 2 decimals); the pass set itself is exact (see DESIGN.md,
+ * "boundary audit").
+ * ---------------------------------------------------------------------------------------- */
+enum flx_cut_outcome {
+    FLX_CUT_NONE = 0,          /* neither --target_bases nor --keep_percent given             */
+    FLX_CUT_NOT_ENOUGH = 1,    /* "not enough reads to reach target"          main.cpp:239-240 */
+    FLX_CUT_ALREADY_BELOW = 2, /* "reads already fall below target after filtering"   242-243 */
+    FLX_CUT_SORTED = 3         /* sorted and cut; kept_bases is "keeping N bp"        247-258 */
+};
+
+typedef struct flx_cut_report {
+    int64_t target_bases;
+    int64_t kept_bases;
+    int32_t outcome;
+    int32_t exact_fallback; /* 1 if a tie group straddled the cut and the host std::sort path decided */
+    double mean_quality, stdev_quality, min_z, max_z; /* main.cpp:170-196 */
+    uint64_t audited;       /* reads whose score was re-derived with the host libm at the boundary */
+} flx_cut_report;
+
+int flx_rank_and_cut(flx_ctx *ctx, uint64_t n, const double *mean_q, const double *window_q, const int32_t *length,
+                     uint8_t *passed, double length_weight, double mean_q_weight, double window_q_weight,
+                     int target_bases_set, int64_t target_bases, int keep_percent_set, double keep_percent,
+                     int64_t total_bases, double *final_score, flx_cut_report *report);
+
+int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean_q, const void *d_window_q,
+                         const void *d_length, void *d_passed, double length_weight, double mean_q_weight,
+                         double window_q_weight, int target_bases_set, int64_t target_bases, int keep_percent_set,
+                         double keep_percent, int64_t total_bases, void *d_final_score, flx_cut_report *report);
+
+/* ------------------------------------------------------------------------------------------
+ * seam 1 — reference 16-mer set   (replaces Kmers, src/kmers.cpp:28-172 + src/bloom_filter.h)
+ *
+ * Sequences are handed over packed: bases[offsets[i] .. offsets[i]+lengths[i]).  Call order for
+ * short reads must be the reference's: all of -1, then all of -2 (src/kmers.cpp:54-55); the
+ * ">= 4 copies, or 3 with a Bloom false positive" rule (src/kmers.cpp:142-166) is order
+ * dependent only through the Bloom filter, which is restated bit-exactly.
+ * After flx_kmerset_finalize the set is immutable.  An empty finalized set selects Phred mode,
+ * like Kmers::empty() (src/kmers.h:34, src/read.cpp:35).
+ * ---------------------------------------------------------------------------------------- */
+int flx_kmerset_create(flx_ctx *ctx, flx_kmerset **out);
+void flx_kmerset_destroy(flx_kmerset *set);
+int flx_kmerset_add_assembly(flx_kmerset *set, const uint8_t *bases, const uint64_t *offsets,
+                             const int64_t *lengths, uint64_t n_seqs);
+int flx_kmerset_add_short_reads(flx_kmerset *set, const uint8_t *bases, const uint64_t *offsets,
+                                const int64_t *lengths, uint64_t n_seqs);
+int flx_kmerset_finalize(flx_kmerset *set);
+uint64_t flx_kmerset_size(const flx_kmerset *set);
+int flx_kmerset_contains(const flx_kmerset *set, const uint32_t *kmers, uint64_t n, uint8_t *present);
+
+/* ------------------------------------------------------------------------------------------
+ * bench / test support: deterministic synthetic Phred planes generated directly in HBM
+ * (same integer hash as filtlong_amd/synth.py and oracle/synth.h).
+ * d_read_ids[i] is the global index of read i in the synthetic population.
+ * ---------------------------------------------------------------------------------------- */
+int flx_synth_qual_dev(flx_ctx *ctx, uint64_t seed, void *d_plane, uint64_t plane_bytes, const void *d_offsets,
+                       const void *d_lengths, const void *d_read_ids, uint64_t n_reads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FILTLONG_HIP_H */

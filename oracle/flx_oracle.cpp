@@ -489,3 +489,61 @@ extern "C" void flo_synth_bases(uint64_t seed, uint64_t stream, uint64_t read, u
                                 uint8_t *out) {
     for (uint64_t i = 0; i < length; ++i) out[i] = flx_synth_base(seed, stream, read, start + i);
 }
+
+// ---------------------------------------------------------------------------
+// bench support ("port" CPU baseline): score + rank n synthetic Phred-only reads
+// with the restatement above, in memory, timed.  Used by bench.py only when the
+// real reference harness (oracle/_ref/ref_bench) is not available.
+// ---------------------------------------------------------------------------
+#include <chrono>
+
+extern "C" int flo_bench_phred(uint64_t n, uint64_t seed, uint64_t first_read, int64_t target_bases,
+                               double *score_s, double *rank_s, int64_t *total_bases_out, int64_t *kept_out) {
+    using clk = std::chrono::steady_clock;
+    std::vector<int> len(n);
+    int64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        double g = 0.0;
+        for (int j = 0; j < 4; ++j) {
+            uint64_t h = flx_mix(seed, FLX_STREAM_LEN, first_read + i, j);
+            g += -log(((double)(h >> 11) + 0.5) / 9007199254740992.0);
+        }
+        long long L = llround(2500.0 * g);
+        len[i] = (int)std::min<long long>(std::max<long long>(L, 200), 200000);
+        total += len[i];
+    }
+    std::vector<char> plane((size_t)total + 1);
+    {
+        size_t off = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            flo_synth_qual(seed, first_read + i, (uint64_t)len[i], (uint8_t *)&plane[off]);
+            off += len[i];
+        }
+    }
+    flo_params p;
+    memset(&p, 0, sizeof p);
+    p.window_size = 250;
+    std::vector<double> mq(n), wq(n), fs(n);
+    std::vector<uint8_t> passed(n);
+    auto t0 = clk::now();
+    {
+        size_t off = 0;
+        std::vector<double> q;
+        flo_read_result r;
+        for (uint64_t i = 0; i < n; ++i) {
+            score_slice(nullptr, &plane[off], &plane[off], len[i], &p, q, &r);
+            mq[i] = r.mean_q; wq[i] = r.window_q; passed[i] = (uint8_t)r.passed;
+            off += len[i];
+        }
+    }
+    auto t1 = clk::now();
+    flo_cut_report rep;
+    flo_rank_and_cut(n, mq.data(), wq.data(), len.data(), passed.data(), 1.0, 1.0, 1.0, 1, target_bases, 0, 0.0, total,
+                     fs.data(), &rep);
+    auto t2 = clk::now();
+    *score_s = std::chrono::duration<double>(t1 - t0).count();
+    *rank_s = std::chrono::duration<double>(t2 - t1).count();
+    *total_bases_out = total;
+    *kept_out = rep.kept_bases;
+    return 0;
+}

@@ -86,6 +86,9 @@ uint64_t flo_synth_mix(uint64_t seed, uint64_t stream, uint64_t read, uint64_t p
 void flo_synth_qual(uint64_t seed, uint64_t read, uint64_t length, uint8_t *out);
 void flo_synth_bases(uint64_t seed, uint64_t stream, uint64_t read, uint64_t start, uint64_t length, uint8_t *out);
 
+int flo_bench_phred(uint64_t n, uint64_t seed, uint64_t first_read, int64_t target_bases, double *score_s,
+                    double *rank_s, int64_t *total_bases_out, int64_t *kept_out);
+
 #ifdef __cplusplus
 }
 #endif

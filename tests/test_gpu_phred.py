@@ -1,0 +1,112 @@
+"""HIP Phred scoring (flx_score_batch) vs the oracle and the reference's golden vectors — bit exact.
+
+Covers: every PHRED_PARAM_SETS window size (ring kernel and the direct fallback), edge lengths
+(0, 1, ws-1, ws, ws+1, 16-byte boundaries), arbitrary byte values (negative q), ragged batches,
+the reference's own fixture, hard cut-offs, processing order on/off.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import _cases
+import _oracle
+from filtlong_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def bits(a):
+    return np.asarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_same_f64(got, want, what):
+    g, w = bits(got), bits(want)
+    nan_g, nan_w = np.isnan(got), np.isnan(want)
+    assert (nan_g == nan_w).all(), what + ": NaN pattern differs"
+    bad = np.nonzero((g != w) & ~nan_w)[0]
+    assert len(bad) == 0, "%s: %d mismatches, first at %d: got %s want %s" % (
+        what, len(bad), bad[0], float(got[bad[0]]).hex(), float(want[bad[0]]).hex())
+
+
+def score_hip(ctx, reads, pkw, use_order=True):
+    plane, offsets, lengths = api.pack_reads([q for _, _, q in reads])
+    order = api.length_order(lengths) if use_order else None
+    return ctx.score_reads(plane, offsets, lengths, api.make_params(**pkw), order=order)
+
+
+@pytest.mark.parametrize("kernel", ["ring", "direct"])
+def test_golden_synth_phred(ctx, kernel, monkeypatch):
+    if kernel == "direct":
+        monkeypatch.setenv("FLX_PHRED_KERNEL", "direct")
+    gold = json.load(open(os.path.join(_cases.GOLDEN, "probe_synth_phred.json")))
+    reads = _cases.phred_reads()
+    for key, case in gold.items():
+        o = score_hip(ctx, reads, case["params"])
+        want_m = np.array([float.fromhex(r["mean_q"]) for r in case["reads"]])
+        want_w = np.array([float.fromhex(r["window_q"]) for r in case["reads"]])
+        assert_same_f64(o["mean_q"], want_m, key + " mean_q")
+        assert_same_f64(o["window_q"], want_w, key + " window_q")
+        assert list(o["passed"]) == [r["passed"] for r in case["reads"]], key
+        assert (o["first"] == -1).all() and (o["last"] == -1).all() and len(o["child_ranges"]) == 0
+
+
+def test_reference_fixture_phred(ctx):
+    reads = _oracle.read_fastx(os.path.join(_cases.FIXTURES, "test_sort.fastq"))
+    o = score_hip(ctx, reads, {})
+    exp = [("0x1.6765056776ee5p+6", "0x1.656d069f0b576p+6"), ("0x1.8bebf07f8e0a2p+6", "0x1.8bd0b23c524bfp+6"),
+           ("0x1.831476491630dp+6", "0x1.82b0ce9fc8fd7p+6")]
+    for i, (m, w) in enumerate(exp):
+        assert o["mean_q"][i] == float.fromhex(m) and o["window_q"][i] == float.fromhex(w)
+
+
+@pytest.mark.parametrize("ws", [250, 7, 64, 333])
+def test_random_batch_vs_oracle(ctx, ws):
+    """3000 seeded reads with gamma lengths: ragged waves, many rounds, both orders."""
+    n = 3000
+    lens = np.maximum(synth.lengths(n, first=777, seed=99) // 3, 1)
+    reads = [("r%d" % i, b"", synth.qual_read(10_000 + i, int(L), 99).tobytes()) for i, L in enumerate(lens)]
+    pkw = dict(window_size=ws, min_length=500, min_mean_q=80.0, min_window_q=55.0)
+    p = _oracle.make_params(**pkw)
+    want = [_oracle.score_read(None, q, p) for _, _, q in reads]
+    for use_order in (True, False):
+        o = score_hip(ctx, reads, pkw, use_order)
+        assert_same_f64(o["mean_q"], np.array([w["mean_q"] for w in want]), "mean_q")
+        assert_same_f64(o["window_q"], np.array([w["window_q"] for w in want]), "window_q")
+        assert (o["passed"] == np.array([w["passed"] for w in want], dtype=np.uint8)).all()
+
+
+def test_empty_batch_and_all_empty_reads(ctx):
+    o = score_hip(ctx, [], {})
+    assert len(o["mean_q"]) == 0
+    o = score_hip(ctx, [("a", b"", b""), ("b", b"", b"")], dict(min_length=1))
+    assert np.isnan(o["mean_q"]).all() and np.isnan(o["window_q"]).all() and list(o["passed"]) == [0, 0]
+
+
+def test_device_generator_matches_numpy(ctx):
+    """flx_synth_qual_dev (HBM) == filtlong_amd/synth.py (host), so full-size runs score known bytes."""
+    import torch
+    lens = np.array([1, 15, 16, 17, 250, 1000, 4097, 33], dtype=np.int32)
+    ids = np.array([0, 5, 9, 123456789, 2, 77, 1 << 33, 3], dtype=np.uint64)
+    plane, offsets, _ = api.pack_reads([b"\0" * int(L) for L in lens])
+    d_plane = torch.zeros(plane.nbytes, dtype=torch.uint8, device="cuda")
+    d_off = torch.from_numpy(offsets.astype(np.int64)).cuda()
+    d_len = torch.from_numpy(lens).cuda()
+    d_ids = torch.from_numpy(ids.astype(np.int64)).cuda()
+    torch.cuda.synchronize()
+    ctx.synth_qual_dev(synth.SEED, d_plane.data_ptr(), plane.nbytes, d_off.data_ptr(), d_len.data_ptr(),
+                       d_ids.data_ptr(), len(lens))
+    got = d_plane.cpu().numpy()
+    for i, L in enumerate(lens):
+        o = int(offsets[i])
+        assert (got[o:o + L] == synth.qual_read(int(ids[i]), int(L))).all(), i
+        assert (got[o + L:o + ((L + 15) & ~15)] == 0).all()

@@ -1,0 +1,111 @@
+"""HIP global stage (flx_rank_and_cut: exact statistics, normalise, final score, radix sort, cut, boundary
+audit) vs the oracle, which is itself pinned to the reference binary's outputs (tests/test_oracle_e2e.py).
+The pass set must be IDENTICAL; device final scores only order reads and are checked to 1e-12 relative.
+"""
+import numpy as np
+import pytest
+
+import _e2e_checks
+import _oracle
+import _pipeline
+from filtlong_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def random_reads2(n, seed, dup=0):
+    rng = np.random.RandomState(seed)
+    mean = rng.uniform(60, 99, n)
+    window = mean * rng.uniform(0.3, 1.05, n)
+    length = np.clip(rng.gamma(4, 2500, n), 1, None).astype(np.int32)
+    passed = (rng.random_sample(n) > 0.1).astype(np.uint8)
+    if dup:  # exact duplicates -> exact score ties
+        src = rng.randint(0, n, dup)
+        dst = rng.randint(0, n, dup)
+        mean[dst], window[dst], length[dst] = mean[src], window[src], length[src]
+    return mean, window, length, passed
+
+
+def compare(ctx, mean, window, length, passed, **kw):
+    want = _oracle.rank_and_cut(mean, window, length, passed, **{k: v for k, v in kw.items()})
+    got = ctx.rank_and_cut(mean, window, length, passed,
+                           length_weight=kw.get("lw", 1.0), mean_q_weight=kw.get("mw", 1.0),
+                           window_q_weight=kw.get("ww", 1.0), target_bases=kw.get("target_bases"),
+                           keep_percent=kw.get("keep_percent"), total_bases=kw.get("total_bases"))
+    rep = got["report"]
+    assert rep.outcome == want["outcome"]
+    assert rep.target_bases == want["target_bases"]
+    assert (got["passed"] == want["passed"]).all(), "pass set differs (%d reads)" % int((got["passed"] != want["passed"]).sum())
+    if want["outcome"] == 3:
+        assert rep.kept_bases == want["kept_bases"]
+    # statistics are bit exact
+    for a, b in ((rep.mean_quality, want["mean_quality"]), (rep.stdev_quality, want["stdev_quality"]),
+                 (rep.min_z, want["min_z"]), (rep.max_z, want["max_z"])):
+        assert a == b or (np.isnan(a) and np.isnan(b))
+    fs, wf = got["final_score"], want["final_score"]
+    ok = ~np.isnan(wf)
+    assert np.allclose(fs[ok], wf[ok], rtol=1e-12, atol=0)
+    return rep
+
+
+@pytest.mark.parametrize("n,seed", [(1, 1), (2, 2), (65, 3), (1000, 4), (4097, 5), (100_000, 6)])
+def test_random_vs_oracle(ctx, n, seed):
+    mean, window, length, passed = random_reads2(n, seed)
+    tot = int(length.astype(np.int64).sum())
+    for frac in (0.01, 0.33, 0.5, 0.9, 0.999):
+        compare(ctx, mean, window, length, passed, target_bases=max(1, int(tot * frac)))
+    compare(ctx, mean, window, length, passed, keep_percent=42.5)
+    compare(ctx, mean, window, length, passed, keep_percent=80.0, target_bases=tot // 3, lw=2.0, mw=0.5, ww=3.0)
+    compare(ctx, mean, window, length, passed)                       # no cut at all
+    compare(ctx, mean, window, length, passed, target_bases=tot)     # not enough reads
+    compare(ctx, mean, window, length, passed, target_bases=tot - 1, total_bases=tot)  # usually "already below"
+
+
+def test_million_reads(ctx):
+    mean, window, length, passed = random_reads2(1_000_000, 11)
+    tot = int(length.astype(np.int64).sum())
+    rep = compare(ctx, mean, window, length, passed, target_bases=tot // 2)
+    assert rep.exact_fallback == 0
+
+
+def test_ties_straddling_the_cut(ctx):
+    """Duplicate reads give exactly equal scores; wherever such a tie group straddles the cut the reference's
+    std::sort tie order decides (main.cpp:247-248) and the library must reproduce it."""
+    n = 3000
+    mean, window, length, passed = random_reads2(n, 21, dup=2500)
+    tot = int(length.astype(np.int64).sum())
+    fallbacks = 0
+    for t in np.linspace(tot * 0.05, tot * 0.95, 40):
+        fallbacks += compare(ctx, mean, window, length, passed, target_bases=int(t)).exact_fallback
+    assert fallbacks > 0
+
+
+def test_all_equal_quality_gives_nan_scores(ctx):
+    """stdev == 0 -> 0/0 (main.cpp:192-195,206): all scores NaN; must follow the reference's order, not crash."""
+    n = 500
+    rng = np.random.RandomState(3)
+    length = rng.randint(100, 5000, n).astype(np.int32)
+    compare(ctx, np.full(n, 77.0), np.full(n, 70.0), length, np.ones(n, np.uint8),
+            target_bases=int(length.sum()) // 2)
+
+
+def test_zero_and_negative_qualities(ctx):
+    mean, window, length, passed = random_reads2(5000, 31)
+    mean[:50] = 0.0
+    window[:50] = 0.0
+    mean[50:60] = -3.5  # negative mean quality: possible with Phred bytes below '!' 
+    compare(ctx, mean, window, length, passed, target_bases=int(length.astype(np.int64).sum()) // 2)
+
+
+def test_e2e_phred_goldens(ctx):
+    """Reference binary outputs for the Phred-only configurations (fixtures + seeded synthetic)."""
+    be = _pipeline.HipBackend(ctx)
+    n = _e2e_checks.check_all(be, only=lambda k: k.startswith("synth_phred") or k.startswith("sort|phred"))
+    assert n == 10 + 6
