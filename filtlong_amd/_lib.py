@@ -83,6 +83,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own HIP runtime.  When torch shares the process (tests, bench.py use it for
+    # device memory / torch.distributed), it must initialise first so that both sides talk to ONE runtime;
+    # loading ours first leaves torch unable to see the GPU.  Pure C/C++ callers are unaffected.
+    if os.environ.get("FLX_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)" % LIB_PATH)

@@ -58,7 +58,7 @@ __device__ __host__ inline double final_score_with(PowFn powfn, int length, doub
     double scale;
     if (mq > 0.0) {
         scale = wq / mq;
-        if (!(scale < 1.0)) scale = 1.0;  // std::min(x, 1.0): returns 1.0 unless x < 1.0 (NaN -> 1.0 as b<a is false)
+        if (1.0 < scale) scale = 1.0;  // std::min(x, 1.0) == (1.0 < x) ? 1.0 : x   (x NaN stays NaN)
     } else
         scale = 1.0;
     total = s.lw + s.mw + s.ww;
@@ -73,10 +73,12 @@ struct DevPow {
 };
 
 __global__ void k_final_score(uint64_t n, const double *mean_q, const double *window_q, const int32_t *length,
-                              NormArgs s, double *final_score, uint64_t *keys, uint32_t *vals) {
+                              NormArgs s, double *final_score, uint64_t *keys, uint32_t *vals,
+                              unsigned int *any_nan) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double f = final_score_with(DevPow(), length[i], mean_q[i], window_q[i], s);
+    if (any_nan && f != f) atomicOr(any_nan, 1u);
     if (final_score) final_score[i] = f;
     if (keys) {
         keys[i] = ~key_ascending(f);  // descending score == ascending key
@@ -251,7 +253,8 @@ extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean
         if (d_final_score) {
             flx_time_begin(ctx, "flx_rank_final_score");
             hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s,
-                               (double *)d_final_score, (uint64_t *)nullptr, (uint32_t *)nullptr);
+                               (double *)d_final_score, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                               (unsigned int *)nullptr);
             flx_time_end(ctx);
             FLX_HIP(ctx, hipStreamSynchronize(st));
         }
@@ -274,9 +277,10 @@ extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean
     unsigned long long *d_acc = (unsigned long long *)p; p += 256;
     void *sort_tmp = p;
 
+    FLX_HIP(ctx, hipMemsetAsync(d_acc, 0, 32, st));
     flx_time_begin(ctx, "flx_rank_final_score");
     hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s,
-                       (double *)d_final_score, keys0, vals0);
+                       (double *)d_final_score, keys0, vals0, (unsigned int *)(d_acc + 2));
     flx_time_end(ctx);
 
     // ---- a24: device radix sort (stable, descending score) -------------------------------------
@@ -288,14 +292,17 @@ extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean
     flx_time_begin(ctx, "flx_rank_cut");
     hipLaunchKernelGGL(k_cut_weights, dim3(nb), dim3(256), 0, st, n, svals, length, passed, wts, pre_sorted);
     FLX_CHECK(flx_exclusive_scan_i64(ctx, n, wts, excl, sort_tmp, sort_ws));
-    FLX_HIP(ctx, hipMemsetAsync(d_acc, 0, 16, st));
 
     hipLaunchKernelGGL(k_cut_apply, dim3(nb), dim3(256), 0, st, n, svals, excl, wts, target, passed, d_acc, d_acc + 1);
     flx_time_end(ctx);
-    unsigned long long h_acc[2] = {0, 0};
-    FLX_HIP(ctx, hipMemcpyAsync(h_acc, d_acc, 16, hipMemcpyDeviceToHost, st));
+    unsigned long long h_acc[3] = {0, 0, 0};
+    FLX_HIP(ctx, hipMemcpyAsync(h_acc, d_acc, 24, hipMemcpyDeviceToHost, st));
     FLX_HIP(ctx, hipStreamSynchronize(st));
     rep->kept_bases = (int64_t)h_acc[0];
+    // Any NaN score (stdev == 0 -> 0/0 at main.cpp:206, or 0/0 window ratios) makes the reference's comparator
+    // inconsistent; its outcome is then whatever libstdc++'s introsort does on reads2 order.  Reproduce exactly
+    // that on the host instead of guessing.
+    if (h_acc[2] & 1ull) return exact_host_cut(ctx, n, mean, window, length, passed, svals, pre_sorted, s, target, rep);
 
     // ---- boundary audit ------------------------------------------------------------------------
     // p = sorted position of the read that crossed the target.  Every read whose DEVICE score is within

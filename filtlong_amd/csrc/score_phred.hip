@@ -59,6 +59,24 @@ __device__ __forceinline__ uint32_t byte_of(const uint4 &v, int i) {
     return (d >> (8 * (i & 3))) & 0xffu;
 }
 
+// byte `b` of dword x, times 8: the LDS byte offset of that Phred value's table entry.  One SDWA shift.
+__device__ __forceinline__ uint32_t lut_addr(uint32_t x, int b) {
+    uint32_t r;
+    const uint32_t three = 3;
+    switch (b) {
+        case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(x)); break;
+        case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(three), "v"(x)); break;
+        case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(three), "v"(x)); break;
+        default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(three), "v"(x)); break;
+    }
+    return r;
+}
+
+// 8-byte LDS table load at a byte offset (the offset already carries the x8 scaling)
+__device__ __forceinline__ double lds_f64(const double *table, uint32_t byte_off) {
+    return *reinterpret_cast<const double *>(reinterpret_cast<const unsigned char *>(table) + byte_off);
+}
+
 // hard cut-offs, src/read.cpp:64-73 (pre-normalisation 0-100 values; NaN compares false)
 __device__ __forceinline__ uint8_t hard_cutoffs(const flx_params &p, int L, double mean, double window) {
     bool ok = true;
@@ -87,10 +105,12 @@ __device__ __forceinline__ void finish_read(const PhredArgs &a, uint32_t rid, in
 // ---------------------------------------------------------------------------------------------
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *lq = reinterpret_cast<double *>(smem);
-    double *ld = lq + LUT_PAD;
-    unsigned char *rings = smem + 2 * LUT_PAD * sizeof(double);
+    // Static LDS: the two lookup tables.  Static LDS is laid out at compile time, so the table base folds into
+    // the ds_read offset field and a lookup costs one address op.  2 * 264 * 8 = 4224 B keeps the dynamic
+    // region (the rings) 16-byte aligned.
+    __shared__ __attribute__((aligned(16))) double lq[LUT_PAD];
+    __shared__ __attribute__((aligned(16))) double ld[LUT_PAD];
+    extern __shared__ __attribute__((aligned(16))) unsigned char rings[];
 
     for (int i = threadIdx.x; i < 257; i += WAVES * 64) {
         lq[i] = a.lut_q[i];
@@ -179,11 +199,11 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredAr
 
             if (j0 + 16 <= Lmin && j0 + 16 <= ws) {
                 // ---- pure head: only the running sum ----
+                double qj[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const uint32_t cj = (lw[i >> 2] >> (8 * (i & 3))) & 0xffu;
-                    s += lq[cj];
-                }
+                for (int i = 0; i < 16; ++i) qj[i] = lds_f64(lq, lut_addr(lw[i >> 2], i & 3));
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s += qj[i];
                 if (j0 + 16 == ws) {
                     w = s / a.ws_d;  // src/read.cpp:223
                     mn = w;
@@ -217,17 +237,27 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredAr
                     carry = nxt;
                     carry_pos = ta + 16;
                 }
+                // LDS byte addresses of the table entries (c * 8), then every lookup of the piece is issued before
+                // the dependent FP64 chain starts, so the LDS latency overlaps the arithmetic of earlier bases.
+                uint32_t aj[16], ai[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const uint32_t cj = (lw[i >> 2] >> (8 * (i & 3))) & 0xffu;
-                    const uint32_t ci = (tw[i >> 2] >> (8 * (i & 3))) & 0xffu;
-                    const double qj = lq[cj];
-                    const double dj = ld[cj];
-                    const double di = ld[ci];
-                    s += qj;
-                    w -= di;  // src/read.cpp:228
-                    w += dj;  // src/read.cpp:229
-                    if (w < mn) mn = w;
+                    aj[i] = lut_addr(lw[i >> 2], i & 3);
+                    ai[i] = lut_addr(tw[i >> 2], i & 3);
+                }
+                double qj[16], dj[16], di[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    qj[i] = lds_f64(lq, aj[i]);
+                    di[i] = lds_f64(ld, ai[i]);
+                    dj[i] = lds_f64(ld, aj[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s += qj[i];
+                    w -= di[i];  // src/read.cpp:228
+                    w += dj[i];  // src/read.cpp:229
+                    mn = fmin(mn, w);  // if (w < mn) mn = w;  (no NaNs here; the sign of a zero minimum is irrelevant)
                 }
             } else {
                 // ---- generic piece: straddles window_size or the end of some read in this wave ----
@@ -346,7 +376,7 @@ int flx_launch_score_phred(flx_ctx *ctx, const uint8_t *d_plane, uint64_t plane_
         if (waves > 7) waves = 7;
         a.n_slots = (int)n_slots;
         a.stride = (int)(slots16 * 16);
-        const size_t lds = kLutBytes + (size_t)waves * ring_bytes;
+        const size_t lds = (size_t)waves * ring_bytes;  // dynamic part; the tables are static LDS
         const unsigned grid = (unsigned)((n_waves + waves - 1) / waves);
 #define FLX_LAUNCH_RING(W)                                                                                    \
     case W: {                                                                                                 \
