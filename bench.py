@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--target-frac", type=float, default=0.5, help="--target_bases as a fraction of all bases")
     ap.add_argument("--cpu-sample-reads", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--window-size", type=int, default=250)
     args = ap.parse_args()
 
     import torch
@@ -131,7 +132,7 @@ def main():
     else:
         total_bases = local_bases
     target = int(total_bases * args.target_frac)
-    params = api.make_params()
+    params = api.make_params(window_size=args.window_size)
     setup_s = time.time() - t_setup
 
     def step():
@@ -202,7 +203,7 @@ def main():
                 "workload": "%s synthetic reads per GPU x %s, Phred-only, --target_bases %d (%.0f%% of bases)%s" % (
                     "{:,}".format(n), ("fixed %d bp" % args.fixed_len) if args.fixed_len else "gamma(k=4) mean 10 kbp",
                     target, args.target_frac * 100, "; C2" if (n == 10_000_000 and not args.fixed_len) else ""),
-                "reads_total": total_n, "bases_total": total_bases, "window_size": 250,
+                "reads_total": total_n, "bases_total": total_bases, "window_size": args.window_size,
                 "parallelism": "reads sharded by count, 1 RCCL all-gather of per-read records" if world > 1 else "1 GPU",
                 "device": info["name"],
             },

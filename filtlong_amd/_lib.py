@@ -8,7 +8,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libfiltlong_hip.so")
+LIB_PATH = os.environ.get("FLX_LIB_PATH") or os.path.join(HERE, "lib", "libfiltlong_hip.so")  # FLX_LIB_PATH: experiment builds
 CSRC = os.path.join(HERE, "csrc")
 
 FLX_OK = 0

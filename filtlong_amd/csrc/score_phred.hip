@@ -102,7 +102,74 @@ __device__ __forceinline__ void finish_read(const PhredArgs &a, uint32_t rid, in
 
 // ---------------------------------------------------------------------------------------------
 // ring kernel: the fast path (window_size small enough for the LDS ring)
+//
+// Ring row of one read: NS slots of CH bytes (NS = ceil(ws / CH) + 1) followed by a 16-byte mirror of
+// the row's first 16 bytes, so that any 20-byte window starting inside the row is contiguous.  The
+// row stride is NS*CH + 16 (+16 more when needed to make stride/16 odd: conflict-free b128 rows).
 // ---------------------------------------------------------------------------------------------
+struct Fold {  // per-lane state of the two recurrences
+    double s;   // running sum of Q            (get_mean_quality / first window sum)
+    double w;   // current window quality      (src/read.cpp:223-229)
+    double mn;  // minimum window quality      (src/read.cpp:230-231)
+};
+
+// 16 bases that only feed the running sum (positions < window_size)
+__device__ __forceinline__ void head16(const double *lq, const uint32_t (&lw)[4], Fold &f) {
+    double qj[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) qj[i] = lds_f64(lq, lut_addr(lw[i >> 2], i & 3));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) f.s += qj[i];
+}
+
+// 16 bases in the steady state: every position valid in every lane and >= window_size.
+// All table lookups of the piece are issued ahead of the dependent FP64 chain.
+//
+// Measured on MI355X (tools/gatherbench.hip, tools/ldspeak.hip): a random-address ds_read_b64 costs ~5
+// cycles of CU time whatever the occupancy (~100-128 B/clk/CU of gathered data), so three gathers per
+// base put the floor of this formulation at ~15 cycles per 64 bases per CU.  Two alternatives were built
+// and timed and lost: one 16-byte gather of {Q,D} (ds_read_b128 gathers cost ~10 cycles) and deriving
+// D = Q/ws on the VALU with a verified 3-op FMA division (the extra FP64 ops cost more than the gather).
+__device__ __forceinline__ void body16(const double *lq, const double *ld, const uint32_t (&lw)[4],
+                                       const uint32_t (&tw)[4], Fold &f) {
+    uint32_t aj[16], ai[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        aj[i] = lut_addr(lw[i >> 2], i & 3);
+        ai[i] = lut_addr(tw[i >> 2], i & 3);
+    }
+    double qj[16], dj[16], di[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        qj[i] = lds_f64(lq, aj[i]);
+        di[i] = lds_f64(ld, ai[i]);
+        dj[i] = lds_f64(ld, aj[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        f.s += qj[i];
+        f.w -= di[i];            // src/read.cpp:228
+        f.w += dj[i];            // src/read.cpp:229
+        f.mn = fmin(f.mn, f.w);  // if (w < min) min = w — no NaNs here; the sign of a zero minimum is irrelevant
+    }
+}
+
+// the 16 trailing bytes that start at ring byte offset `ro` (4-byte granular read + byte funnel)
+__device__ __forceinline__ void trail16(const unsigned char *my_row, int ro, uint32_t (&tw)[4]) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(my_row + (ro & ~3));
+    const uint32_t x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3], x4 = p[4];
+    const uint32_t bsh = (uint32_t)ro & 3u;
+    tw[0] = __builtin_amdgcn_alignbyte(x1, x0, bsh);
+    tw[1] = __builtin_amdgcn_alignbyte(x2, x1, bsh);
+    tw[2] = __builtin_amdgcn_alignbyte(x3, x2, bsh);
+    tw[3] = __builtin_amdgcn_alignbyte(x4, x3, bsh);
+}
+
+#ifndef FLX_PREFETCH
+#define FLX_PREFETCH 3
+#endif
+constexpr int PF = FLX_PREFETCH;  // rounds of global loads kept in flight per wave (PF * 4 KiB)
+
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredArgs a) {
     // Static LDS: the two lookup tables.  Static LDS is laid out at compile time, so the table base folds into
@@ -122,6 +189,7 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredAr
     const int wave = threadIdx.x >> 6;
     const int stride = a.stride;
     const int NS = a.n_slots;
+    const int ring_len = NS * CH;  // bytes of ring proper (the mirror lives at [ring_len, ring_len + 16))
     const int ws = a.ws;
     unsigned char *ring = rings + (size_t)wave * 64 * stride;
     unsigned char *my_row = ring + lane * stride;
@@ -158,126 +226,122 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredAr
         dst_off[m] = r * stride + k * 16;
     }
 
-    uint4 pre[PPR];
-    auto issue_loads = [&](int t) {
+    // Global loads run PF rounds ahead of the compute (PF * 4 KiB in flight per wave): with only ~7 waves per CU
+    // the HBM latency has to be covered by depth, not by occupancy.
+    uint4 pre[PF][PPR];
+    auto issue_loads = [&](int t, uint4 (&buf)[PPR]) {
 #pragma unroll
         for (int m = 0; m < PPR; ++m) {
             const int o = t * CH;
-            if (o < src_l16[m]) pre[m] = *reinterpret_cast<const uint4 *>(a.plane + src_base[m] + (uint64_t)o);
-            else pre[m] = make_uint4(0, 0, 0, 0);
+            if (o < src_l16[m]) buf[m] = *reinterpret_cast<const uint4 *>(a.plane + src_base[m] + (uint64_t)o);
+            else buf[m] = make_uint4(0, 0, 0, 0);
         }
     };
-    auto write_ring = [&](int ring_slot) {
+    auto write_ring = [&](int ring_slot, const uint4 (&buf)[PPR]) {
 #pragma unroll
-        for (int m = 0; m < PPR; ++m) *reinterpret_cast<uint4 *>(ring + dst_off[m] + ring_slot * CH) = pre[m];
+        for (int m = 0; m < PPR; ++m) *reinterpret_cast<uint4 *>(ring + dst_off[m] + ring_slot * CH) = buf[m];
+        if (ring_slot == 0 && k == 0) {  // mirror of the row's first 16 bytes behind the last slot
+#pragma unroll
+            for (int m = 0; m < PPR; ++m) *reinterpret_cast<uint4 *>(ring + dst_off[m] + ring_len) = buf[m];
+        }
     };
-    // ring byte offset of stream position p (wave-uniform, p >= 0)
+    // ring byte offset of stream position p (wave-uniform, p >= 0); only used to (re)start a trailing stream
     auto ring_off = [&](int p) { return ((p / CH) % NS) * CH + (p % CH); };
 
-    double s = 0.0, w = 0.0, mn = 0.0;
+    Fold f;
+    f.s = 0.0;
+    f.w = 0.0;
+    f.mn = 0.0;
     const int n_rounds = (Lmax + CH - 1) / CH;
-    const int tshift = (16 - (ws & 15)) & 15;  // byte offset of the trailing stream inside its aligned piece
 
-    issue_loads(0);
-    write_ring(0);
+    issue_loads(0, pre[0]);
+    write_ring(0, pre[0]);
+#pragma unroll
+    for (int r = 1; r <= PF; ++r)
+        if (r < n_rounds) issue_loads(r, pre[r % PF]);  // round r lives in pre[r % PF]
     __builtin_amdgcn_wave_barrier();
 
-    int lslot = 0;       // ring slot of the current round
-    int carry_pos = -1;  // aligned stream position whose 16 bytes are held in `carry`
-    uint4 carry = make_uint4(0, 0, 0, 0);
+    int lslot = 0;      // ring slot of the current round
+    int tro = -1;       // ring byte offset of the trailing edge of the NEXT body piece; -1 = not tracking
+    int tro_pos = -1;   // stream position tro belongs to
 
-    for (int t = 0; t < n_rounds; ++t) {
+    for (int tb = 0; tb < n_rounds; tb += PF) {
+#pragma unroll
+      for (int d = 0; d < PF; ++d) {
+        const int t = tb + d;
+        if (t >= n_rounds) break;
         const bool more = t + 1 < n_rounds;
-        if (more) issue_loads(t + 1);
+        const int r_lo = t * CH, r_hi = r_lo + CH;
+        const unsigned char *lead_p = my_row + lslot * CH;
 
+        if (r_hi <= Lmin && r_lo >= ws) {
+            // ---------------- whole round in the steady state ----------------
+            if (tro_pos != r_lo - ws) tro = ring_off(r_lo - ws);
+            uint4 lead[PPR];
+            uint32_t tw[PPR][4];
+#pragma unroll
+            for (int kk = 0; kk < PPR; ++kk) lead[kk] = *reinterpret_cast<const uint4 *>(lead_p + kk * 16);
+#pragma unroll
+            for (int kk = 0; kk < PPR; ++kk) {
+                trail16(my_row, tro, tw[kk]);
+                tro += 16;
+                if (tro >= ring_len) tro -= ring_len;
+            }
+            tro_pos = r_hi - ws;
+#pragma unroll
+            for (int kk = 0; kk < PPR; ++kk) {
+                const uint32_t lw[4] = {lead[kk].x, lead[kk].y, lead[kk].z, lead[kk].w};
+                body16(lq, ld, lw, tw[kk], f);
+            }
+        } else if (r_hi <= Lmin && r_hi <= ws) {
+            // ---------------- whole round before the first full window ----------------
+#pragma unroll
+            for (int kk = 0; kk < PPR; ++kk) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(lead_p + kk * 16);
+                const uint32_t lw[4] = {v.x, v.y, v.z, v.w};
+                head16(lq, lw, f);
+            }
+            if (r_hi == ws) {
+                f.w = f.s / a.ws_d;  // src/read.cpp:223
+                f.mn = f.w;
+            }
+        } else {
+            // ---------------- mixed round: straddles window_size or the end of some read of this wave --------
 #pragma unroll 1
-        for (int kk = 0; kk < PPR; ++kk) {
-            const int j0 = t * CH + kk * 16;
-            if (j0 >= Lmax) break;
-            const uint4 lead = *reinterpret_cast<const uint4 *>(my_row + lslot * CH + kk * 16);
-            const uint32_t lw[4] = {lead.x, lead.y, lead.z, lead.w};
-
-            if (j0 + 16 <= Lmin && j0 + 16 <= ws) {
-                // ---- pure head: only the running sum ----
-                double qj[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) qj[i] = lds_f64(lq, lut_addr(lw[i >> 2], i & 3));
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s += qj[i];
-                if (j0 + 16 == ws) {
-                    w = s / a.ws_d;  // src/read.cpp:223
-                    mn = w;
-                }
-            } else if (j0 + 16 <= Lmin && j0 >= ws) {
-                // ---- pure body: all 16 positions valid in every lane ----
-                const int ta = (j0 - ws) & ~15;
-                if (carry_pos != ta) {
-                    carry = *reinterpret_cast<const uint4 *>(my_row + ring_off(ta));
-                    carry_pos = ta;
-                }
-                uint32_t tw[4];
-                if (tshift == 0) {
-                    tw[0] = carry.x; tw[1] = carry.y; tw[2] = carry.z; tw[3] = carry.w;
-                    // next piece's trailing data starts at ta + 16
-                    carry_pos = -1;
+            for (int kk = 0; kk < PPR; ++kk) {
+                const int j0 = r_lo + kk * 16;
+                if (j0 >= Lmax) break;
+                const uint4 lead = *reinterpret_cast<const uint4 *>(lead_p + kk * 16);
+                const uint32_t lw[4] = {lead.x, lead.y, lead.z, lead.w};
+                if (j0 + 16 <= Lmin && j0 + 16 <= ws) {
+                    head16(lq, lw, f);
+                    if (j0 + 16 == ws) {
+                        f.w = f.s / a.ws_d;
+                        f.mn = f.w;
+                    }
+                } else if (j0 + 16 <= Lmin && j0 >= ws) {
+                    uint32_t tw[4];
+                    trail16(my_row, ring_off(j0 - ws), tw);
+                    body16(lq, ld, lw, tw, f);
                 } else {
-                    const uint4 nxt = *reinterpret_cast<const uint4 *>(my_row + ring_off(ta + 16));
-                    const uint32_t x[8] = {carry.x, carry.y, carry.z, carry.w, nxt.x, nxt.y, nxt.z, nxt.w};
-                    const int dsh = tshift >> 2;         // wave-uniform dword shift 0..3
-                    const uint32_t bsh = tshift & 3;     // byte shift inside the dword
-                    uint32_t y[5];
-                    switch (dsh) {
-                        case 0: y[0] = x[0]; y[1] = x[1]; y[2] = x[2]; y[3] = x[3]; y[4] = x[4]; break;
-                        case 1: y[0] = x[1]; y[1] = x[2]; y[2] = x[3]; y[3] = x[4]; y[4] = x[5]; break;
-                        case 2: y[0] = x[2]; y[1] = x[3]; y[2] = x[4]; y[3] = x[5]; y[4] = x[6]; break;
-                        default: y[0] = x[3]; y[1] = x[4]; y[2] = x[5]; y[3] = x[6]; y[4] = x[7]; break;
-                    }
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) tw[d] = __builtin_amdgcn_alignbyte(y[d + 1], y[d], bsh);
-                    carry = nxt;
-                    carry_pos = ta + 16;
-                }
-                // LDS byte addresses of the table entries (c * 8), then every lookup of the piece is issued before
-                // the dependent FP64 chain starts, so the LDS latency overlaps the arithmetic of earlier bases.
-                uint32_t aj[16], ai[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    aj[i] = lut_addr(lw[i >> 2], i & 3);
-                    ai[i] = lut_addr(tw[i >> 2], i & 3);
-                }
-                double qj[16], dj[16], di[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    qj[i] = lds_f64(lq, aj[i]);
-                    di[i] = lds_f64(ld, ai[i]);
-                    dj[i] = lds_f64(ld, aj[i]);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    s += qj[i];
-                    w -= di[i];  // src/read.cpp:228
-                    w += dj[i];  // src/read.cpp:229
-                    mn = fmin(mn, w);  // if (w < mn) mn = w;  (no NaNs here; the sign of a zero minimum is irrelevant)
-                }
-            } else {
-                // ---- generic piece: straddles window_size or the end of some read in this wave ----
 #pragma unroll 1
-                for (int i = 0; i < 16; ++i) {
-                    const int j = j0 + i;
-                    if (j >= Lmax) break;
-                    const bool act = j < L;
-                    const uint32_t cj = act ? byte_of(lead, i) : 256u;
-                    s += lq[cj];
-                    if (j == ws - 1) {
-                        w = s / a.ws_d;
-                        mn = w;
-                    }
-                    if (j >= ws) {
-                        const uint32_t tb = my_row[ring_off(j - ws)];
-                        const uint32_t ci = act ? tb : 256u;
-                        w -= ld[ci];
-                        w += ld[cj];
-                        if (w < mn) mn = w;
+                    for (int i = 0; i < 16; ++i) {
+                        const int j = j0 + i;
+                        if (j >= Lmax) break;
+                        const bool act = j < L;
+                        const uint32_t cj = act ? byte_of(lead, i) : 256u;  // entry 256 = 0.0: exact no-op
+                        f.s += lq[cj];
+                        if (j == ws - 1) {
+                            f.w = f.s / a.ws_d;
+                            f.mn = f.w;
+                        }
+                        if (j >= ws) {
+                            const uint32_t tb = my_row[ring_off(j - ws)];
+                            const uint32_t ci = act ? tb : 256u;
+                            f.w -= ld[ci];
+                            f.w += ld[cj];
+                            if (f.w < f.mn) f.mn = f.w;
+                        }
                     }
                 }
             }
@@ -285,12 +349,14 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredAr
 
         if (more) {
             lslot = (lslot + 1 == NS) ? 0 : lslot + 1;
-            write_ring(lslot);
+            write_ring(lslot, pre[(d + 1) % PF]);                                  // round t + 1
+            if (t + 1 + PF < n_rounds) issue_loads(t + 1 + PF, pre[(d + 1) % PF]);  // refill the buffer just drained
         }
         __builtin_amdgcn_wave_barrier();
+      }
     }
 
-    if (live) finish_read(a, rid, L, s, mn);
+    if (live) finish_read(a, rid, L, f.s, f.mn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -363,8 +429,8 @@ int flx_launch_score_phred(flx_ctx *ctx, const uint8_t *d_plane, uint64_t plane_
     a.passed = out.passed;
 
     const long long n_slots = ((long long)p->window_size + CH - 1) / CH + 1;
-    long long slots16 = n_slots * CH / 16;
-    if ((slots16 & 1) == 0) slots16 += 1;  // odd number of 16-byte slots per row: b128 rows never collide
+    long long slots16 = n_slots * CH / 16 + 1;  // + the 16-byte mirror behind the last slot
+    if ((slots16 & 1) == 0) slots16 += 1;       // odd number of 16-byte slots per row: b128 rows never collide
     const size_t ring_bytes = (size_t)64 * slots16 * 16;
 
     const uint64_t n_waves = (n_reads + 63) / 64;
@@ -380,10 +446,11 @@ int flx_launch_score_phred(flx_ctx *ctx, const uint8_t *d_plane, uint64_t plane_
         const unsigned grid = (unsigned)((n_waves + waves - 1) / waves);
 #define FLX_LAUNCH_RING(W)                                                                                    \
     case W: {                                                                                                 \
-        FLX_HIP(ctx, hipFuncSetAttribute((const void *)flx_score_phred_ring<W>,                               \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+        auto kern = flx_score_phred_ring<W>;                                                                  \
+        FLX_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                         (int)lds));                                                          \
         flx_time_begin(ctx, "flx_score_phred_ring");                                                          \
-        hipLaunchKernelGGL(flx_score_phred_ring<W>, dim3(grid), dim3(W * 64), lds, ctx->stream, a);           \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(W * 64), lds, ctx->stream, a);                              \
         flx_time_end(ctx);                                                                                    \
     } break;
         switch (waves) {
