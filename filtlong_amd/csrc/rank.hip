@@ -106,20 +106,30 @@ __global__ void k_cut_weights(uint64_t n, const uint32_t *sorted_idx, const int3
     w[i] = ok ? (int64_t)length[r] : 0;
 }
 
-// keep iff passed && bases_so_far(before) < target; everything else fails.  Also records the sorted
-// position of the last kept read and the kept base total.
-__global__ void k_cut_apply(uint64_t n, const uint32_t *sorted_idx, const int64_t *excl, const int64_t *w,
-                            int64_t target, uint8_t *passed, unsigned long long *kept_bases,
-                            unsigned long long *last_kept_pos_plus1) {
+// The walk of main.cpp:251-257 keeps a read iff it passed and bases_so_far (before it) < target.  bases_so_far is
+// non-decreasing along the sorted order, so the kept reads are exactly the passed reads up to and including the
+// LAST passed read whose exclusive prefix is below the target.  Find that position (sequential reads only) ...
+__global__ void k_cut_find(uint64_t n, const int64_t *excl, const uint8_t *pre_sorted, int64_t target,
+                           unsigned long long *last_kept_pos_plus1) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long last = 0;
+    if (i < n && pre_sorted[i] && excl[i] < target) last = i + 1;
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long l2 = __shfl_xor(last, o, 64);
+        last = l2 > last ? l2 : last;
+    }
+    if ((threadIdx.x & 63) == 0 && last) atomicMax(last_kept_pos_plus1, last);
+}
+
+// ... and then mark in READ order, without any scattered access: the sort is stable, so "at or before sorted
+// position p" is the same as "(key, read index) <= (key at p, read index at p)".
+__global__ void k_cut_mark(uint64_t n, const uint64_t *keys_orig, uint64_t key_star, uint32_t idx_star,
+                           uint8_t *passed) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t r = sorted_idx[i];
-    const bool keep = passed[r] && excl[i] < target;
-    if (!keep) passed[r] = 0;
-    else {
-        atomicAdd(kept_bases, (unsigned long long)w[i]);
-        atomicMax(last_kept_pos_plus1, (unsigned long long)(i + 1));
-    }
+    const uint64_t k = keys_orig[i];
+    const bool before = k < key_star || (k == key_star && (uint32_t)i <= idx_star);
+    if (!before) passed[i] = 0;
 }
 
 }  // namespace
@@ -263,12 +273,13 @@ extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean
 
     // scratch layout: keys[2][n] u64 | vals[2][n] u32 | weights[n] i64 | excl[n] i64 | sort workspace
     const size_t sort_ws = flx_radix_sort_workspace(n);
-    const size_t bytes = n * (16 + 8 + 8 + 8) + ((n + 255) & ~(size_t)255) + 256 + sort_ws;
+    const size_t bytes = n * (24 + 8 + 8 + 8) + ((n + 255) & ~(size_t)255) + 256 + sort_ws;
     void *scr;
     FLX_CHECK(flx_scratch(ctx, bytes, &scr));
     char *p = (char *)scr;
     uint64_t *keys0 = (uint64_t *)p; p += n * 8;
     uint64_t *keys1 = (uint64_t *)p; p += n * 8;
+    uint64_t *keys_orig = (uint64_t *)p; p += n * 8;  // keys in read order (the sort ping-pongs keys0/keys1)
     int64_t *wts = (int64_t *)p; p += n * 8;
     int64_t *excl = (int64_t *)p; p += n * 8;
     uint32_t *vals0 = (uint32_t *)p; p += n * 4;
@@ -283,6 +294,8 @@ extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean
                        (double *)d_final_score, keys0, vals0, (unsigned int *)(d_acc + 2));
     flx_time_end(ctx);
 
+    FLX_HIP(ctx, hipMemcpyAsync(keys_orig, keys0, n * 8, hipMemcpyDeviceToDevice, st));
+
     // ---- a24: device radix sort (stable, descending score) -------------------------------------
     uint64_t *skeys = nullptr;
     uint32_t *svals = nullptr;
@@ -293,12 +306,32 @@ extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean
     hipLaunchKernelGGL(k_cut_weights, dim3(nb), dim3(256), 0, st, n, svals, length, passed, wts, pre_sorted);
     FLX_CHECK(flx_exclusive_scan_i64(ctx, n, wts, excl, sort_tmp, sort_ws));
 
-    hipLaunchKernelGGL(k_cut_apply, dim3(nb), dim3(256), 0, st, n, svals, excl, wts, target, passed, d_acc, d_acc + 1);
-    flx_time_end(ctx);
+    hipLaunchKernelGGL(k_cut_find, dim3(nb), dim3(256), 0, st, n, excl, pre_sorted, target, d_acc + 1);
     unsigned long long h_acc[3] = {0, 0, 0};
     FLX_HIP(ctx, hipMemcpyAsync(h_acc, d_acc, 24, hipMemcpyDeviceToHost, st));
     FLX_HIP(ctx, hipStreamSynchronize(st));
-    rep->kept_bases = (int64_t)h_acc[0];
+    if (h_acc[1] == 0) {  // nothing can be kept (not reachable when 0 < target < passed_bases); fail everything
+        FLX_HIP(ctx, hipMemsetAsync(passed, 0, n, st));
+        flx_time_end(ctx);
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+        rep->kept_bases = 0;
+        return FLX_OK;
+    }
+    {
+        const uint64_t ps = h_acc[1] - 1;
+        uint64_t kstar;
+        uint32_t istar;
+        int64_t ex_w[2];
+        FLX_HIP(ctx, hipMemcpyAsync(&kstar, skeys + ps, 8, hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipMemcpyAsync(&istar, svals + ps, 4, hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipMemcpyAsync(&ex_w[0], excl + ps, 8, hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipMemcpyAsync(&ex_w[1], wts + ps, 8, hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+        hipLaunchKernelGGL(k_cut_mark, dim3(nb), dim3(256), 0, st, n, keys_orig, kstar, istar, passed);
+        flx_time_end(ctx);
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+        rep->kept_bases = ex_w[0] + ex_w[1];  // "keeping N bp", main.cpp:258
+    }
     // Any NaN score (stdev == 0 -> 0/0 at main.cpp:206, or 0/0 window ratios) makes the reference's comparator
     // inconsistent; its outcome is then whatever libstdc++'s introsort does on reads2 order.  Reproduce exactly
     // that on the host instead of guessing.

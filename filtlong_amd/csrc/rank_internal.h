@@ -6,6 +6,7 @@
 // compute them (src/main.cpp:170-186).
 struct flx_stats {
     double min, max, sum, mean, sq_sum, stdev;
+    unsigned long long serial_chunks;  // diagnostic: 512-element chunks folded serially (binade crossings etc.)
 };
 int flx_exact_stats(flx_ctx *ctx, uint64_t n, const double *d_mean_q, flx_stats *out);
 
@@ -19,5 +20,7 @@ int flx_radix_sort_pairs(flx_ctx *ctx, uint64_t n, uint64_t *keys0, uint64_t *ke
 // out[i] = sum_{j<i} in[j]   (int64, exact).  workspace >= flx_radix_sort_workspace(n) suffices.
 int flx_exclusive_scan_i64(flx_ctx *ctx, uint64_t n, const int64_t *in, int64_t *out, void *workspace,
                            size_t workspace_bytes);
+// in-place exclusive scan of doubles in tree order (APPROXIMATE sums; only used to guess binades in stats.hip)
+int flx_exclusive_scan_f64_approx(flx_ctx *ctx, uint64_t n, double *data, void *workspace);
 int flx_exclusive_scan_u32(flx_ctx *ctx, uint64_t n, const uint32_t *in, uint32_t *out, void *workspace,
                            size_t workspace_bytes);

@@ -219,6 +219,10 @@ int flx_exclusive_scan_i64(flx_ctx *ctx, uint64_t n, const int64_t *in, int64_t 
     return exclusive_scan<int64_t>(ctx, n, in, out, workspace, workspace_bytes);
 }
 
+int flx_exclusive_scan_f64_approx(flx_ctx *ctx, uint64_t n, double *data, void *workspace) {
+    return exclusive_scan<double>(ctx, n, data, data, workspace, (n / SCAN_TILE + 4096) * 8 * 2);
+}
+
 int flx_exclusive_scan_u32(flx_ctx *ctx, uint64_t n, const uint32_t *in, uint32_t *out, void *workspace,
                            size_t workspace_bytes) {
     return exclusive_scan<uint32_t>(ctx, n, in, out, workspace, workspace_bytes);

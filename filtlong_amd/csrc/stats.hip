@@ -1,40 +1,364 @@
-// stats.hip — a20: statistics of the mean qualities, bit-identical to the reference's serial folds
+// stats.hip — a20: statistics of the mean qualities, bit-identical to the reference's SERIAL folds
 // (src/main.cpp:170-186):
 //     for read in reads2: quality_sum += mean_q; track min/max        (strict reads2 order)
 //     mean = quality_sum / N
 //     for read in reads2: d = mean_q - mean; stdev_sum += d*d         (strict reads2 order)
 //     stdev = sqrt(stdev_sum / N)
-// FP64 addition is not associative, so a tree reduction gives a different last bit and
-// through the z-scores a different normalised quality for every read.
+// FP64 addition is not associative: a tree reduction changes the last bits of the sums and,
+// through the z-scores, the normalised quality of every read.  Ten million dependent adds are ~25 ms on
+// a host core — as long as the whole scoring kernel — so the folds are reproduced EXACTLY on the device
+// with a parallel algorithm:
+//
+//   While the running sum S stays inside one binade [2^e, 2^(e+1)) every addend x >= 0 is first rounded
+//   to that binade's grid u = 2^(e-52); in units of u the fold is then plain INTEGER addition
+//   (associative), except for ties (x/u ending in exactly .5), which round to even and therefore depend
+//   on the parity of the running integer.  An element is thus a map  m -> m + a[m & 1]  and such maps
+//   compose associatively:  (a o b)[p] = a[p] + b[(p + a[p]) & 1].
+//
+//   1. k_chunk_sums:  approximate sum of every 512-element chunk (any order) + "clean" flag (all finite, >= 0).
+//   2. scan:          approximate running sum at every chunk start -> a GUESS of the binade of S there.
+//   3. k_chunk_maps:  one wavefront per chunk composes the integer maps of its 512 elements for the guessed
+//                     binade (ordered wave reduction).
+//   4. k_walk:        one wavefront walks the chunks in order carrying the EXACT S.  A chunk's map is used
+//                     only if S really is in the guessed binade at the chunk start and stays there (checked
+//                     on the exact integers); otherwise the chunk is folded serially, element by element.
+//                     So a wrong guess costs time, never correctness.  Binade crossings (~30 per fold),
+//                     negative or non-finite values take the serial path.
 #include <cmath>
 
 #include "flx_internal.h"
 #include "rank_internal.h"
 
+namespace {
+
+constexpr int CHUNK = 512;  // elements per chunk = 64 lanes x 8
+constexpr int PER_LANE = CHUNK / 64;
+
+struct Identity {
+    double mean;
+    __device__ __forceinline__ double operator()(double x) const { return x; }
+};
+struct SqDev {  // main.cpp:182-185: d = x - mean; d * d   (separate IEEE sub and mul, no FMA)
+    double mean;
+    __device__ __forceinline__ double operator()(double x) const {
+        const double d = x - mean;
+        return d * d;
+    }
+};
+
+struct ChunkMeta {
+    long long a0, a1;  // integer increment (units of 2^(e-52)) for entry parity 0 / 1
+    int e;             // guessed unbiased binade exponent of the running sum, or INT_MIN: no map
+    int pad;
+};
+constexpr int NO_MAP = -2147483647 - 1;
+
+__device__ __forceinline__ int exponent_of(double v) {  // unbiased exponent of a positive normal double
+    return (int)((__double_as_longlong(v) >> 52) & 0x7ff) - 1023;
+}
+
+template <typename F>
+__global__ void __launch_bounds__(256) k_chunk_sums(uint64_t n, const double *x, F f, double *chunk_sum,
+                                                    unsigned char *chunk_clean, double *minmax) {
+    // one wave per chunk
+    const int lane = threadIdx.x & 63;
+    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t base = chunk * CHUNK;
+    if (base >= n) return;
+    double acc = 0.0;
+    bool clean = true;
+    double lo = 100.0, hi = 0.0;  // main.cpp:170-171 initial values
+#pragma unroll
+    for (int k = 0; k < PER_LANE; ++k) {
+        const uint64_t i = base + (uint64_t)k * 64 + lane;  // coalesced; order is irrelevant here
+        if (i < n) {
+            const double raw = x[i];
+            const double v = f(raw);
+            acc += v;
+            clean = clean && (v >= 0.0) && (v < __longlong_as_double(0x7ff0000000000000ll));
+            if (raw > hi) hi = raw;
+            if (raw < lo) lo = raw;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_xor(acc, o, 64);
+        const double h2 = __shfl_xor(hi, o, 64), l2 = __shfl_xor(lo, o, 64);
+        if (h2 > hi) hi = h2;
+        if (l2 < lo) lo = l2;
+    }
+    const bool all_clean = __all(clean);
+    if (lane == 0) {
+        chunk_sum[chunk] = acc;
+        chunk_clean[chunk] = all_clean ? 1 : 0;
+        if (minmax) {
+            minmax[2 * chunk] = lo;
+            minmax[2 * chunk + 1] = hi;
+        }
+    }
+}
+
+// final min / max over the per-chunk values (order free; NaN never wins a comparison, like the reference)
+__global__ void __launch_bounds__(256) k_minmax(uint64_t n_chunks, const double *minmax, double *out) {
+    double lo = 100.0, hi = 0.0;
+    for (uint64_t c = threadIdx.x; c < n_chunks; c += 256) {
+        const double l = minmax[2 * c], h = minmax[2 * c + 1];
+        if (l < lo) lo = l;
+        if (h > hi) hi = h;
+    }
+    __shared__ double sl[256], sh[256];
+    sl[threadIdx.x] = lo;
+    sh[threadIdx.x] = hi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 256; ++i) {
+            if (sl[i] < lo) lo = sl[i];
+            if (sh[i] > hi) hi = sh[i];
+        }
+        out[0] = lo;
+        out[1] = hi;
+    }
+}
+
+struct Map2 {
+    long long a0, a1;
+};
+__device__ __forceinline__ Map2 compose(const Map2 &a, const Map2 &b) {  // a first, then b
+    Map2 c;
+    c.a0 = a.a0 + ((a.a0 & 1) ? b.a1 : b.a0);
+    c.a1 = a.a1 + (((1 + a.a1) & 1) ? b.a1 : b.a0);
+    return c;
+}
+
+// integer map of one addend v >= 0 (finite) for a running sum in binade e; ok = false if v cannot be added
+// without leaving the binade
+__device__ __forceinline__ Map2 elem_map(double v, int e, bool &ok) {
+    Map2 m;
+    m.a0 = m.a1 = 0;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if ((bits << 1) == 0) return m;  // +-0
+    const int eb = (int)((bits >> 52) & 0x7ff);
+    unsigned long long mx = bits & 0x000fffffffffffffull;
+    int ex;
+    if (eb == 0) ex = -1022;  // subnormal
+    else { mx |= 1ull << 52; ex = eb - 1023; }
+    const int sh = e - ex;  // v / u = mx >> sh
+    if (sh < 0) { ok = false; return m; }
+    if (sh == 0) { m.a0 = m.a1 = (long long)mx; return m; }
+    if (sh >= 55) return m;
+    const unsigned long long f = mx >> sh;
+    const unsigned long long rem = mx & ((1ull << sh) - 1ull);
+    const unsigned long long half = 1ull << (sh - 1);
+    if (rem > half) m.a0 = m.a1 = (long long)(f + 1);
+    else if (rem < half) m.a0 = m.a1 = (long long)f;
+    else {  // tie: the sum rounds to even
+        m.a0 = (long long)(f + (f & 1));
+        m.a1 = (long long)(f + ((f + 1) & 1));
+    }
+    return m;
+}
+
+template <typename F>
+__global__ void __launch_bounds__(256) k_chunk_maps(uint64_t n, const double *x, F f, const double *chunk_start,
+                                                    const double *chunk_sum, const unsigned char *chunk_clean,
+                                                    ChunkMeta *meta) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t chunk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t base = chunk * CHUNK;
+    if (base >= n) return;
+    // guess the binade from the approximate running sum at the chunk's start and end
+    const double p0 = chunk_start[chunk] * (1.0 - 1e-9);
+    const double p1 = (chunk_start[chunk] + chunk_sum[chunk]) * (1.0 + 1e-9);
+    int e = NO_MAP;
+    if (chunk_clean[chunk] && p0 > 2.3e-308 && p1 < 1e300 && exponent_of(p0) == exponent_of(p1)) e = exponent_of(p0);
+    Map2 m;
+    m.a0 = m.a1 = 0;
+    bool ok = true;
+    if (e != NO_MAP) {
+        // lane l owns elements [l*8, l*8+8) so that lane order == element order
+#pragma unroll
+        for (int k = 0; k < PER_LANE; ++k) {
+            const uint64_t i = base + (uint64_t)lane * PER_LANE + k;
+            if (i < n) m = compose(m, elem_map(f(x[i]), e, ok));
+        }
+        // ordered wave reduction
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            Map2 nb;
+            nb.a0 = __shfl_down(m.a0, o, 64);
+            nb.a1 = __shfl_down(m.a1, o, 64);
+            if ((lane & (2 * o - 1)) == 0) m = compose(m, nb);
+        }
+        if (!__all(ok)) e = NO_MAP;
+    }
+    if (lane == 0) {
+        ChunkMeta cm;
+        cm.a0 = m.a0;
+        cm.a1 = m.a1;
+        cm.e = e;
+        cm.pad = 0;
+        meta[chunk] = cm;
+    }
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// single wavefront: the exact fold
+template <typename F>
+__global__ void __launch_bounds__(64) k_walk(uint64_t n, const double *x, F f, const ChunkMeta *meta,
+                                             uint64_t n_chunks, double *result, unsigned long long *serial_chunks) {
+    const int lane = threadIdx.x;
+    double S = 0.0;
+    unsigned long long n_serial = 0;
+    for (uint64_t cb = 0; cb < n_chunks; cb += 64) {
+        ChunkMeta mine;
+        mine.a0 = mine.a1 = 0;
+        mine.e = NO_MAP;
+        if (cb + lane < n_chunks) mine = meta[cb + lane];
+        const int cnt = (int)((n_chunks - cb) < 64 ? (n_chunks - cb) : 64);
+        // Fast path for the whole batch of 64 chunks: if they all carry a map for the same binade, compose the 64
+        // maps with an ordered wave reduction and apply the result in one step (same exact checks as per chunk).
+        {
+            const int e0 = __builtin_amdgcn_readfirstlane(mine.e);
+            if (cnt == 64 && e0 != NO_MAP && __all(mine.e == e0) && S == S) {
+                Map2 m;
+                m.a0 = mine.a0;
+                m.a1 = mine.a1;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    Map2 nb;
+                    nb.a0 = __shfl_down(m.a0, o, 64);
+                    nb.a1 = __shfl_down(m.a1, o, 64);
+                    if ((lane & (2 * o - 1)) == 0) m = compose(m, nb);
+                }
+                const long long a0 = __double_as_longlong(readlane_f64(__longlong_as_double(m.a0), 0));
+                const long long a1 = __double_as_longlong(readlane_f64(__longlong_as_double(m.a1), 0));
+                const unsigned long long sb = (unsigned long long)__double_as_longlong(S);
+                const int se = (int)((sb >> 52) & 0x7ff) - 1023;
+                if (se == e0 && (sb >> 63) == 0 && a0 >= 0 && a1 >= 0) {
+                    const unsigned long long mm = (sb & 0x000fffffffffffffull) | (1ull << 52);
+                    const unsigned long long m2 = mm + (unsigned long long)((mm & 1) ? a1 : a0);
+                    if (m2 <= (1ull << 53)) {
+                        if (m2 == (1ull << 53)) S = __longlong_as_double((long long)(((unsigned long long)(e0 + 1 + 1023)) << 52));
+                        else S = __longlong_as_double((long long)((((unsigned long long)(e0 + 1023)) << 52) | (m2 & 0x000fffffffffffffull)));
+                        continue;  // next batch
+                    }
+                }
+            }
+        }
+        for (int k = 0; k < cnt; ++k) {
+            if (S != S) break;  // NaN is absorbing
+            const int e = __builtin_amdgcn_readlane(mine.e, k);
+            bool done = false;
+            if (e != NO_MAP) {
+                const unsigned long long sb = (unsigned long long)__double_as_longlong(S);
+                const int se = (int)((sb >> 52) & 0x7ff) - 1023;
+                if (se == e && (sb >> 63) == 0) {
+                    const unsigned long long m = (sb & 0x000fffffffffffffull) | (1ull << 52);
+                    const long long a0 = __double_as_longlong(readlane_f64(__longlong_as_double(mine.a0), k));
+                    const long long a1 = __double_as_longlong(readlane_f64(__longlong_as_double(mine.a1), k));
+                    const unsigned long long m2 = m + (unsigned long long)((m & 1) ? a1 : a0);
+                    if (m2 <= (1ull << 53)) {  // never left the binade (reaching 2^(e+1) exactly is still on the grid)
+                        if (m2 == (1ull << 53)) S = __longlong_as_double((long long)(((unsigned long long)(e + 1 + 1023)) << 52));
+                        else S = __longlong_as_double((long long)((((unsigned long long)(e + 1023)) << 52) | (m2 & 0x000fffffffffffffull)));
+                        done = true;
+                    }
+                }
+            }
+            if (!done) {  // serial, element by element, exactly like the reference loop
+                ++n_serial;
+                const uint64_t base = (cb + k) * CHUNK;
+                double v[PER_LANE];
+#pragma unroll
+                for (int j = 0; j < PER_LANE; ++j) {
+                    const uint64_t i = base + (uint64_t)lane * PER_LANE + j;
+                    v[j] = i < n ? f(x[i]) : 0.0;
+                }
+                const int m_el = (int)((n - base) < CHUNK ? (n - base) : CHUNK);
+                for (int l = 0; l * PER_LANE < m_el; ++l) {
+#pragma unroll
+                    for (int j = 0; j < PER_LANE; ++j)
+                        if (l * PER_LANE + j < m_el) S += readlane_f64(v[j], l);
+                }
+            }
+        }
+        if (S != S) break;
+    }
+    if (lane == 0) {
+        result[0] = S;
+        serial_chunks[0] = n_serial;
+    }
+}
+
+template <typename F>
+int exact_fold(flx_ctx *ctx, uint64_t n, const double *x, F f, char *ws, double *d_result, unsigned long long *d_serial,
+               double *d_minmax_out) {
+    const uint64_t n_chunks = (n + CHUNK - 1) / CHUNK;
+    double *chunk_sum = (double *)ws;
+    double *chunk_start = chunk_sum + n_chunks;
+    double *minmax = chunk_start + n_chunks;
+    ChunkMeta *meta = (ChunkMeta *)(minmax + 2 * n_chunks);
+    unsigned char *clean = (unsigned char *)(meta + n_chunks);
+    char *scan_ws = (char *)(((uintptr_t)(clean + n_chunks) + 255) & ~(uintptr_t)255);
+    hipStream_t st = ctx->stream;
+    const unsigned nb = (unsigned)((n_chunks + 3) / 4);
+    hipLaunchKernelGGL(k_chunk_sums<F>, dim3(nb), dim3(256), 0, st, n, x, f, chunk_sum, clean,
+                       d_minmax_out ? minmax : (double *)nullptr);
+    if (d_minmax_out) hipLaunchKernelGGL(k_minmax, dim3(1), dim3(256), 0, st, n_chunks, minmax, d_minmax_out);
+    FLX_HIP(ctx, hipMemcpyAsync(chunk_start, chunk_sum, n_chunks * 8, hipMemcpyDeviceToDevice, st));
+    FLX_CHECK(flx_exclusive_scan_f64_approx(ctx, n_chunks, chunk_start, scan_ws));
+    hipLaunchKernelGGL(k_chunk_maps<F>, dim3(nb), dim3(256), 0, st, n, x, f, chunk_start, chunk_sum, clean, meta);
+    hipLaunchKernelGGL(k_walk<F>, dim3(1), dim3(64), 0, st, n, x, f, meta, n_chunks, d_result, d_serial);
+    FLX_HIP(ctx, hipGetLastError());
+    return FLX_OK;
+}
+
+}  // namespace
+
 int flx_exact_stats(flx_ctx *ctx, uint64_t n, const double *d_mean_q, flx_stats *out) {
-    std::vector<double> h(n);
-    if (n) {
-        FLX_HIP(ctx, hipMemcpyAsync(h.data(), d_mean_q, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memset(out, 0, sizeof *out);
+    if (n == 0) {  // 0/0, like the reference would compute
+        volatile double z = 0.0;
+        out->min = 100.0; out->max = 0.0; out->sum = 0.0; out->mean = z / z; out->sq_sum = 0.0; out->stdev = sqrt(z / z);
+        return FLX_OK;
     }
-    double qmin = 100.0, qmax = 0.0, qsum = 0.0;  // main.cpp:170-172
-    for (uint64_t i = 0; i < n; ++i) {
-        const double v = h[i];
-        qsum += v;
-        if (v > qmax) qmax = v;
-        if (v < qmin) qmin = v;
+    const uint64_t n_chunks = (n + CHUNK - 1) / CHUNK;
+    const size_t bytes = n_chunks * (8 + 8 + 16 + sizeof(ChunkMeta) + 1) + 512 + (n_chunks / 2048 + 4096) * 8 * 2 + 4096;
+    void *scr;
+    FLX_CHECK(flx_scratch(ctx, bytes, &scr));
+    char *ws = (char *)scr;
+    double *d_res = (double *)ws;             // [0]=sum/sq_sum, [2..3] = min,max
+    unsigned long long *d_serial = (unsigned long long *)(ws + 64);
+    ws += 256;
+
+    flx_time_begin(ctx, "flx_rank_stats");
+    FLX_CHECK(exact_fold(ctx, n, d_mean_q, Identity{0.0}, ws, d_res, d_serial, d_res + 2));
+    double h[4];
+    unsigned long long h_serial[2] = {0, 0};
+    FLX_HIP(ctx, hipMemcpyAsync(h, d_res, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    FLX_HIP(ctx, hipMemcpyAsync(&h_serial[0], d_serial, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->sum = h[0];
+    out->min = h[2];
+    out->max = h[3];
+    {
+        volatile double s = out->sum, nn = (double)n;
+        out->mean = s / nn;  // main.cpp:181
     }
-    const double qmean = qsum / (double)n;
-    double ssum = 0.0;
-    for (uint64_t i = 0; i < n; ++i) {
-        const double d = h[i] - qmean;
-        ssum += d * d;
+    FLX_CHECK(exact_fold(ctx, n, d_mean_q, SqDev{out->mean}, ws, d_res, d_serial, (double *)nullptr));
+    FLX_HIP(ctx, hipMemcpyAsync(h, d_res, 8, hipMemcpyDeviceToHost, ctx->stream));
+    FLX_HIP(ctx, hipMemcpyAsync(&h_serial[1], d_serial, 8, hipMemcpyDeviceToHost, ctx->stream));
+    flx_time_end(ctx);
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->sq_sum = h[0];
+    {
+        volatile double ss = out->sq_sum, nn = (double)n;
+        out->stdev = sqrt(ss / nn);  // main.cpp:186 (sqrt is correctly rounded)
     }
-    out->min = qmin;
-    out->max = qmax;
-    out->sum = qsum;
-    out->mean = qmean;
-    out->sq_sum = ssum;
-    out->stdev = sqrt(ssum / (double)n);
+    out->serial_chunks = h_serial[0] + h_serial[1];
     return FLX_OK;
 }

@@ -109,3 +109,34 @@ def test_e2e_phred_goldens(ctx):
     be = _pipeline.HipBackend(ctx)
     n = _e2e_checks.check_all(be, only=lambda k: k.startswith("synth_phred") or k.startswith("sort|phred"))
     assert n == 10 + 6
+
+
+def test_exact_serial_statistics_hard_cases(ctx):
+    """The device reproduces the reference's two SERIAL FP64 folds bit for bit (main.cpp:173-186), including
+    binade crossings, round-to-even ties (addends that are exact multiples of half an ulp of the running sum),
+    tiny / huge spreads, negatives and NaN."""
+    rng = np.random.RandomState(77)
+    cases = []
+    cases.append(rng.uniform(0, 100, 300_000))
+    cases.append(np.full(200_000, 64.0))                                  # every add is exact; many binade crossings
+    cases.append(rng.choice([0.5, 1.5, 64.0, 96.0, 3.0, 0.25, 0.125, 100.0], 250_000))   # ties galore
+    cases.append(np.concatenate([rng.uniform(90, 100, 100_000), [2.0 ** -30] * 5000, rng.uniform(0, 1, 50_000)]))
+    cases.append(rng.uniform(0, 100, 70_000) * (2.0 ** -200))             # tiny values
+    x = rng.uniform(50, 100, 120_000); x[777] = -12.25; x[5000:5010] = -0.5
+    cases.append(x)                                                       # negatives -> serial chunks
+    cases.append(np.array([77.7]))
+    cases.append(rng.uniform(0, 100, 513))
+    # exact multiples of 2^-44 around 90: with the running sum near 2^23..2^26 these hit half-ulp ties often
+    cases.append(np.round(rng.uniform(80, 100, 400_000) * 2.0 ** 28) / 2.0 ** 28)
+    for i, mean in enumerate(cases):
+        n = len(mean)
+        window = mean * 0.9
+        length = rng.randint(200, 20000, n).astype(np.int32)
+        want = _oracle.rank_and_cut(mean, window, length, np.ones(n, np.uint8))
+        got = ctx.rank_and_cut(mean, window, length, np.ones(n, np.uint8))["report"]
+        for a, b, what in ((got.mean_quality, want["mean_quality"], "mean"), (got.stdev_quality, want["stdev_quality"], "stdev"),
+                           (got.min_z, want["min_z"], "min_z"), (got.max_z, want["max_z"], "max_z")):
+            assert a == b or (np.isnan(a) and np.isnan(b)), "case %d %s: %r vs %r" % (i, what, a, b)
+    nan_case = rng.uniform(0, 100, 5000); nan_case[1234] = np.nan
+    got = ctx.rank_and_cut(nan_case, nan_case, np.full(5000, 100, np.int32), np.ones(5000, np.uint8))["report"]
+    assert np.isnan(got.mean_quality) and np.isnan(got.stdev_quality)

@@ -1,14 +1,21 @@
+#!/bin/bash
+# rocprofv3 evidence for the scoring hot path (run on the GPU box through gpurun).  Writes rocpd databases
+# and text summaries under gpurun_out/prof/; the summaries are then copied into profiles/.
 set -x
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/prof
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/stats -o c2 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof/bench_under_stats.json 2> $R/gpurun_out/prof/stats.err
-ls -R $R/gpurun_out/prof/stats | head -30
-# PMC pass 1: SQ counters
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -d $R/gpurun_out/prof/pmc_sq -o c2 -- python $R/bench.py --reads 2000000 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof/pmc_sq.err
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $R/gpurun_out/prof/pmc_lds -o c2 -- python $R/bench.py --reads 2000000 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof/pmc_lds.err
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/prof/pmc_fetch -o c2 -- python $R/bench.py --reads 2000000 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/prof/pmc_write -o c2 -- python $R/bench.py --reads 2000000 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/prof/pmc_write.err
-find $R/gpurun_out/prof -name "*.csv" | head -20
-du -sh $R/gpurun_out/prof
+# 1. kernel trace + stats of the SAME command bench.py's default run uses (C2, 10 M reads)
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o c2 -- python $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+python $R/tools/rocprof_summary.py $OUT/stats/c2_results.db > $OUT/c2_kernel_stats.txt
+# 2. PMC passes (separate runs, counters only), smaller batch
+B="python $R/bench.py --reads 2000000 --steps 1 --warmup 0 --no-cpu-baseline"
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -d $OUT/pmc_sq -o p -- $B > /dev/null 2> $OUT/pmc_sq.err
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_lds -o p -- $B > /dev/null 2> $OUT/pmc_lds.err
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- $B > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- $B > /dev/null 2> $OUT/pmc_write.err
+for d in pmc_sq pmc_lds pmc_fetch pmc_write; do python $R/tools/rocprof_summary.py $OUT/$d/p_results.db phred > $OUT/$d.txt; done
+rm -rf $OUT/stats $OUT/pmc_sq $OUT/pmc_lds $OUT/pmc_fetch $OUT/pmc_write
+ls -la $OUT
