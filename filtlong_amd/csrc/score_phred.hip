@@ -278,15 +278,36 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredAr
             // ---------------- whole round in the steady state ----------------
             if (tro_pos != r_lo - ws) tro = ring_off(r_lo - ws);
             uint4 lead[PPR];
-            uint32_t tw[PPR][4];
 #pragma unroll
             for (int kk = 0; kk < PPR; ++kk) lead[kk] = *reinterpret_cast<const uint4 *>(lead_p + kk * 16);
+            // Trailing bytes of the round: PPR + 1 ALIGNED 16-byte ring pieces (conflict-free b128 rows), then a
+            // funnel shift by the constant (tro & 15).  Dword-granular reads would be 4-way bank conflicted
+            // because every row stride is a multiple of 16 bytes.
+            uint32_t x[(PPR + 1) * 4];
+            {
+                int o = tro & ~15;
 #pragma unroll
-            for (int kk = 0; kk < PPR; ++kk) {
-                trail16(my_row, tro, tw[kk]);
-                tro += 16;
-                if (tro >= ring_len) tro -= ring_len;
+                for (int kk = 0; kk <= PPR; ++kk) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(my_row + o);
+                    x[4 * kk + 0] = v.x; x[4 * kk + 1] = v.y; x[4 * kk + 2] = v.z; x[4 * kk + 3] = v.w;
+                    o += 16;
+                    if (o >= ring_len) o -= ring_len;
+                }
             }
+            uint32_t tw[PPR][4];
+            const uint32_t bsh = (uint32_t)tro & 3u;
+#define FLX_FUNNEL(D)                                                                               \
+    _Pragma("unroll") for (int kk = 0; kk < PPR; ++kk) _Pragma("unroll") for (int d = 0; d < 4; ++d) \
+        tw[kk][d] = __builtin_amdgcn_alignbyte(x[4 * kk + (D) + d + 1], x[4 * kk + (D) + d], bsh);
+            switch ((tro >> 2) & 3) {  // wave-uniform and constant for the whole launch
+                case 0: FLX_FUNNEL(0) break;
+                case 1: FLX_FUNNEL(1) break;
+                case 2: FLX_FUNNEL(2) break;
+                default: FLX_FUNNEL(3) break;
+            }
+#undef FLX_FUNNEL
+            tro += CH;
+            if (tro >= ring_len) tro -= ring_len;
             tro_pos = r_hi - ws;
 #pragma unroll
             for (int kk = 0; kk < PPR; ++kk) {
