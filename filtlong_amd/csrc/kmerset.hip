@@ -1,34 +1,550 @@
-// kmerset.hip — seam 1 (reference 16-mer set) and k-mer scoring; placeholder until the k-mer path lands.
+// kmerset.hip — seam 1: the reference 16-mer set on the device.
+//
+// Replaces the reference's Kmers (src/kmers.cpp:28-172): an std::unordered_set<uint32_t> built from an
+// assembly (every 16-mer, both strands, src/kmers.cpp:61-72,137-139) and/or from short reads (a 16-mer
+// enters once it has been seen 4 times — or 3 times if the Bloom filter gave a false positive at its first
+// sighting, src/kmers.cpp:142-166), queried by exact lookup (is_kmer_present, src/kmers.cpp:170-172).
+//
+// Device representation: there are only 4^16 = 2^32 possible 16-mers, so an EXACT set is a 512 MiB bitmap
+// (one random 4-byte access per query, no probing, no false positives).  The short-read
+// multiplicity rule is evaluated with three more bitmaps acting as a saturating counter: each occurrence of
+// a 16-mer sets the lowest clear level among seen1, seen2, seen3, present (an atomicOr cascade), so after c
+// occurrences exactly min(c,4) levels are set regardless of the order in which the GPU processes them.
+//
+// The Bloom filter (src/bloom_filter.h, restated bit-exactly: 13 hashes, 1 917 295 480 bits, salts and
+// hash_ap's 4-byte branch) only matters for 16-mers seen exactly 3 times whose 13 Bloom bits were all set
+// by OTHER 16-mers before their first sighting.  finalize() screens for that with a conservative superset
+// test (all 13 bits set by at least two insertions in the final filter) and, for the candidates (expected:
+// none — at Filtlong's filter size the probability is ~1e-15 per 16-mer), replays first-sighting times to
+// decide exactly (resolve_bloom_candidates).
+#include <algorithm>
+
 #include "flx_internal.h"
 #include "kmerset.h"
 
+namespace {
+
+constexpr uint64_t kBitmapWords = 1ull << 27;  // 2^32 bits
+constexpr uint32_t kBloomHashes = 13;          // bloom_parameters::compute_optimal_parameters (n=1e8, p=1e-4)
+constexpr uint64_t kBloomBits = 1917295480ull;
+constexpr uint64_t kBloomWords = (kBloomBits + 31) / 32;
+
+// generate_unique_salt (bloom_filter.h:467-529) with seed 0xA5A5A5A5 (kmers.cpp:34): see oracle/flx_oracle.cpp
+__constant__ uint32_t c_salts[13] = {0x1B5793D2u, 0x81BDFA38u, 0xEB8E30D5u, 0x45B52496u, 0x85C1FE3Cu, 0x3DACB627u,
+                                     0x78776869u, 0x94A40D1Eu, 0x5F9BB638u, 0x40FB59D5u, 0x8174BDB2u, 0x0B466EAAu,
+                                     0x209D29A7u};
+
+__device__ __forceinline__ uint32_t bloom_index(uint32_t kmer, int i) {
+    uint32_t h = c_salts[i];
+    h ^= ~((h << 11) + (kmer ^ (h >> 5)));  // hash_ap, 4-byte key (bloom_filter.h:569-583)
+    return h % (uint32_t)kBloomBits;        // compute_indices (bloom_filter.h:461-465)
+}
+
+// src/kmers.cpp:176-196 / 199-219: anything that is not ACGTacgt encodes as 0 on BOTH strands
+__device__ __forceinline__ uint32_t base_fwd(uint8_t c) {
+    switch (c) {
+        case 'C': case 'c': return 1u;
+        case 'G': case 'g': return 2u;
+        case 'T': case 't': return 3u;
+        default: return 0u;
+    }
+}
+__device__ __forceinline__ uint32_t base_rev_code(uint8_t c) {  // the 2-bit value placed in the top bits
+    switch (c) {
+        case 'G': case 'g': return 1u;
+        case 'C': case 'c': return 2u;
+        case 'A': case 'a': return 3u;
+        default: return 0u;
+    }
+}
+
+__device__ __forceinline__ bool test_bit(const uint32_t *bm, uint32_t k) { return (bm[k >> 5] >> (k & 31)) & 1u; }
+__device__ __forceinline__ bool set_bit(uint32_t *bm, uint32_t k) {  // returns the previous value
+    const uint32_t m = 1u << (k & 31);
+    return (atomicOr(&bm[k >> 5], m) & m) != 0;
+}
+
+// One thread per 16-mer START position of the packed reference sequences.  `pos_base[s]` is the number of
+// start positions of sequences before s (exclusive scan of max(len-15,0)), so the grid is flat.
+template <bool MULTI>
+__global__ void __launch_bounds__(256) k_add_reference(const uint8_t *bases, const uint64_t *offsets,
+                                                       const int64_t *lengths, const uint64_t *pos_base,
+                                                       uint64_t n_seqs, uint64_t n_pos, uint32_t *present,
+                                                       uint32_t *seen1, uint32_t *seen2, uint32_t *seen3) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_pos) return;
+    // find the sequence: largest s with pos_base[s] <= g
+    uint64_t lo = 0, hi = n_seqs;
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (pos_base[mid] <= g) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t p = g - pos_base[lo];  // start position inside the sequence
+    const uint8_t *s = bases + offsets[lo] + p;
+    uint32_t f = 0, r = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {  // starting_kmer_to_bits_forward / _reverse, kmers.cpp:222-239
+        const uint8_t c = s[i];
+        f = (f << 2) | base_fwd(c);
+        r = (r >> 2) | (base_rev_code(c) << 30);
+    }
+    (void)lengths;
+    const uint32_t two[2] = {f, r};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t k = two[q];
+        if (!MULTI) {
+            if (!test_bit(present, k)) set_bit(present, k);  // add_kmer_require_one_copy
+        } else {
+            // add_kmer_require_multiple_copies: already in the set (assembly, or promoted) -> nothing to do;
+            // otherwise raise the saturating count by one level.
+            if (test_bit(present, k)) continue;
+            if (!set_bit(seen1, k)) continue;
+            if (!set_bit(seen2, k)) continue;
+            if (!set_bit(seen3, k)) continue;
+            set_bit(present, k);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_popcount(const uint32_t *bm, uint64_t n_words, unsigned long long *out) {
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x)
+        acc += __popc(bm[i]);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+// Final Bloom filter with multiplicity: F1 = bit set by >= 1 distinct inserted 16-mer, F2 = by >= 2 insertions.
+// Every distinct short-read 16-mer that was not already in the assembly set is assumed to insert (a superset of
+// the truth: false-positive 16-mers do not insert), which makes the candidate test below conservative.
+__global__ void __launch_bounds__(256) k_bloom_fill(const uint32_t *seen1, uint64_t n_words, uint32_t *F1, uint32_t *F2) {
+    for (uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < n_words; wi += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t w = seen1[wi];
+        while (w) {
+            const int b = __ffs(w) - 1;
+            w &= w - 1;
+            const uint32_t k = (uint32_t)(wi << 5) | (uint32_t)b;
+            for (int i = 0; i < (int)kBloomHashes; ++i) {
+                const uint32_t idx = bloom_index(k, i);
+                if (set_bit(F1, idx)) set_bit(F2, idx);
+            }
+        }
+    }
+}
+
+// Candidates for "Bloom false positive at first sighting": seen exactly 3 times (otherwise the outcome does not
+// depend on the filter) and all 13 bits set at least twice in the final filter.
+__global__ void __launch_bounds__(256) k_bloom_candidates(const uint32_t *seen1, const uint32_t *seen3,
+                                                          const uint32_t *present, uint64_t n_words, const uint32_t *F2,
+                                                          uint32_t *cand, unsigned int *n_cand, unsigned int cap,
+                                                          int only_count3) {
+    for (uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < n_words; wi += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t w = only_count3 ? (seen3[wi] & ~present[wi]) : seen1[wi];
+        while (w) {
+            const int b = __ffs(w) - 1;
+            w &= w - 1;
+            const uint32_t k = (uint32_t)(wi << 5) | (uint32_t)b;
+            bool all = true;
+            for (int i = 0; i < (int)kBloomHashes && all; ++i) all = test_bit(F2, bloom_index(k, i));
+            if (all) {
+                const unsigned int at = atomicAdd(n_cand, 1u);
+                if (at < cap) cand[at] = k;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_contains(const uint32_t *present, const uint32_t *kmers, uint64_t n, uint8_t *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = test_bit(present, kmers[i]) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_set_bits(uint32_t *bm, const uint32_t *kmers, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) set_bit(bm, kmers[i]);
+}
+
+// First-sighting times for the exact Bloom replay (only when candidates exist).  Occurrence index of the 16-mer
+// starting at position p of sequence s: tau = 2 * (global start position) + strand, which is the order in which
+// the reference's loop visits them (forward then reverse at every position, sequences in file order, -1 before -2;
+// src/kmers.cpp:106-121).  watch_keys is a small sorted list of 16-mers (candidates) or Bloom bit indices.
+__device__ __forceinline__ int find_sorted(const uint32_t *a, int n, uint32_t key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < n && a[lo] == key) ? lo : -1;
+}
+
+__global__ void __launch_bounds__(256) k_first_sightings(const uint8_t *bases, const uint64_t *offsets,
+                                                         const uint64_t *pos_base, uint64_t n_seqs, uint64_t n_pos,
+                                                         uint64_t tau_base, const uint32_t *asm_present,
+                                                         const uint32_t *cand_sorted, int n_cand,
+                                                         const uint32_t *bits_sorted, int n_bits,
+                                                         unsigned long long *cand_tau, unsigned long long *bit_tau_noncand) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_pos) return;
+    uint64_t lo = 0, hi = n_seqs;
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (pos_base[mid] <= g) lo = mid;
+        else hi = mid;
+    }
+    const uint8_t *s = bases + offsets[lo] + (g - pos_base[lo]);
+    uint32_t f = 0, r = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint8_t c = s[i];
+        f = (f << 2) | base_fwd(c);
+        r = (r >> 2) | (base_rev_code(c) << 30);
+    }
+    const uint32_t two[2] = {f, r};
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t k = two[q];
+        if (test_bit(asm_present, k)) continue;  // never reaches the Bloom filter (kmers.cpp:144-145)
+        const unsigned long long tau = tau_base + 2ull * g + (unsigned long long)q;
+        const int ci = find_sorted(cand_sorted, n_cand, k);
+        if (ci >= 0) {
+            atomicMin(&cand_tau[ci], tau);
+        } else {  // definitely inserts at its first sighting: earliest time it sets each watched bit
+            for (int i = 0; i < (int)kBloomHashes; ++i) {
+                const int bi = find_sorted(bits_sorted, n_bits, bloom_index(k, i));
+                if (bi >= 0) atomicMin(&bit_tau_noncand[bi], tau);
+            }
+        }
+    }
+}
+
+}  // namespace
+
 struct flx_kmerset {
-    flx_ctx *ctx;
-    bool final_;
-    uint64_t size;
+    flx_ctx *ctx = nullptr;
+    bool final_ = false;
+    bool has_short = false;
+    uint64_t size = 0;
+    uint32_t *present = nullptr;        // 512 MiB
+    uint32_t *asm_only = nullptr;       // copy of `present` taken when the first short reads arrive (512 MiB)
+    uint32_t *seen1 = nullptr, *seen2 = nullptr, *seen3 = nullptr;
+    // short-read sequences kept on the device until finalize (only replayed if Bloom candidates exist)
+    struct Batch {
+        uint8_t *bases;
+        uint64_t *offsets;
+        uint64_t *pos_base;
+        uint64_t n_seqs, n_pos;
+    };
+    std::vector<Batch> short_batches;
+    uint64_t bloom_candidates = 0;
+    uint64_t bloom_false_positives = 0;
 };
 
 bool flx_kmerset_is_final(const flx_kmerset *set) { return set->final_; }
-const uint32_t *flx_kmerset_bitmap(const flx_kmerset *) { return nullptr; }
+const uint32_t *flx_kmerset_bitmap(const flx_kmerset *set) { return set->present; }
 
 extern "C" int flx_kmerset_create(flx_ctx *ctx, flx_kmerset **out) {
     if (!ctx || !out) return FLX_ERR_INVALID;
-    *out = new flx_kmerset{ctx, false, 0};
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    flx_kmerset *s = new flx_kmerset();
+    s->ctx = ctx;
+    hipError_t e = hipMalloc((void **)&s->present, kBitmapWords * 4);
+    if (e != hipSuccess) {
+        delete s;
+        return flx_fail(ctx, FLX_ERR_NOMEM, "k-mer bitmap (512 MiB): %s", hipGetErrorString(e));
+    }
+    FLX_HIP(ctx, hipMemsetAsync(s->present, 0, kBitmapWords * 4, ctx->stream));
+    *out = s;
     return FLX_OK;
 }
-extern "C" void flx_kmerset_destroy(flx_kmerset *set) { delete set; }
-extern "C" int flx_kmerset_add_assembly(flx_kmerset *set, const uint8_t *, const uint64_t *, const int64_t *, uint64_t) {
-    return flx_fail(set->ctx, FLX_ERR_STATE, "k-mer set build not implemented yet");
+
+static void free_batches(flx_kmerset *s) {
+    for (auto &b : s->short_batches) {
+        (void)hipFree(b.bases);
+        (void)hipFree(b.offsets);
+        (void)hipFree(b.pos_base);
+    }
+    s->short_batches.clear();
 }
-extern "C" int flx_kmerset_add_short_reads(flx_kmerset *set, const uint8_t *, const uint64_t *, const int64_t *, uint64_t) {
-    return flx_fail(set->ctx, FLX_ERR_STATE, "k-mer set build not implemented yet");
+
+extern "C" void flx_kmerset_destroy(flx_kmerset *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    free_batches(s);
+    for (uint32_t *p : {s->present, s->asm_only, s->seen1, s->seen2, s->seen3})
+        if (p) (void)hipFree(p);
+    delete s;
 }
-extern "C" int flx_kmerset_finalize(flx_kmerset *set) { set->final_ = true; return FLX_OK; }
-extern "C" uint64_t flx_kmerset_size(const flx_kmerset *set) { return set ? set->size : 0; }
-extern "C" int flx_kmerset_contains(const flx_kmerset *set, const uint32_t *, uint64_t, uint8_t *) {
-    return flx_fail(set->ctx, FLX_ERR_STATE, "k-mer set build not implemented yet");
+
+// uploads the packed sequences and the flat position index; returns device pointers in `b`
+static int upload_sequences(flx_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, const int64_t *lengths,
+                            uint64_t n_seqs, flx_kmerset::Batch &b) {
+    std::vector<uint64_t> pos_base(n_seqs + 1);
+    uint64_t np = 0, total = 0;
+    for (uint64_t i = 0; i < n_seqs; ++i) {
+        if (lengths[i] < 0) return flx_fail(ctx, FLX_ERR_INVALID, "negative sequence length");
+        pos_base[i] = np;
+        if (lengths[i] >= 16) np += (uint64_t)lengths[i] - 15;  // sequences shorter than 16 give no 16-mers (kmers.cpp:99-100)
+        total = std::max<uint64_t>(total, offsets[i] + (uint64_t)lengths[i]);
+    }
+    pos_base[n_seqs] = np;
+    // pos_base must be strictly usable by the binary search: sequences without positions share their successor's base,
+    // and "largest s with pos_base[s] <= g" then picks the LAST such s, which is the one that owns position g only if
+    // it has positions.  Compact the index to sequences that have at least one position.
+    std::vector<uint64_t> c_off, c_base;
+    for (uint64_t i = 0; i < n_seqs; ++i)
+        if (lengths[i] >= 16) {
+            c_off.push_back(offsets[i]);
+            c_base.push_back(pos_base[i]);
+        }
+    b.n_seqs = c_off.size();
+    b.n_pos = np;
+    b.bases = nullptr;
+    b.offsets = nullptr;
+    b.pos_base = nullptr;
+    if (np == 0) return FLX_OK;
+    FLX_HIP(ctx, hipMalloc((void **)&b.bases, total + 16));
+    FLX_HIP(ctx, hipMalloc((void **)&b.offsets, b.n_seqs * 8));
+    FLX_HIP(ctx, hipMalloc((void **)&b.pos_base, b.n_seqs * 8));
+    FLX_HIP(ctx, hipMemcpyAsync(b.bases, bases, total, hipMemcpyHostToDevice, ctx->stream));
+    FLX_HIP(ctx, hipMemcpyAsync(b.offsets, c_off.data(), b.n_seqs * 8, hipMemcpyHostToDevice, ctx->stream));
+    FLX_HIP(ctx, hipMemcpyAsync(b.pos_base, c_base.data(), b.n_seqs * 8, hipMemcpyHostToDevice, ctx->stream));
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host vectors go out of scope
+    return FLX_OK;
 }
-int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *, const uint8_t *, uint64_t, const uint64_t *, const int32_t *,
-                       const uint32_t *, uint64_t, const flx_params *, flx_scores *) {
-    return flx_fail(ctx, FLX_ERR_STATE, "k-mer scoring not implemented yet");
+
+extern "C" int flx_kmerset_add_assembly(flx_kmerset *s, const uint8_t *bases, const uint64_t *offsets,
+                                        const int64_t *lengths, uint64_t n_seqs) {
+    if (!s) return FLX_ERR_INVALID;
+    flx_ctx *ctx = s->ctx;
+    if (s->final_) return flx_fail(ctx, FLX_ERR_STATE, "k-mer set is already finalized");
+    if (s->has_short)
+        return flx_fail(ctx, FLX_ERR_STATE, "assembly must be added before short reads (the reference hashes the "
+                                            "assembly first, src/main.cpp:55-58, and the multi-copy rule depends on it)");
+    if (n_seqs == 0) return FLX_OK;
+    if (!bases || !offsets || !lengths) return flx_fail(ctx, FLX_ERR_INVALID, "NULL sequence arrays");
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    flx_kmerset::Batch b;
+    FLX_CHECK(upload_sequences(ctx, bases, offsets, lengths, n_seqs, b));
+    if (b.n_pos) {
+        flx_time_begin(ctx, "flx_kmerset_add_assembly");
+        hipLaunchKernelGGL(k_add_reference<false>, dim3((unsigned)((b.n_pos + 255) / 256)), dim3(256), 0, ctx->stream,
+                           b.bases, b.offsets, (const int64_t *)nullptr, b.pos_base, b.n_seqs, b.n_pos, s->present,
+                           (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        flx_time_end(ctx);
+        FLX_HIP(ctx, hipGetLastError());
+        FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(b.bases);
+        (void)hipFree(b.offsets);
+        (void)hipFree(b.pos_base);
+    }
+    return FLX_OK;
+}
+
+extern "C" int flx_kmerset_add_short_reads(flx_kmerset *s, const uint8_t *bases, const uint64_t *offsets,
+                                           const int64_t *lengths, uint64_t n_seqs) {
+    if (!s) return FLX_ERR_INVALID;
+    flx_ctx *ctx = s->ctx;
+    if (s->final_) return flx_fail(ctx, FLX_ERR_STATE, "k-mer set is already finalized");
+    if (n_seqs == 0) return FLX_OK;
+    if (!bases || !offsets || !lengths) return flx_fail(ctx, FLX_ERR_INVALID, "NULL sequence arrays");
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    if (!s->has_short) {
+        for (uint32_t **p : {&s->seen1, &s->seen2, &s->seen3, &s->asm_only}) {
+            hipError_t e = hipMalloc((void **)p, kBitmapWords * 4);
+            if (e != hipSuccess) return flx_fail(ctx, FLX_ERR_NOMEM, "k-mer count bitmap (512 MiB): %s", hipGetErrorString(e));
+        }
+        for (uint32_t *p : {s->seen1, s->seen2, s->seen3}) FLX_HIP(ctx, hipMemsetAsync(p, 0, kBitmapWords * 4, ctx->stream));
+        FLX_HIP(ctx, hipMemcpyAsync(s->asm_only, s->present, kBitmapWords * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        s->has_short = true;
+    }
+    flx_kmerset::Batch b;
+    FLX_CHECK(upload_sequences(ctx, bases, offsets, lengths, n_seqs, b));
+    if (b.n_pos) {
+        flx_time_begin(ctx, "flx_kmerset_add_short_reads");
+        hipLaunchKernelGGL(k_add_reference<true>, dim3((unsigned)((b.n_pos + 255) / 256)), dim3(256), 0, ctx->stream,
+                           b.bases, b.offsets, (const int64_t *)nullptr, b.pos_base, b.n_seqs, b.n_pos, s->present, s->seen1,
+                           s->seen2, s->seen3);
+        flx_time_end(ctx);
+        FLX_HIP(ctx, hipGetLastError());
+        FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        s->short_batches.push_back(b);
+    }
+    return FLX_OK;
+}
+
+// Exact replay of the Bloom filter for the candidate 16-mers (see the file header).  A candidate k with first
+// sighting tau(k) is a false positive iff each of its 13 bits was set strictly before tau(k) by a 16-mer that
+// really inserted.  Non-candidates always insert (they are not false positives even against the FINAL filter);
+// candidates are resolved in tau order, each resolved non-false-positive inserting at its tau.
+static int resolve_bloom_candidates(flx_kmerset *s, std::vector<uint32_t> &cand /* sorted */,
+                                    std::vector<uint8_t> &is_fp) {
+    flx_ctx *ctx = s->ctx;
+    const int nc = (int)cand.size();
+    // watched Bloom bits
+    std::vector<uint32_t> salts = {0x1B5793D2u, 0x81BDFA38u, 0xEB8E30D5u, 0x45B52496u, 0x85C1FE3Cu, 0x3DACB627u, 0x78776869u,
+                                   0x94A40D1Eu, 0x5F9BB638u, 0x40FB59D5u, 0x8174BDB2u, 0x0B466EAAu, 0x209D29A7u};
+    auto bidx = [&](uint32_t k, int i) {
+        uint32_t h = salts[i];
+        h ^= ~((h << 11) + (k ^ (h >> 5)));
+        return h % (uint32_t)kBloomBits;
+    };
+    std::vector<uint32_t> bits;
+    for (uint32_t k : cand)
+        for (int i = 0; i < 13; ++i) bits.push_back(bidx(k, i));
+    std::sort(bits.begin(), bits.end());
+    bits.erase(std::unique(bits.begin(), bits.end()), bits.end());
+    const int nb = (int)bits.size();
+    flx_dbuf d_cand, d_bits, d_ctau, d_btau;
+    FLX_CHECK(flx_dalloc(ctx, d_cand, nc * 4));
+    FLX_CHECK(flx_dalloc(ctx, d_bits, nb * 4));
+    FLX_CHECK(flx_dalloc(ctx, d_ctau, nc * 8));
+    FLX_CHECK(flx_dalloc(ctx, d_btau, nb * 8));
+    FLX_HIP(ctx, hipMemcpy(d_cand.p, cand.data(), nc * 4, hipMemcpyHostToDevice));
+    FLX_HIP(ctx, hipMemcpy(d_bits.p, bits.data(), nb * 4, hipMemcpyHostToDevice));
+    FLX_HIP(ctx, hipMemset(d_ctau.p, 0xff, nc * 8));
+    FLX_HIP(ctx, hipMemset(d_btau.p, 0xff, nb * 8));
+    uint64_t tau_base = 0;
+    for (auto &b : s->short_batches) {
+        if (b.n_pos)
+            hipLaunchKernelGGL(k_first_sightings, dim3((unsigned)((b.n_pos + 255) / 256)), dim3(256), 0, ctx->stream, b.bases,
+                               b.offsets, b.pos_base, b.n_seqs, b.n_pos, tau_base, s->asm_only, d_cand.as<uint32_t>(), nc,
+                               d_bits.as<uint32_t>(), nb, d_ctau.as<unsigned long long>(), d_btau.as<unsigned long long>());
+        tau_base += 2 * b.n_pos;
+    }
+    FLX_HIP(ctx, hipGetLastError());
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> ctau(nc), btau(nb);
+    FLX_HIP(ctx, hipMemcpy(ctau.data(), d_ctau.p, nc * 8, hipMemcpyDeviceToHost));
+    FLX_HIP(ctx, hipMemcpy(btau.data(), d_btau.p, nb * 8, hipMemcpyDeviceToHost));
+    std::vector<int> ord(nc);
+    for (int i = 0; i < nc; ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return ctau[a] < ctau[b]; });
+    is_fp.assign(nc, 0);
+    for (int oi = 0; oi < nc; ++oi) {
+        const int c = ord[oi];
+        bool fp = true;
+        int bi[13];
+        for (int i = 0; i < 13; ++i) {
+            bi[i] = (int)(std::lower_bound(bits.begin(), bits.end(), bidx(cand[c], i)) - bits.begin());
+            if (!(btau[bi[i]] < ctau[c])) fp = false;
+        }
+        is_fp[c] = fp ? 1 : 0;
+        if (!fp)  // it inserts at its first sighting
+            for (int i = 0; i < 13; ++i) btau[bi[i]] = std::min(btau[bi[i]], ctau[c]);
+    }
+    return FLX_OK;
+}
+
+extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
+    if (!s) return FLX_ERR_INVALID;
+    flx_ctx *ctx = s->ctx;
+    if (s->final_) return FLX_OK;
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (s->has_short) {
+        // Bloom screening (see file header)
+        flx_dbuf F1, F2, d_cand, d_n;
+        FLX_CHECK(flx_dalloc(ctx, F1, kBloomWords * 4));
+        FLX_CHECK(flx_dalloc(ctx, F2, kBloomWords * 4));
+        const unsigned cap = 1u << 20;
+        FLX_CHECK(flx_dalloc(ctx, d_cand, (size_t)cap * 4));
+        FLX_CHECK(flx_dalloc(ctx, d_n, 16));
+        FLX_HIP(ctx, hipMemsetAsync(F1.p, 0, kBloomWords * 4, st));
+        FLX_HIP(ctx, hipMemsetAsync(F2.p, 0, kBloomWords * 4, st));
+        FLX_HIP(ctx, hipMemsetAsync(d_n.p, 0, 16, st));
+        flx_time_begin(ctx, "flx_kmerset_bloom_screen");
+        hipLaunchKernelGGL(k_bloom_fill, dim3(8192), dim3(256), 0, st, s->seen1, kBitmapWords, F1.as<uint32_t>(), F2.as<uint32_t>());
+        // 1st: is any 16-mer with exactly 3 sightings a candidate?  (only those change the set)
+        hipLaunchKernelGGL(k_bloom_candidates, dim3(8192), dim3(256), 0, st, s->seen1, s->seen3, s->present, kBitmapWords,
+                           F2.as<uint32_t>(), d_cand.as<uint32_t>(), (unsigned int *)d_n.p, cap, 1);
+        flx_time_end(ctx);
+        unsigned int n3 = 0;
+        FLX_HIP(ctx, hipMemcpyAsync(&n3, d_n.p, 4, hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+        s->bloom_candidates = n3;
+        if (n3 > 0) {
+            // Exact replay needs EVERY candidate non-inserter (any count), because a false-positive 16-mer does not
+            // insert its bits and that can change the filter other 16-mers see.
+            FLX_HIP(ctx, hipMemsetAsync(d_n.p, 0, 16, st));
+            hipLaunchKernelGGL(k_bloom_candidates, dim3(8192), dim3(256), 0, st, s->seen1, s->seen3, s->present, kBitmapWords,
+                               F2.as<uint32_t>(), d_cand.as<uint32_t>(), (unsigned int *)d_n.p, cap, 0);
+            unsigned int nall = 0;
+            FLX_HIP(ctx, hipMemcpyAsync(&nall, d_n.p, 4, hipMemcpyDeviceToHost, st));
+            FLX_HIP(ctx, hipStreamSynchronize(st));
+            if (nall > cap) return flx_fail(ctx, FLX_ERR_CAPACITY, "too many Bloom false-positive candidates (%u)", nall);
+            std::vector<uint32_t> cand(nall);
+            FLX_HIP(ctx, hipMemcpy(cand.data(), d_cand.p, (size_t)nall * 4, hipMemcpyDeviceToHost));
+            std::sort(cand.begin(), cand.end());
+            std::vector<uint8_t> is_fp;
+            FLX_CHECK(resolve_bloom_candidates(s, cand, is_fp));
+            // a false positive starts counting at 2 (kmers.cpp:152-155): 3 sightings are enough
+            std::vector<uint32_t> promote;
+            std::vector<uint32_t> h3(nall);
+            {
+                // which candidates have exactly 3 sightings: seen3 set, present clear
+                flx_dbuf d_q, d_o3, d_op;
+                FLX_CHECK(flx_dalloc(ctx, d_q, (size_t)nall * 4));
+                FLX_CHECK(flx_dalloc(ctx, d_o3, nall));
+                FLX_CHECK(flx_dalloc(ctx, d_op, nall));
+                FLX_HIP(ctx, hipMemcpy(d_q.p, cand.data(), (size_t)nall * 4, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(k_contains, dim3((nall + 255) / 256), dim3(256), 0, st, s->seen3, d_q.as<uint32_t>(), (uint64_t)nall, d_o3.as<uint8_t>());
+                hipLaunchKernelGGL(k_contains, dim3((nall + 255) / 256), dim3(256), 0, st, s->present, d_q.as<uint32_t>(), (uint64_t)nall, d_op.as<uint8_t>());
+                std::vector<uint8_t> o3(nall), op(nall);
+                FLX_HIP(ctx, hipStreamSynchronize(st));
+                FLX_HIP(ctx, hipMemcpy(o3.data(), d_o3.p, nall, hipMemcpyDeviceToHost));
+                FLX_HIP(ctx, hipMemcpy(op.data(), d_op.p, nall, hipMemcpyDeviceToHost));
+                for (unsigned i = 0; i < nall; ++i)
+                    if (is_fp[i]) {
+                        ++s->bloom_false_positives;
+                        if (o3[i] && !op[i]) promote.push_back(cand[i]);
+                    }
+            }
+            if (!promote.empty()) {
+                flx_dbuf d_p;
+                FLX_CHECK(flx_dalloc(ctx, d_p, promote.size() * 4));
+                FLX_HIP(ctx, hipMemcpy(d_p.p, promote.data(), promote.size() * 4, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(k_set_bits, dim3((unsigned)((promote.size() + 255) / 256)), dim3(256), 0, st, s->present,
+                                   d_p.as<uint32_t>(), (uint64_t)promote.size());
+                FLX_HIP(ctx, hipStreamSynchronize(st));
+            }
+        }
+        free_batches(s);
+        for (uint32_t **p : {&s->seen1, &s->seen2, &s->seen3, &s->asm_only}) {
+            (void)hipFree(*p);
+            *p = nullptr;
+        }
+    }
+    // size
+    void *scr;
+    FLX_CHECK(flx_scratch(ctx, 64, &scr));
+    FLX_HIP(ctx, hipMemsetAsync(scr, 0, 8, st));
+    hipLaunchKernelGGL(k_popcount, dim3(4096), dim3(256), 0, st, s->present, kBitmapWords, (unsigned long long *)scr);
+    unsigned long long sz = 0;
+    FLX_HIP(ctx, hipMemcpyAsync(&sz, scr, 8, hipMemcpyDeviceToHost, st));
+    FLX_HIP(ctx, hipStreamSynchronize(st));
+    s->size = sz;
+    s->final_ = true;
+    return FLX_OK;
+}
+
+extern "C" uint64_t flx_kmerset_size(const flx_kmerset *s) { return s ? s->size : 0; }
+
+extern "C" int flx_kmerset_contains(const flx_kmerset *s, const uint32_t *kmers, uint64_t n, uint8_t *present) {
+    if (!s) return FLX_ERR_INVALID;
+    flx_ctx *ctx = s->ctx;
+    if (!s->final_) return flx_fail(ctx, FLX_ERR_STATE, "k-mer set is not finalized");
+    if (n == 0) return FLX_OK;
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    flx_dbuf d_k, d_o;
+    FLX_CHECK(flx_dalloc(ctx, d_k, n * 4));
+    FLX_CHECK(flx_dalloc(ctx, d_o, n));
+    FLX_HIP(ctx, hipMemcpyAsync(d_k.p, kmers, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_contains, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, s->present, d_k.as<uint32_t>(), n,
+                       d_o.as<uint8_t>());
+    FLX_HIP(ctx, hipMemcpyAsync(present, d_o.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FLX_OK;
 }

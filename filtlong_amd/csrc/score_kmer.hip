@@ -1,0 +1,440 @@
+// score_kmer.hip — k-mer mode per-read scoring on gfx950.
+//
+// Replaces the k-mer branch of the reference's Read::Read (src/read.cpp:43-58: rolling 2-bit 16-mer, one
+// set lookup per position, mark bases i-15..i on a hit), first/last covered base (75-84), bad ranges /
+// trim / split -> child ranges (86-130) and the scoring of every child read (131-141), plus the shared
+// mean / window / cut-off code (208-236, 64-73).
+//
+// Two kernels:
+//   k_kmer_cover  (position-parallel)  seq plane -> coverage bit plane (1 bit per base) + per-read covered
+//                 count / first / last.  One workgroup per read; a thread builds the 16 rolling 16-mers ending
+//                 at its 16 positions, issues its 16 bitmap lookups back to back, and turns hits into
+//                 coverage with a 4-step OR-dilation over its own and its right neighbour's hit mask.
+//                 The qualities are 0.0 / 1.0, so the reference's serial FP64 sum is an exact integer:
+//                 mean = 100 * popcount / L needs no serial pass.
+//   k_kmer_fold   (read-serial)  one lane per read walks its coverage bits and replays get_window_quality
+//                 bit-exactly (w -= q[i]/ws; w += q[j]/ws with q/ws in {0, fl(1/ws)}: the drift is real,
+//                 SURVEY §8c test_trim_3 = 0x1.5ffffffffffffp+6), and — under --trim/--split — finds the bad
+//                 zero-runs, the child ranges, and runs the same recurrence for every child on the fly.
+//                 Children never have grandchildren (their coverage is a slice of the parent's),
+//                 so a child's mean/window/cut-offs come from the parent's bits without new lookups.
+#include "flx_internal.h"
+#include "kmerset.h"
+#include "rank_internal.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t code_fwd(uint32_t c) {  // src/kmers.cpp:176-196; anything else -> 0
+    switch (c) {
+        case 'C': case 'c': return 1u;
+        case 'G': case 'g': return 2u;
+        case 'T': case 't': return 3u;
+        default: return 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// coverage
+// ---------------------------------------------------------------------------------------------------
+constexpr int COVER_THREADS = 256;
+constexpr int COVER_SPAN = COVER_THREADS * 16;  // positions per workgroup iteration
+
+__global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *plane, const uint64_t *offsets,
+                                                              const int32_t *lengths, const uint32_t *order,
+                                                              uint64_t n_reads, const uint32_t *bitmap,
+                                                              uint32_t *cov, const uint64_t *cov_off, int32_t *count,
+                                                              int32_t *first, int32_t *last) {
+    __shared__ uint32_t sh_hits[COVER_THREADS];
+    __shared__ uint32_t sh_carry;
+    __shared__ int sh_cnt[COVER_THREADS / 64], sh_first[COVER_THREADS / 64], sh_last[COVER_THREADS / 64];
+    for (uint64_t slot = blockIdx.x; slot < n_reads; slot += gridDim.x) {
+        const uint32_t rid = order ? order[slot] : (uint32_t)slot;
+        const int L = lengths[rid];
+        const uint8_t *seq = plane + offsets[rid];
+        uint32_t *row = cov + (cov_off[rid] >> 2);
+        const int row_words = (((L + 7) / 8 + 15) & ~15) >> 2;
+        const int t = threadIdx.x;
+        int cnt = 0, fst = 0x7fffffff, lst = -1;
+        if (t == 0) sh_carry = 0;
+        __syncthreads();
+        const int n_spans = (L + COVER_SPAN - 1) / COVER_SPAN;
+        for (int sp = n_spans - 1; sp >= 0; --sp) {  // descending: the right neighbour's hits are already known
+            const int p0 = sp * COVER_SPAN + t * 16;
+            uint32_t hits = 0;
+            if (p0 < L && L >= 16) {
+                // bases [p0-16, p0+16): both loads are 16-byte aligned (read starts are)
+                uint4 a = make_uint4(0, 0, 0, 0);
+                if (p0 > 0) a = *reinterpret_cast<const uint4 *>(seq + p0 - 16);
+                const uint4 b = *reinterpret_cast<const uint4 *>(seq + p0);
+                const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                uint32_t k = 0;
+#pragma unroll
+                for (int j = 1; j < 16; ++j) k = (k << 2) | code_fwd((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                uint32_t kmers[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    k = (k << 2) | code_fwd((w[4 + (j >> 2)] >> (8 * (j & 3))) & 0xffu);
+                    kmers[j] = k;  // 16-mer ending at position p0 + j
+                }
+                uint32_t words[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) words[j] = bitmap[kmers[j] >> 5];  // 16 independent lookups in flight
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int i = p0 + j;
+                    const bool valid = i >= 15 && i < L;
+                    if (valid && ((words[j] >> (kmers[j] & 31)) & 1u)) hits |= 1u << j;
+                }
+            }
+            sh_hits[t] = hits;
+            __syncthreads();
+            const uint32_t next = (t + 1 < COVER_THREADS) ? sh_hits[t + 1] : sh_carry;
+            uint32_t x = hits | (next << 16);
+            x |= x >> 1;
+            x |= x >> 2;
+            x |= x >> 4;
+            x |= x >> 8;  // bit j = OR of hit bits j .. j+15: base p0+j lies in a present 16-mer
+            uint32_t c16 = x & 0xffffu;
+            if (p0 >= L) c16 = 0;
+            else if (p0 + 16 > L) c16 &= (1u << (L - p0)) - 1u;
+            cnt += __popc(c16);
+            if (c16) {
+                fst = min(fst, p0 + (__ffs(c16) - 1));
+                lst = max(lst, p0 + (32 - __clz(c16)));
+            }
+            const uint32_t hi = __shfl_down(c16, 1, 64);
+            const int word = p0 >> 5;
+            if ((t & 1) == 0 && word < row_words) row[word] = c16 | (hi << 16);
+            __syncthreads();
+            if (t == 0) sh_carry = hits;
+            __syncthreads();
+        }
+        // zero the padding words beyond the spans (rows are padded to 16 bytes)
+        for (int wd = n_spans * (COVER_SPAN / 32) + t; wd < row_words; wd += COVER_THREADS) row[wd] = 0;
+        // block reduction of count / first / last
+        for (int o = 32; o > 0; o >>= 1) {
+            cnt += __shfl_xor(cnt, o, 64);
+            fst = min(fst, __shfl_xor(fst, o, 64));
+            lst = max(lst, __shfl_xor(lst, o, 64));
+        }
+        if ((t & 63) == 0) {
+            sh_cnt[t >> 6] = cnt;
+            sh_first[t >> 6] = fst;
+            sh_last[t >> 6] = lst;
+        }
+        __syncthreads();
+        if (t == 0) {
+            int c = 0, f = 0x7fffffff, l = -1;
+            for (int wv = 0; wv < COVER_THREADS / 64; ++wv) {
+                c += sh_cnt[wv];
+                f = min(f, sh_first[wv]);
+                l = max(l, sh_last[wv]);
+            }
+            count[rid] = c;
+            first[rid] = c ? f : -1;  // m_first_base_in_kmer / m_last_base_in_kmer, src/read.cpp:75-84
+            last[rid] = c ? l : -1;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// serial fold over the coverage bits
+// ---------------------------------------------------------------------------------------------------
+struct FoldArgs {
+    const uint32_t *cov;
+    const uint64_t *cov_off;
+    const int32_t *lengths;
+    const uint32_t *order;
+    uint64_t n_reads;
+    const int32_t *count;
+    const int32_t *first;
+    const int32_t *last;
+    int ws;
+    double ws_d;
+    double delta;  // fl(1.0 / ws): the value of q/ws for a covered base (src/read.cpp:228-229)
+    double clamp;  // 0.5 / ws
+    flx_params p;
+    double *mean_q;
+    double *window_q;
+    uint8_t *passed;
+    // children
+    uint32_t *n_child;              // [n] (count pass)
+    const uint64_t *child_offsets;  // [n+1] (emit pass)
+    int32_t *child_ranges;
+    double *child_mean_q;
+    double *child_window_q;
+    uint8_t *child_passed;
+};
+
+__device__ __forceinline__ uint8_t cutoffs(const flx_params &p, int L, double mean, double window) {
+    bool ok = true;  // src/read.cpp:64-73
+    if (p.min_length_set && L < p.min_length) ok = false;
+    else if (p.max_length_set && L > p.max_length) ok = false;
+    else if (p.min_mean_q_set && mean < p.min_mean_q) ok = false;
+    else if (p.min_window_q_set && window < p.min_window_q) ok = false;
+    return ok ? 1 : 0;
+}
+
+struct Win {  // one sliding-window recurrence (parent or current child)
+    int cnt;    // covered bases so far
+    double w;   // window quality
+    double mn;  // its minimum
+};
+
+__device__ __forceinline__ double window_result(const FoldArgs &a, int len, int cnt, double mn) {
+    const double mean = 100.0 * (double)cnt / (double)len;
+    if (len <= a.ws) return mean;  // src/read.cpp:217-218
+    if (mn < a.clamp) mn = 0.0;
+    return 100.0 * mn;
+}
+
+// MODE 0: parent only (no --trim/--split).  MODE 1: count children.  MODE 2: emit children.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
+    const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = slot < a.n_reads;
+    uint32_t rid = 0;
+    int L = 0;
+    if (live) {
+        rid = a.order ? a.order[slot] : (uint32_t)slot;
+        L = a.lengths[rid];
+    }
+    int Lmax = L;
+    for (int o = 32; o > 0; o >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, o, 64));
+    const uint32_t *row = live ? a.cov + (a.cov_off[rid] >> 2) : a.cov;
+    const int ws = a.ws;
+    const double delta = a.delta;
+
+    Win P = {0, 0.0, 0.0};
+    // child machinery
+    Win C = {0, 0.0, 0.0};
+    Win S = {0, 0.0, 0.0};  // snapshot of C at the start of the current zero run
+    int cs = 0;             // start of the current child candidate
+    int zs = -1;            // start of the current zero run (-1: none)
+    bool any_bad = false;
+    uint32_t nchild = 0;
+    const uint64_t cbase = (MODE == 2 && live) ? a.child_offsets[rid] : 0;
+    const bool split_set = a.p.split_set != 0;
+    const bool trim = a.p.trim != 0;
+    const int split = a.p.split;
+
+    auto emit_child = [&](int start, int end, const Win &st) {
+        if (end <= start) return;
+        if (MODE == 2) {
+            const int len = end - start;
+            const double mean = 100.0 * (double)st.cnt / (double)len;
+            const double window = window_result(a, len, st.cnt, st.mn);
+            const uint64_t at = cbase + nchild;
+            a.child_ranges[2 * at] = start;
+            a.child_ranges[2 * at + 1] = end;
+            a.child_mean_q[at] = mean;
+            a.child_window_q[at] = window;
+            a.child_passed[at] = cutoffs(a.p, len, mean, window);
+        }
+        ++nchild;
+    };
+
+    // trailing stream: word index / bit offset of position (j - ws), advanced in lock step with j
+    uint32_t lead_w = 0, trail_w = 0;
+    for (int j = 0; j < Lmax; ++j) {
+        if ((j & 31) == 0) lead_w = (j < L) ? row[j >> 5] : 0u;
+        const int tj = j - ws;
+        if (tj >= 0 && ((tj & 31) == 0 || j == ws)) trail_w = (tj < L) ? row[tj >> 5] : 0u;
+        const bool act = j < L;
+        const uint32_t b = act ? ((lead_w >> (j & 31)) & 1u) : 0u;
+        const uint32_t tb = (act && tj >= 0) ? ((trail_w >> (tj & 31)) & 1u) : 0u;
+        const double dl = b ? delta : 0.0;
+        const double dt = tb ? delta : 0.0;
+
+        if (act) {
+            // ---- parent window (src/read.cpp:216-236) ----
+            P.cnt += (int)b;
+            if (j == ws - 1) {
+                P.w = (double)P.cnt / a.ws_d;
+                P.mn = P.w;
+            } else if (j >= ws) {
+                P.w -= dt;
+                P.w += dl;
+                if (P.w < P.mn) P.mn = P.w;
+            }
+            if (MODE != 0) {
+                // ---- zero runs -> bad ranges -> children (src/read.cpp:89-141) ----
+                if (b == 0 && zs < 0) {
+                    zs = j;
+                    S = C;
+                }
+                if (b == 1 && zs >= 0) {  // the run [zs, j) has ended
+                    const bool bad = (split_set && j - zs >= split) || (trim && zs == 0);
+                    if (bad) {
+                        any_bad = true;
+                        emit_child(cs, zs, S);
+                        cs = j;
+                        C.cnt = 0;
+                        C.w = 0.0;
+                        C.mn = 0.0;
+                    }
+                    zs = -1;
+                }
+                const int k = j - cs;  // position inside the current child
+                C.cnt += (int)b;
+                if (k == ws - 1) {
+                    C.w = (double)C.cnt / a.ws_d;
+                    C.mn = C.w;
+                } else if (k >= ws) {
+                    C.w -= dt;
+                    C.w += dl;
+                    if (C.w < C.mn) C.mn = C.w;
+                }
+            }
+        }
+    }
+    if (!live) return;
+
+    if (MODE != 0) {
+        int end = L;
+        if (zs >= 0) {  // the read ends inside a zero run [zs, L)
+            const bool bad = (split_set && L - zs >= split) || (trim && zs > 0);
+            if (bad) {
+                any_bad = true;
+                end = zs;
+                C = S;
+            }
+        }
+        if (any_bad) emit_child(cs, end, C);
+        else nchild = 0;
+    }
+    if (MODE == 1) a.n_child[rid] = nchild;
+    if (MODE != 2) {
+        const double mean = 100.0 * (double)a.count[rid] / (double)L;  // exact: the qualities are 0.0 / 1.0
+        const double window = window_result(a, L, P.cnt, P.mn);
+        a.mean_q[rid] = mean;
+        a.window_q[rid] = window;
+        a.passed[rid] = cutoffs(a.p, L, mean, window);
+    }
+}
+
+__global__ void k_cov_row_bytes(uint64_t n, const int32_t *lengths, int64_t *row_bytes) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) row_bytes[i] = (int64_t)((((uint64_t)lengths[i] + 7) / 8 + 15) & ~15ull);
+}
+
+__global__ void k_widen_u32_i64(uint64_t n, const uint32_t *in, int64_t *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int64_t)in[i];
+}
+
+}  // namespace
+
+int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_plane, uint64_t plane_bytes,
+                       const uint64_t *d_offsets, const int32_t *d_lengths, const uint32_t *d_order,
+                       uint64_t n_reads, const flx_params *params, flx_scores *out) {
+    (void)plane_bytes;
+    out->n_children = 0;
+    if (n_reads == 0) return FLX_OK;
+    hipStream_t st = ctx->stream;
+    const bool want_children = params->trim || params->split_set;
+    if (want_children && !out->child_offsets)
+        return flx_fail(ctx, FLX_ERR_INVALID, "trim/split requested but child_offsets is NULL");
+    const unsigned nb = (unsigned)((n_reads + 255) / 256);
+
+    // ---- coverage plane layout: row i = ceil(L/8) bytes rounded up to 16, rows packed by an exclusive scan ----
+    flx_dbuf d_rowb, d_covoff, d_cnt, d_first_tmp, d_last_tmp, d_scanws, d_nchild;
+    FLX_CHECK(flx_dalloc(ctx, d_rowb, (n_reads + 1) * 8));
+    FLX_CHECK(flx_dalloc(ctx, d_covoff, (n_reads + 1) * 8));
+    FLX_CHECK(flx_dalloc(ctx, d_cnt, n_reads * 4));
+    const size_t scan_ws = flx_radix_sort_workspace(n_reads + 1);
+    FLX_CHECK(flx_dalloc(ctx, d_scanws, scan_ws));
+    int32_t *first = out->first, *last = out->last;
+    if (!first) {
+        FLX_CHECK(flx_dalloc(ctx, d_first_tmp, n_reads * 4));
+        first = d_first_tmp.as<int32_t>();
+    }
+    if (!last) {
+        FLX_CHECK(flx_dalloc(ctx, d_last_tmp, n_reads * 4));
+        last = d_last_tmp.as<int32_t>();
+    }
+    FLX_HIP(ctx, hipMemsetAsync(d_rowb.p, 0, (n_reads + 1) * 8, st));
+    hipLaunchKernelGGL(k_cov_row_bytes, dim3(nb), dim3(256), 0, st, n_reads, d_lengths, d_rowb.as<int64_t>());
+    FLX_CHECK(flx_exclusive_scan_i64(ctx, n_reads + 1, d_rowb.as<int64_t>(), d_covoff.as<int64_t>(), d_scanws.p, scan_ws));
+    int64_t cov_bytes = 0;
+    FLX_HIP(ctx, hipMemcpyAsync(&cov_bytes, d_covoff.as<int64_t>() + n_reads, 8, hipMemcpyDeviceToHost, st));
+    FLX_HIP(ctx, hipStreamSynchronize(st));
+    flx_dbuf d_cov;
+    FLX_CHECK(flx_dalloc(ctx, d_cov, (size_t)cov_bytes + 64));
+
+    // ---- kernel 1: lookups -> coverage bits ----
+    {
+        const unsigned grid = (unsigned)std::min<uint64_t>(n_reads, 1u << 20);
+        flx_time_begin(ctx, "flx_score_kmer_cover");
+        hipLaunchKernelGGL(k_kmer_cover, dim3(grid), dim3(COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
+                           flx_kmerset_bitmap(set), d_cov.as<uint32_t>(), d_covoff.as<uint64_t>(), d_cnt.as<int32_t>(), first,
+                           last);
+        flx_time_end(ctx);
+    }
+
+    // ---- kernel 2: serial fold ----
+    FoldArgs a;
+    a.cov = d_cov.as<uint32_t>();
+    a.cov_off = d_covoff.as<uint64_t>();
+    a.lengths = d_lengths;
+    a.order = d_order;
+    a.n_reads = n_reads;
+    a.count = d_cnt.as<int32_t>();
+    a.first = first;
+    a.last = last;
+    a.ws = params->window_size;
+    a.ws_d = (double)(size_t)params->window_size;
+    {
+        volatile double one = 1.0, half = 0.5, wsd = a.ws_d;
+        a.delta = one / wsd;
+        a.clamp = half / wsd;
+    }
+    a.p = *params;
+    a.mean_q = out->mean_q;
+    a.window_q = out->window_q;
+    a.passed = out->passed;
+    a.n_child = nullptr;
+    a.child_offsets = nullptr;
+    a.child_ranges = out->child_ranges;
+    a.child_mean_q = out->child_mean_q;
+    a.child_window_q = out->child_window_q;
+    a.child_passed = out->child_passed;
+
+    if (!want_children) {
+        flx_time_begin(ctx, "flx_score_kmer_fold");
+        hipLaunchKernelGGL(k_kmer_fold<0>, dim3(nb), dim3(256), 0, st, a);
+        flx_time_end(ctx);
+        if (out->child_offsets) FLX_HIP(ctx, hipMemsetAsync(out->child_offsets, 0, (n_reads + 1) * 8, st));
+        FLX_HIP(ctx, hipGetLastError());
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+        return FLX_OK;
+    }
+
+    FLX_CHECK(flx_dalloc(ctx, d_nchild, (n_reads + 1) * 4));
+    FLX_HIP(ctx, hipMemsetAsync(d_nchild.p, 0, (n_reads + 1) * 4, st));
+    a.n_child = d_nchild.as<uint32_t>();
+    flx_time_begin(ctx, "flx_score_kmer_fold");
+    hipLaunchKernelGGL(k_kmer_fold<1>, dim3(nb), dim3(256), 0, st, a);
+    flx_time_end(ctx);
+    // child_offsets = exclusive scan of the counts (n + 1 entries; the last one is the total)
+    hipLaunchKernelGGL(k_widen_u32_i64, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, st, n_reads + 1,
+                       d_nchild.as<uint32_t>(), d_rowb.as<int64_t>());
+    FLX_CHECK(flx_exclusive_scan_i64(ctx, n_reads + 1, d_rowb.as<int64_t>(), (int64_t *)out->child_offsets, d_scanws.p, scan_ws));
+    int64_t total_children = 0;
+    FLX_HIP(ctx, hipMemcpyAsync(&total_children, (int64_t *)out->child_offsets + n_reads, 8, hipMemcpyDeviceToHost, st));
+    FLX_HIP(ctx, hipStreamSynchronize(st));
+    out->n_children = (uint64_t)total_children;
+    if ((uint64_t)total_children > out->child_capacity)
+        return flx_fail(ctx, FLX_ERR_CAPACITY, "child outputs need room for %lld children (capacity %llu)",
+                        (long long)total_children, (unsigned long long)out->child_capacity);
+    if (total_children > 0) {
+        a.child_offsets = out->child_offsets;
+        flx_time_begin(ctx, "flx_score_kmer_fold");
+        hipLaunchKernelGGL(k_kmer_fold<2>, dim3(nb), dim3(256), 0, st, a);
+        flx_time_end(ctx);
+    }
+    FLX_HIP(ctx, hipGetLastError());
+    FLX_HIP(ctx, hipStreamSynchronize(st));
+    return FLX_OK;
+}

@@ -1,0 +1,152 @@
+"""HIP k-mer path vs the reference's golden vectors and the oracle — bit exact.
+
+seam 1: reference 16-mer set (assembly rule, >= 4 copies rule, assembly-then-short-reads, size, membership);
+seam 2: coverage marking, mean/window (drift included), first/last, bad ranges -> child ranges, child scores.
+"""
+import gzip
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _cases
+import _e2e_checks
+import _oracle
+import _pipeline
+from filtlong_amd import api
+
+pytestmark = pytest.mark.gpu
+FIX = _cases.FIXTURES
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def be(ctx):
+    return _pipeline.HipBackend(ctx)
+
+
+@pytest.fixture(scope="module")
+def synth(be):
+    contigs = _cases.synth_reference()
+    r1, r2 = _cases.short_read_pairs(contigs)
+    return {"contigs": contigs, "sr": [r1, r2],
+            "asm": be.kmers(assembly=contigs), "short": be.kmers(short_files=[r1, r2]),
+            "both": be.kmers(assembly=contigs, short_files=[r1])}
+
+
+@pytest.fixture(scope="module")
+def fixture_sets(be):
+    asm = [s for _, s, _ in _oracle.read_fastx(os.path.join(FIX, "test_reference.fasta"))]
+    sr = [[s for _, s, _ in _oracle.read_fastx(os.path.join(FIX, f))]
+          for f in ("test_reference_1.fastq.gz", "test_reference_2.fastq.gz")]
+    return {"asm": be.kmers(assembly=asm), "short": be.kmers(short_files=sr), "asm_seqs": asm, "sr_seqs": sr}
+
+
+def test_set_sizes_match_reference(fixture_sets, synth):
+    assert len(fixture_sets["asm"]) == 199964      # "1 contig, 199,964 16-mers"   
+    assert len(fixture_sets["short"]) == 204833    # "40,000 reads, 204,833 16-mers"
+    gold = json.load(gzip.open(os.path.join(_cases.GOLDEN, "probe_synth_kmer.json.gz"), "rt"))["__sets__"]
+    assert len(synth["asm"]) == gold["asm"]["n_present"]
+    assert len(synth["short"]) == gold["short"]["n_present"]
+
+
+def test_membership_matches_reference(fixture_sets, synth):
+    """is_kmer_present over (every 16-mer seen at least once + 20k random ones): same answers as the reference."""
+    gold = json.load(gzip.open(os.path.join(_cases.GOLDEN, "probe_synth_kmer.json.gz"), "rt"))["__sets__"]
+    srcs = {"asm": (synth["asm"], synth["contigs"]), "short": (synth["short"], synth["sr"][0] + synth["sr"][1]),
+            "fix_asm": (fixture_sets["asm"], fixture_sets["asm_seqs"]),
+            "fix_short": (fixture_sets["short"], fixture_sets["sr_seqs"][0] + fixture_sets["sr_seqs"][1])}
+    rng = np.random.RandomState(5)
+    for mode in ("asm", "short", "fix_asm", "fix_short"):  # same order / rng stream as make_golden.py
+        ks, src = srcs[mode]
+        seen = _oracle.KmerSet(); seen.add_assembly(src)
+        q = np.unique(np.concatenate([seen.dump(), rng.randint(0, 2 ** 32, size=20000, dtype=np.uint64).astype(np.uint32)]))
+        assert hashlib.sha256(q.tobytes()).hexdigest() == gold[mode]["queries_sha256"]
+        pres = q[ks.is_kmer_present(q)]
+        assert len(pres) == gold[mode]["n_present"] == len(ks)
+        assert hashlib.sha256(pres.tobytes()).hexdigest() == gold[mode]["present_sha256"]
+
+
+def test_encoders_non_acgt_and_lowercase(ctx, be):
+    """'N' acts as A on the forward strand and as T on the reverse strand (src/kmers.cpp:176-220)."""
+    seqs = [b"ACGTNNNNacgtACGTTTGGCCAANNAC", b"nnnnnnnnnnnnnnnnnnnn", b"ACGTACGTACGTACG", b"A" * 16]
+    ks = be.kmers(assembly=seqs)
+    orc = _oracle.KmerSet(); orc.add_assembly(seqs)
+    want = orc.dump()
+    assert len(ks) == len(want)
+    assert ks.is_kmer_present(want).all()
+
+
+def check_reads(got, gold_reads, where):
+    for g, o in zip(gold_reads, got):
+        for k in ("mean_q", "window_q"):
+            w = float.fromhex(g[k])
+            assert (w == o[k]) or (np.isnan(w) and np.isnan(o[k])), "%s %s %s: ref %s hip %s" % (where, g["name"], k, g[k], float(o[k]).hex())
+        assert g["passed"] == o["passed"] and g["first"] == o["first"] and g["last"] == o["last"], (where, g["name"])
+        assert [tuple(x) for x in g["child_ranges"]] == o["child_ranges"], (where, g["name"])
+        for gc, oc in zip(g["children"], o["children"]):
+            for k in ("mean_q", "window_q"):
+                w = float.fromhex(gc[k])
+                assert (w == oc[k]) or (np.isnan(w) and np.isnan(oc[k])), "%s %s child %s" % (where, g["name"], k)
+            assert gc["passed"] == oc["passed"] and gc["length"] == oc["length"]
+
+
+def test_reference_fixtures_probe(be, fixture_sets):
+    gold = json.load(open(os.path.join(_cases.GOLDEN, "probe_fixtures.json")))
+    n = 0
+    for key, case in gold.items():
+        fx, mode, _ = key.split("|", 2)
+        if mode == "phred":
+            continue
+        reads = _oracle.read_fastx(os.path.join(FIX, fx))
+        got = be.score(reads, case["params"], fixture_sets[mode])
+        check_reads(got, case["reads"], key)
+        n += 1
+    assert n == 3 * 2 * 11
+
+
+def test_synth_kmer_probe(be, synth):
+    gold = json.load(gzip.open(os.path.join(_cases.GOLDEN, "probe_synth_kmer.json.gz"), "rt"))
+    reads = _cases.kmer_reads(synth["contigs"])
+    n = 0
+    for key, case in gold.items():
+        if key == "__sets__":
+            continue
+        mode = key.split("|")[0]
+        got = be.score(reads, case["params"], synth[mode])
+        check_reads(got, case["reads"], key)
+        n += sum(len(r["children"]) for r in case["reads"])
+    assert n > 500
+
+
+def test_empty_set_falls_back_to_phred(ctx, be):
+    """A reference that yields no 16-mer leaves Kmers::empty() true -> Phred mode (src/read.cpp:35)."""
+    ks = be.kmers(assembly=[b"ACGTACGT"])  # shorter than 16
+    assert ks.empty()
+    reads = _cases.phred_reads()[:20]
+    got = be.score(reads, {}, ks)
+    p = _oracle.make_params()
+    for (n, s, q), o in zip(reads, got):
+        w = _oracle.score_read(None, q, p)
+        assert (w["mean_q"] == o["mean_q"]) or (np.isnan(w["mean_q"]) and np.isnan(o["mean_q"]))
+
+
+def test_call_order_is_enforced(ctx):
+    ks = api.Kmers(ctx)
+    ks.add_read_fastqs([[b"ACGTACGTACGTACGTACGT"]])
+    with pytest.raises(api.FlxError):
+        ks.add_assembly_fasta([b"ACGTACGTACGTACGTACGT"])
+
+
+def test_e2e_all_goldens(be):
+    """Every end-to-end golden of the real reference binary (Phred, -a, -1/-2, --trim, --split, weights, cut-offs)."""
+    n = _e2e_checks.check_all(be)
+    assert n >= 50
