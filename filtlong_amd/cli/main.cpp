@@ -1,0 +1,631 @@
+// filtlong-amd — C++ host of the MI355X-native Filtlong hot path: same command line, same stdout FASTQ/FASTA,
+// same stderr lines and exit codes as the reference binary, with the per-read scoring and the global rank/cut
+// done on the GPU through the C ABI (include/filtlong_hip.h).
+//
+// What this file mirrors of the reference (rrwick/Filtlong v0.3.1, paths relative to its root):
+//   arguments       src/arguments.cpp:28-393  flags, unit suffixes, validation order and messages
+//   input parsing   src/kseq.h:176-224         FASTA/FASTQ records, multi-line, "\r\n", gz via zlib
+//   orchestration   src/main.cpp:37-321        sections printed to stderr, reads2 gather, output order
+//   formatting      src/misc.cpp:24-49         2-decimal doubles, locale-grouped integers
+// Differences by design: the input is parsed once and kept in memory (the reference parses the file twice,
+// main.cpp:70-127 and 264-313); scoring is batched (flx_score_batch) instead of one Read per record.
+#include <zlib.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <locale>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/filtlong_hip.h"
+
+#define PROGRAM_VERSION "0.3.1"
+
+// ------------------------------------------------------------------------------------------------ formatting
+static std::string double_to_string(double n) {  // src/misc.cpp:24-32
+    std::stringstream ss;
+    ss << std::fixed << std::setprecision(2) << n;
+    std::string s = ss.str();
+    if (s.size() < 5) return std::string(5 - s.size(), ' ') + s;
+    return s;
+}
+
+static std::string int_to_string(long long n) {  // src/misc.cpp:35-40 (thousands grouping of the user's locale)
+    std::stringstream ss;
+    ss.imbue(std::locale(""));
+    ss << std::fixed << n;
+    return ss.str();
+}
+
+static std::string pad(const std::string &s, size_t width) { return width > s.size() ? s + std::string(width - s.size(), ' ') : s; }
+
+// ------------------------------------------------------------------------------------------------ arguments
+struct Args {
+    std::string input_reads;
+    bool target_bases_set = false; long long target_bases = 0;
+    bool keep_percent_set = false; double keep_percent = 0;
+    bool min_length_set = false; int min_length = 0;
+    bool max_length_set = false; int max_length = 0;
+    bool min_mean_q_set = false; double min_mean_q = 0;
+    bool min_window_q_set = false; double min_window_q = 0;
+    bool assembly_set = false; std::string assembly;
+    std::vector<std::string> short_reads;
+    double length_weight = 1.0, mean_q_weight = 1.0, window_q_weight = 1.0;
+    bool trim = false;
+    bool split_set = false; int split = 0;
+    long long window_size = 250;
+    bool verbose = false;
+};
+enum ParsingResult { GOOD, BAD, HELP, VERSION };
+
+struct ParseError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+static double read_double(const std::string &name, const std::string &value) {  // DoublesReader, arguments.cpp:28-39
+    try {
+        if (value.find_first_not_of("0123456789.") != std::string::npos) throw std::invalid_argument("");
+        return std::stod(value);
+    } catch (...) {
+        throw ParseError("Error: argument '" + name + "' received invalid value type '" + value + "'");
+    }
+}
+
+static long long parse_int_with_suffix(const std::string &value) {  // arguments.cpp:53-93
+    if (value.empty()) throw std::invalid_argument("Empty value");
+    std::string lower = value;
+    std::transform(lower.begin(), lower.end(), lower.begin(), ::tolower);
+    const size_t start = value[0] == '-' ? 1 : 0;
+    const size_t suffix_pos = lower.find_first_not_of("0123456789.", start);
+    if (suffix_pos == std::string::npos) return static_cast<long long>(std::stod(value));
+    const std::string numeric = value.substr(0, suffix_pos), suffix = lower.substr(suffix_pos);
+    if (numeric.empty() || (numeric.size() == 1 && numeric[0] == '-')) throw std::invalid_argument("No numeric value before suffix");
+    const double v = std::stod(numeric);
+    long long mult;
+    if (suffix == "k" || suffix == "kb") mult = 1000;
+    else if (suffix == "m" || suffix == "mb") mult = 1000000;
+    else if (suffix == "g" || suffix == "gb") mult = 1000000000;
+    else throw std::invalid_argument("Unknown suffix: " + suffix);
+    return static_cast<long long>(v * mult);
+}
+
+static long long read_ll_suffix(const std::string &name, const std::string &value) {  // arguments.cpp:42-51
+    try { return parse_int_with_suffix(value); }
+    catch (...) { throw ParseError("Error: argument '" + name + "' received invalid value '" + value + "'"); }
+}
+
+static int read_int_suffix(const std::string &name, const std::string &value) {  // arguments.cpp:96-113
+    try {
+        const long long r = parse_int_with_suffix(value);
+        if (r > INT_MAX || r < INT_MIN) throw std::invalid_argument("Value out of range for int");
+        return static_cast<int>(r);
+    } catch (...) { throw ParseError("Error: argument '" + name + "' received invalid value '" + value + "'"); }
+}
+
+static long long read_ll(const std::string &name, const std::string &value) {  // default args.h reader (operator>>)
+    std::istringstream ss(value);
+    long long v;
+    if (!(ss >> v) || !ss.eof()) throw ParseError("Argument '" + name + "' received invalid value type '" + value + "'");
+    return v;
+}
+
+static void print_help(const char *prog) {
+    std::cerr <<
+        "  " << prog << " {OPTIONS} [input_reads]\n\n"
+        "Filtlong: a quality filtering tool for Nanopore and PacBio reads\n"
+        "(MI355X-native scoring hot path; drop-in for the reference command line)\n\n"
+        "usage:\n"
+        "  positional arguments:\n"
+        "    input_reads                         input long reads to be filtered\n\n"
+        "  output thresholds:\n"
+        "    -t[int], --target_bases [int]       keep only the best reads up to this many total bases (unit suffixes: k, kb, m, mb, g, gb)\n"
+        "    -p[float], --keep_percent [float]   keep only this percentage of the best reads (measured by bases)\n"
+        "    -l[int], --min_length [int]         minimum length threshold (unit suffixes: k, kb, m, mb, g, gb)\n"
+        "    -L[int], --max_length [int]         maximum length threshold (unit suffixes: k, kb, m, mb, g, gb)\n"
+        "    -q[float], --min_mean_q [float]     minimum mean quality threshold\n"
+        "    --min_window_q [float]              minimum window quality threshold\n\n"
+        "  external references (if provided, read quality will be determined using these instead of from the Phred scores):\n"
+        "    -a[file], --assembly [file]         reference assembly in FASTA format\n"
+        "    -1[file], --short_1 [file]          reference short reads in FASTQ format\n"
+        "    -2[file], --short_2 [file]          reference short reads in FASTQ format\n\n"
+        "  score weights (control the relative contribution of each score to the final read score):\n"
+        "    --length_weight [float]             weight given to the length score (default: 1)\n"
+        "    --mean_q_weight [float]             weight given to the mean quality score (default: 1)\n"
+        "    --window_q_weight [float]           weight given to the window quality score (default: 1)\n\n"
+        "  read manipulation:\n"
+        "    --trim                              trim non-k-mer-matching bases from start/end of reads\n"
+        "    --split [split]                     split reads at this many (or more) consecutive non-k-mer-matching bases (unit suffixes: k, kb, m, mb, g, gb)\n\n"
+        "  other:\n"
+        "    --window_size [int]                 size of sliding window used when measuring window quality (default: 250)\n"
+        "    --verbose                           verbose output to stderr with info for each read\n"
+        "    --version                           display the program version and quit\n"
+        "    -h, --help                          display this help menu\n\n"
+        "For more information, go to: https://github.com/rrwick/Filtlong\n";
+}
+
+static bool file_exists(const std::string &f) { std::ifstream in(f); return in.good(); }
+
+static ParsingResult parse_args(int argc, char **argv, Args &a) {
+    bool version = false;
+    bool short1_set = false, short2_set = false;
+    std::string short1, short2;
+    std::vector<std::string> positional;
+    try {
+        for (int i = 1; i < argc; ++i) {
+            std::string tok = argv[i];
+            std::string flag, value;
+            bool have_value = false;
+            if (tok.size() >= 2 && tok[0] == '-' && tok[1] == '-') {
+                flag = tok.substr(2);  // long flags take their value from the next token (LongSeparator(" "), arguments.cpp:128)
+            } else if (tok.size() >= 2 && tok[0] == '-' && !(isdigit((unsigned char)tok[1]) && false)) {
+                flag = std::string(1, tok[1]);
+                if (tok.size() > 2) { value = tok.substr(2); have_value = true; }  // -t100
+                static const char *shorts = "tplLqa12h";
+                if (!strchr(shorts, tok[1])) throw ParseError("Flag could not be matched: " + std::string(1, tok[1]));
+            } else {
+                positional.push_back(tok);
+                continue;
+            }
+            auto need = [&](const char *n) -> std::string {
+                if (have_value) return value;
+                if (i + 1 >= argc) throw ParseError(std::string("Flag '") + n + "' requires an argument but received none");
+                return argv[++i];
+            };
+            if (flag == "h" || flag == "help") { print_help(argv[0]); return HELP; }
+            else if (flag == "version") version = true;
+            else if (flag == "verbose") a.verbose = true;
+            else if (flag == "trim") a.trim = true;
+            else if (flag == "t" || flag == "target_bases") { a.target_bases = read_ll_suffix("int", need("target_bases")); a.target_bases_set = true; }
+            else if (flag == "p" || flag == "keep_percent") { a.keep_percent = read_double("float", need("keep_percent")); a.keep_percent_set = true; }
+            else if (flag == "l" || flag == "min_length") { a.min_length = read_int_suffix("int", need("min_length")); a.min_length_set = true; }
+            else if (flag == "L" || flag == "max_length") { a.max_length = read_int_suffix("int", need("max_length")); a.max_length_set = true; }
+            else if (flag == "q" || flag == "min_mean_q") { a.min_mean_q = read_double("float", need("min_mean_q")); a.min_mean_q_set = true; }
+            else if (flag == "min_window_q") { a.min_window_q = read_double("float", need("min_window_q")); a.min_window_q_set = true; }
+            else if (flag == "a" || flag == "assembly") { a.assembly = need("assembly"); a.assembly_set = true; }
+            else if (flag == "1" || flag == "short_1") { short1 = need("short_1"); short1_set = true; }
+            else if (flag == "2" || flag == "short_2") { short2 = need("short_2"); short2_set = true; }
+            else if (flag == "length_weight") a.length_weight = read_double("float", need("length_weight"));
+            else if (flag == "mean_q_weight") a.mean_q_weight = read_double("float", need("mean_q_weight"));
+            else if (flag == "window_q_weight") a.window_q_weight = read_double("float", need("window_q_weight"));
+            else if (flag == "split") { a.split = read_int_suffix("split", need("split")); a.split_set = true; }
+            else if (flag == "window_size") a.window_size = read_ll("int", need("window_size"));
+            else throw ParseError("Flag could not be matched: " + flag);
+        }
+        if (positional.size() > 1) throw ParseError("Passed in argument, but no positional arguments were ready to receive it: " + positional[1]);
+    } catch (const ParseError &e) {
+        std::cerr << e.what() << "\n";
+        return BAD;
+    }
+    if (argc == 1) { print_help(argv[0]); return HELP; }
+    if (version) return VERSION;
+    if (!positional.empty()) a.input_reads = positional[0];
+    if (a.input_reads.empty()) { std::cerr << "Error: input reads are required" << "\n"; return BAD; }
+    if (short1_set) a.short_reads.push_back(short1);
+    if (short2_set) a.short_reads.push_back(short2);
+
+    // validation: same order and messages as arguments.cpp:298-393
+    const bool some_reference = !a.short_reads.empty() || a.assembly_set;
+    if (a.trim && !some_reference) { std::cerr << "Error: assembly or read reference is required to use --trim" << "\n"; return BAD; }
+    if (a.split_set && !some_reference) { std::cerr << "Error: assembly or read reference is required to use --split" << "\n"; return BAD; }
+    std::vector<std::string> files;
+    files.push_back(a.input_reads);
+    for (auto &f : a.short_reads) files.push_back(f);
+    if (a.assembly_set) files.push_back(a.assembly);
+    for (auto &f : files)
+        if (!file_exists(f)) { std::cerr << "Error: cannot find file: " << f << "\n"; return BAD; }
+    if (!a.trim && !a.split_set && !a.target_bases_set && !a.keep_percent_set && !a.min_length_set && !a.max_length_set &&
+        !a.min_mean_q_set && !a.min_window_q_set) {
+        std::cerr << "Error: no thresholds set, you must use one of the following options:\n";
+        std::cerr << "target_bases, keep_percent, min_length, max_length, min_mean_q, min_window_q, trim, split\n";
+        return BAD;
+    }
+    if (a.target_bases_set && a.target_bases <= 0) { std::cerr << "Error: the value for --target_bases must be a positive integer\n"; return BAD; }
+    if (a.min_length_set && a.min_length <= 0) { std::cerr << "Error: the value for --min_length must be a positive integer\n"; return BAD; }
+    if (a.max_length_set && a.max_length <= 0) { std::cerr << "Error: the value for --max_length must be a positive integer\n"; return BAD; }
+    if (a.keep_percent_set && (a.keep_percent <= 0.0 || a.keep_percent >= 100.0)) {
+        std::cerr << "Error: the value for --keep_percent must be greater than 0 and less than 100\n"; return BAD; }
+    if (a.min_mean_q_set && a.min_mean_q <= 0.0) { std::cerr << "Error: the value for --min_mean_q must be greater than 0\n"; return BAD; }
+    if (a.min_window_q_set && a.min_window_q <= 0.0) { std::cerr << "Error: the value for --min_window_q must be greater than 0\n"; return BAD; }
+    if (a.length_weight < 0.0 || a.mean_q_weight < 0.0 || a.window_q_weight < 0.0) { std::cerr << "Error: weight values cannot be negative\n"; return BAD; }
+    if (a.split_set && a.split <= 0) { std::cerr << "Error: the value for --split must be a positive integer\n"; return BAD; }
+    if (a.window_size <= 0) { std::cerr << "Error: the value for --window_size must be a positive integer\n"; return BAD; }
+    return GOOD;
+}
+
+// ------------------------------------------------------------------------------------------------ FASTA/FASTQ
+// In-memory parser with the record grammar of klib's kseq (src/kseq.h:176-224): records start at the next '>' or
+// '@'; the name ends at the first whitespace, the rest of the header line is the comment; sequence lines run until a
+// line whose first character is '>', '+' or '@'; after '+' the quality is read line by line until it is at least as
+// long as the sequence; a trailing '\r' is dropped from every line; empty lines are skipped.
+struct Record {
+    std::string name, comment;
+    std::string seq, qual;
+    bool is_fastq = false;
+};
+
+static bool slurp(const std::string &path, std::string &out) {
+    gzFile fp = gzopen(path.c_str(), "r");
+    if (!fp) return false;
+    gzbuffer(fp, 1 << 20);
+    std::vector<char> buf(1 << 22);
+    for (;;) {
+        const int n = gzread(fp, buf.data(), (unsigned)buf.size());
+        if (n < 0) { gzclose(fp); return false; }
+        if (n == 0) break;
+        out.append(buf.data(), (size_t)n);
+    }
+    gzclose(fp);
+    return true;
+}
+
+struct Parser {
+    const std::string &d;
+    size_t pos = 0;
+    int last_char = 0;
+    explicit Parser(const std::string &data) : d(data) {}
+    int getc() { return pos < d.size() ? (unsigned char)d[pos++] : -1; }
+    // appends the rest of the current line (without '\n', trailing '\r' dropped when the line has > 1 chars so far)
+    // returns false if nothing at all could be read (EOF)
+    bool get_line(std::string &s, bool append) {
+        if (!append) s.clear();
+        if (pos >= d.size()) return false;
+        const size_t nl = d.find('\n', pos);
+        const size_t end = nl == std::string::npos ? d.size() : nl;
+        s.append(d, pos, end - pos);
+        pos = nl == std::string::npos ? d.size() : nl + 1;
+        if (s.size() > 1 && s.back() == '\r') s.pop_back();
+        return true;
+    }
+    // returns length >= 0, -1 at EOF, -2 on truncated / mismatching quality
+    long long next(Record &r) {
+        int c;
+        if (last_char == 0) {
+            while ((c = getc()) >= 0 && c != '>' && c != '@') {}
+            if (c < 0) return -1;
+            last_char = c;
+        }
+        r.comment.clear(); r.seq.clear(); r.qual.clear(); r.name.clear();
+        // name: up to the first whitespace
+        if (pos >= d.size()) return -1;
+        size_t e = pos;
+        while (e < d.size() && !isspace((unsigned char)d[e])) ++e;
+        r.name.assign(d, pos, e - pos);
+        c = e < d.size() ? (unsigned char)d[e] : -1;
+        pos = e < d.size() ? e + 1 : e;
+        if (c != '\n' && c >= 0) get_line(r.comment, false);
+        while ((c = getc()) >= 0 && c != '>' && c != '+' && c != '@') {
+            if (c == '\n') continue;
+            r.seq.push_back((char)c);
+            get_line(r.seq, true);
+        }
+        if (c == '>' || c == '@') last_char = c;
+        r.is_fastq = (c == '+');
+        if (!r.is_fastq) { if (c < 0) last_char = 0; return (long long)r.seq.size(); }
+        while ((c = getc()) >= 0 && c != '\n') {}
+        if (c == -1) return -2;
+        while (get_line(r.qual, true) && r.qual.size() < r.seq.size()) {}
+        last_char = 0;
+        if (r.seq.size() != r.qual.size()) return -2;
+        return (long long)r.seq.size();
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ helpers
+static int fail_flx(flx_ctx *ctx, const char *what) {
+    std::cerr << "Error: " << what << ": " << flx_last_error(ctx) << "\n";
+    return 1;
+}
+
+static void print_hash_progress(const std::string &filename, long long base_count) {
+    std::cerr << "\r  " << filename << " (" << int_to_string(base_count) << " bp)";
+}
+
+// reads one reference file; returns the number of sequences (counting those < 16 bp, src/kmers.cpp:96-100)
+static int load_reference(const std::string &filename, std::vector<std::string> &seqs) {
+    std::string data;
+    int n = 0;
+    long long bases = 0;
+    if (slurp(filename, data)) {
+        Parser p(data);
+        Record r;
+        long long l;
+        while ((l = p.next(r)) >= 0) {  // errors end the loop silently, like src/kmers.cpp:91-94
+            ++n;
+            if (r.seq.size() < 16) continue;
+            bases += (long long)r.seq.size();
+            seqs.push_back(r.seq);
+        }
+    }
+    print_hash_progress(filename, bases);
+    std::cerr << "\n";
+    return n;
+}
+
+static int add_sequences(flx_ctx *ctx, flx_kmerset *set, const std::vector<std::string> &seqs, bool short_reads) {
+    std::vector<uint64_t> offsets(seqs.size());
+    std::vector<int64_t> lengths(seqs.size());
+    uint64_t total = 0;
+    for (size_t i = 0; i < seqs.size(); ++i) { offsets[i] = total; lengths[i] = (int64_t)seqs[i].size(); total += seqs[i].size(); }
+    std::string bases;
+    bases.reserve(total + 1);
+    for (auto &s : seqs) bases += s;
+    if (bases.empty()) bases.push_back('\0');
+    const int rc = short_reads
+        ? flx_kmerset_add_short_reads(set, (const uint8_t *)bases.data(), offsets.data(), lengths.data(), seqs.size())
+        : flx_kmerset_add_assembly(set, (const uint8_t *)bases.data(), offsets.data(), lengths.data(), seqs.size());
+    (void)ctx;
+    return rc;
+}
+
+int main(int argc, char **argv) {
+    Args args;
+    const ParsingResult pr = parse_args(argc, argv, args);
+    if (pr == BAD) return 1;
+    if (pr == HELP) return 0;
+    if (pr == VERSION) { std::cout << "Filtlong v" << PROGRAM_VERSION << "\n"; return 0; }
+
+    std::cerr << "\n";
+    flx_ctx *ctx = nullptr;
+    {
+        const char *dev = getenv("FLX_DEVICE");
+        if (flx_ctx_create(dev ? atoi(dev) : 0, &ctx) != FLX_OK) {
+            std::cerr << "Error: " << flx_last_error(nullptr) << "\n";
+            return 1;
+        }
+    }
+
+    // ---- reference 16-mers (src/main.cpp:51-59, src/kmers.cpp:50-72) --------------------------------------
+    flx_kmerset *kmers = nullptr;
+    bool kmers_empty = true;
+    if (args.assembly_set || !args.short_reads.empty()) {
+        if (flx_kmerset_create(ctx, &kmers) != FLX_OK) return fail_flx(ctx, "k-mer set");
+        if (args.assembly_set) {
+            std::cerr << "Hashing 16-mers from assembly\n";
+            std::cerr << "  " << args.assembly << "\n";
+            std::vector<std::string> seqs;
+            const int count = load_reference(args.assembly, seqs);
+            if (add_sequences(ctx, kmers, seqs, false) != FLX_OK) return fail_flx(ctx, "assembly");
+            if (args.short_reads.empty()) {
+                if (flx_kmerset_finalize(kmers) != FLX_OK) return fail_flx(ctx, "k-mer set");
+                std::cerr << "  " << int_to_string(count) << " " << (count == 1 ? "contig" : "contigs") << ", "
+                          << int_to_string((long long)flx_kmerset_size(kmers)) << " 16-mers\n\n";
+            } else {
+                // the reference prints the set size after the assembly alone; that needs a count before the short reads
+                flx_kmerset *tmp = nullptr;
+                if (flx_kmerset_create(ctx, &tmp) != FLX_OK) return fail_flx(ctx, "k-mer set");
+                if (add_sequences(ctx, tmp, seqs, false) != FLX_OK || flx_kmerset_finalize(tmp) != FLX_OK) return fail_flx(ctx, "assembly");
+                std::cerr << "  " << int_to_string(count) << " " << (count == 1 ? "contig" : "contigs") << ", "
+                          << int_to_string((long long)flx_kmerset_size(tmp)) << " 16-mers\n\n";
+                flx_kmerset_destroy(tmp);
+            }
+        }
+        if (!args.short_reads.empty()) {
+            std::cerr << "Hashing 16-mers from short reads\n";
+            int count = 0;
+            for (auto &f : args.short_reads) {
+                std::vector<std::string> seqs;
+                count += load_reference(f, seqs);
+                if (add_sequences(ctx, kmers, seqs, true) != FLX_OK) return fail_flx(ctx, "short reads");
+            }
+            if (flx_kmerset_finalize(kmers) != FLX_OK) return fail_flx(ctx, "k-mer set");
+            std::cerr << "  " << int_to_string(count) << " reads, " << int_to_string((long long)flx_kmerset_size(kmers)) << " 16-mers\n\n";
+        }
+        kmers_empty = flx_kmerset_size(kmers) == 0;
+    }
+
+    // ---- pass 1: parse, checks (src/main.cpp:63-130) -----------------------------------------------------
+    if (!args.verbose) std::cerr << "Scoring long reads\n";
+    std::string data;
+    if (!slurp(args.input_reads, data)) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
+    std::vector<Record> recs;
+    long long total_bases = 0, last_progress = 0;
+    bool any_fasta = false, any_fastq = false;
+    {
+        Parser p(data);
+        Record r;
+        std::unordered_set<std::string> names;
+        for (;;) {
+            const long long l = p.next(r);
+            if (l == -1) break;
+            if (l == -2) { std::cerr << "Error: incorrect FASTQ format for read " << r.name << "\n"; return 1; }
+            total_bases += (long long)r.seq.size();
+            const bool fasta_format = r.qual.empty() && !r.seq.empty();
+            const bool fastq_format = !r.qual.empty() && !r.seq.empty() && r.qual.size() == r.seq.size();
+            any_fasta = any_fasta || fasta_format;
+            any_fastq = any_fastq || fastq_format;
+            if (any_fasta && any_fastq) {
+                std::cerr << "\n\n" << "Error: could not parse input reads" << "\n";
+                std::cerr << "  problem occurred at read " << r.name << "\n";
+                return 1;
+            }
+            if (fasta_format && kmers_empty) {
+                std::cerr << "\n\n" << "Error: FASTA input not supported without an external reference" << "\n";
+                return 1;
+            }
+            if (!names.insert(r.name).second) { std::cerr << "Error: duplicate read name: " << r.name << "\n"; return 1; }
+            recs.push_back(r);
+            if (total_bases - last_progress >= 483611) {
+                last_progress = total_bases;
+                if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)recs.size()) << " reads (" << int_to_string(total_bases) << " bp)";
+            }
+        }
+    }
+    data.clear();
+    data.shrink_to_fit();
+    if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)recs.size()) << " reads (" << int_to_string(total_bases) << " bp)";
+    std::cerr << "\n";
+    const bool fasta_output = any_fasta, fastq_output = any_fastq;
+
+    // ---- pack and score (replaces one Read::Read per record, src/main.cpp:108) ---------------------------
+    const uint64_t n = recs.size();
+    std::vector<int32_t> lengths(n);
+    for (uint64_t i = 0; i < n; ++i) lengths[i] = (int32_t)recs[i].seq.size();
+    std::vector<uint64_t> offsets(n ? n : 1);
+    uint64_t plane_bytes = 0;
+    flx_plane_layout(lengths.data(), n, offsets.data(), &plane_bytes);
+    std::vector<uint8_t> plane(plane_bytes, 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        const std::string &src = kmers_empty ? recs[i].qual : recs[i].seq;  // Phred mode reads qual, k-mer mode reads seq
+        if (!src.empty()) memcpy(plane.data() + offsets[i], src.data(), src.size());
+    }
+    std::vector<uint32_t> order(n ? n : 1);
+    flx_length_order(lengths.data(), n, order.data());
+
+    flx_params prm;
+    memset(&prm, 0, sizeof prm);
+    prm.window_size = (int32_t)args.window_size;
+    prm.min_length_set = args.min_length_set; prm.min_length = args.min_length;
+    prm.max_length_set = args.max_length_set; prm.max_length = args.max_length;
+    prm.min_mean_q_set = args.min_mean_q_set; prm.min_mean_q = args.min_mean_q;
+    prm.min_window_q_set = args.min_window_q_set; prm.min_window_q = args.min_window_q;
+    prm.trim = args.trim; prm.split_set = args.split_set; prm.split = args.split;
+
+    std::vector<double> mean_q(n), window_q(n), c_mean, c_window;
+    std::vector<uint8_t> passed(n), c_passed;
+    std::vector<int32_t> first(n), last(n), c_ranges;
+    std::vector<uint64_t> child_off(n + 1, 0);
+    uint64_t cap = std::max<uint64_t>(16, 2 * n);
+    uint64_t n_children = 0;
+    for (;;) {
+        c_ranges.assign(2 * cap, 0); c_mean.assign(cap, 0); c_window.assign(cap, 0); c_passed.assign(cap, 0);
+        flx_scores sc;
+        memset(&sc, 0, sizeof sc);
+        sc.mean_q = mean_q.data(); sc.window_q = window_q.data(); sc.passed = passed.data();
+        sc.first = first.data(); sc.last = last.data(); sc.child_offsets = child_off.data();
+        sc.child_ranges = c_ranges.data(); sc.child_mean_q = c_mean.data(); sc.child_window_q = c_window.data();
+        sc.child_passed = c_passed.data(); sc.child_capacity = cap;
+        const int rc = flx_score_batch(ctx, kmers_empty ? nullptr : kmers, plane.data(), plane_bytes, offsets.data(), lengths.data(),
+                                       order.data(), n, &prm, &sc);
+        if (rc == FLX_ERR_CAPACITY && sc.n_children > cap) { cap = sc.n_children; continue; }
+        if (rc != FLX_OK) return fail_flx(ctx, "scoring");
+        n_children = sc.n_children;
+        break;
+    }
+    (void)n_children;
+
+    // ---- reads2: children replace their parents in place (src/main.cpp:138-147) -----------------------------
+    struct Out { uint64_t rec; int start, end; bool child; std::string name; };
+    std::vector<Out> reads2;
+    std::vector<double> r2_mean, r2_window;
+    std::vector<int32_t> r2_len;
+    std::vector<uint8_t> r2_pass;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t a = child_off[i], b = child_off[i + 1];
+        if (a == b) {
+            reads2.push_back({i, 0, lengths[i], false, recs[i].name});
+            r2_mean.push_back(mean_q[i]); r2_window.push_back(window_q[i]); r2_len.push_back(lengths[i]); r2_pass.push_back(passed[i]);
+        } else {
+            for (uint64_t k = a; k < b; ++k) {
+                const int s = c_ranges[2 * k], e = c_ranges[2 * k + 1];
+                reads2.push_back({i, s, e, true, recs[i].name + "_" + std::to_string(s + 1) + "-" + std::to_string(e)});  // read.cpp:135-136
+                r2_mean.push_back(c_mean[k]); r2_window.push_back(c_window[k]); r2_len.push_back(e - s); r2_pass.push_back(c_passed[k]);
+            }
+        }
+    }
+    size_t longest_name = 0;
+    for (auto &o : reads2) longest_name = std::max(longest_name, o.name.size());
+
+    if (args.verbose) {  // Read::print_verbose_read_info, src/read.cpp:169-194 (bad ranges are the complement of the children)
+        for (uint64_t i = 0; i < n; ++i) {
+            std::cerr << "\n" << recs[i].name << "\n";
+            std::cerr << "            length = " << pad(std::to_string(lengths[i]), 11) << "mean quality = " << double_to_string(mean_q[i])
+                      << "      window quality = " << double_to_string(window_q[i]) << "\n";
+            const uint64_t a = child_off[i], b = child_off[i + 1];
+            if (a != b) {
+                std::cerr << "      child ranges = ";
+                for (uint64_t k = a; k < b; ++k) std::cerr << c_ranges[2 * k] << "-" << c_ranges[2 * k + 1] << (k + 1 < b ? ", " : "");
+                std::cerr << "\n";
+                for (uint64_t k = a; k < b; ++k) {
+                    std::cerr << "\n" << recs[i].name << "_" << c_ranges[2 * k] + 1 << "-" << c_ranges[2 * k + 1] << "\n";
+                    std::cerr << "            length = " << pad(std::to_string(c_ranges[2 * k + 1] - c_ranges[2 * k]), 11) << "mean quality = "
+                              << double_to_string(c_mean[k]) << "      window quality = " << double_to_string(c_window[k]) << "\n";
+                }
+            }
+        }
+    }
+
+    if (args.trim || args.split_set) {  // src/main.cpp:155-166
+        long long after = 0;
+        for (auto v : r2_len) after += v;
+        if (args.trim && args.split_set) std::cerr << "  after trimming and splitting: ";
+        else if (args.trim) std::cerr << "  after trimming: ";
+        else std::cerr << "  after splitting: ";
+        std::cerr << int_to_string((long long)reads2.size()) << " reads (" << int_to_string(after) << " bp)\n";
+    }
+    std::cerr << "\n";
+
+    // ---- global stage (src/main.cpp:169-261) ---------------------------------------------------------------
+    const uint64_t n2 = reads2.size();
+    std::vector<double> final_score(n2);
+    flx_cut_report rep;
+    memset(&rep, 0, sizeof rep);
+    const bool cutting = args.target_bases_set || args.keep_percent_set;
+    if (n2 > 0 || cutting) {
+        if (flx_rank_and_cut(ctx, n2, r2_mean.data(), r2_window.data(), r2_len.data(), r2_pass.data(), args.length_weight,
+                             args.mean_q_weight, args.window_q_weight, args.target_bases_set, args.target_bases, args.keep_percent_set,
+                             args.keep_percent, total_bases, args.verbose ? final_score.data() : nullptr, &rep) != FLX_OK)
+            return fail_flx(ctx, "rank and cut");
+    }
+    if (args.verbose) {  // src/main.cpp:199-214: the table shows the NORMALISED qualities; recompute them like main.cpp:203-208
+        std::cerr << "\n\n" << "Read name" << "\t" << "Length score" << "\t" << "Mean quality score" << "\t" << "Window quality score"
+                  << "\t" << "Final score" << "\n";
+        const double zspan = rep.max_z - rep.min_z;
+        for (uint64_t i = 0; i < n2; ++i) {
+            double ratio = r2_window[i] / r2_mean[i];
+            if (ratio > 1.0) ratio = 1.0;
+            const double z = (r2_mean[i] - rep.mean_quality) / rep.stdev_quality;
+            const double mq = 100.0 * (z - rep.min_z) / zspan;
+            const double lscore = 100.0 * (1.0 + (-5000.0 / (r2_len[i] + 5000.0)));
+            std::cerr << pad(reads2[i].name, longest_name) << "\t" << double_to_string(lscore) << "\t" << double_to_string(mq) << "\t"
+                      << double_to_string(mq * ratio) << "\t" << double_to_string(final_score[i]) << "\n";
+        }
+        std::cerr << "\n";
+    }
+    if (cutting) {
+        std::cerr << "Filtering long reads\n";
+        std::cerr << "  target: " << int_to_string(rep.target_bases) << " bp\n";
+        if (rep.outcome == FLX_CUT_NOT_ENOUGH) std::cerr << "  not enough reads to reach target\n";
+        else if (rep.outcome == FLX_CUT_ALREADY_BELOW) std::cerr << "  reads already fall below target after filtering\n";
+        else std::cerr << "  keeping " << int_to_string(rep.kept_bases) << " bp\n";
+        std::cerr << "\n";
+    }
+
+    // ---- output in input order (src/main.cpp:263-313) -----------------------------------------------------
+    std::cerr << "Outputting passed long reads\n";
+    std::string out;
+    out.reserve(1 << 24);
+    for (uint64_t i = 0; i < n2; ++i) {
+        if (!r2_pass[i]) continue;
+        const Out &o = reads2[i];
+        const Record &r = recs[o.rec];
+        if (o.child && o.end - o.start <= 0) continue;
+        out += fasta_output ? '>' : '@';
+        out += o.name;
+        if (!r.comment.empty()) { out += ' '; out += r.comment; }
+        out += '\n';
+        out.append(r.seq, (size_t)o.start, (size_t)(o.end - o.start));
+        out += '\n';
+        if (fastq_output) {
+            out += "+\n";
+            out.append(r.qual, (size_t)o.start, (size_t)(o.end - o.start));
+            out += '\n';
+        }
+        if (out.size() > (1u << 24)) { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
+    }
+    fwrite(out.data(), 1, out.size(), stdout);
+    fflush(stdout);
+
+    if (kmers) flx_kmerset_destroy(kmers);
+    flx_ctx_destroy(ctx);
+    std::cerr << "\n";
+    return 0;
+}

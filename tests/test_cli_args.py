@@ -1,0 +1,71 @@
+"""The C++ command line (filtlong_amd/bin/filtlong) mirrors the reference's argument handling: same validation
+order, messages and exit codes (reference src/arguments.cpp:298-393, pinned by its test/test_error_messages.py
+and test/test_unit_suffixes.py).  Argument errors are raised before any GPU work, so these run on CPU."""
+import os
+import subprocess
+
+import pytest
+
+import _cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "filtlong_amd", "bin", "filtlong")
+INPUT = os.path.join(_cases.FIXTURES, "test_sort.fastq")
+ASM = os.path.join(_cases.FIXTURES, "test_reference.fasta")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.exists(BIN):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "filtlong_amd", "csrc"), "-s", "-j8"])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "filtlong_amd", "cli"), "-s"])
+
+
+def run(*args):
+    p = subprocess.run([BIN] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, LANG="C", LC_ALL="C"))
+    return p.returncode, p.stdout, p.stderr.decode()
+
+
+CASES = [
+    (["INPUT"], "Error: no thresholds set"),
+    (["--target_bases", "1000", "BAD_FILENAME"], "Error: cannot find file"),
+    (["-a", "BAD_FILENAME", "--target_bases", "1000", "INPUT"], "Error: cannot find file"),
+    (["--target_bases", "0", "INPUT"], "Error: the value for --target_bases must be a positive integer"),
+    (["--target_bases", "-10", "INPUT"], "Error: the value for --target_bases must be a positive integer"),
+    (["--keep_percent", "0", "INPUT"], "Error: the value for --keep_percent must be greater than 0 and less than 100"),
+    (["--keep_percent", "100", "INPUT"], "Error: the value for --keep_percent must be greater than 0 and less than 100"),
+    (["--keep_percent", "111.1", "INPUT"], "Error: the value for --keep_percent must be greater than 0 and less than 100"),
+    (["--min_length", "0", "INPUT"], "Error: the value for --min_length must be a positive integer"),
+    (["--min_length", "-10", "INPUT"], "Error: the value for --min_length must be a positive integer"),
+    (["--min_mean_q", "0", "INPUT"], "Error: the value for --min_mean_q must be greater than 0"),
+    (["--min_window_q", "0", "INPUT"], "Error: the value for --min_window_q must be greater than 0"),
+    (["--trim", "INPUT"], "Error: assembly or read reference is required to use --trim"),
+    (["--split", "250", "INPUT"], "Error: assembly or read reference is required to use --split"),
+    (["-a", "ASSEMBLY", "--split", "0", "INPUT"], "Error: the value for --split must be a positive integer"),
+    (["-a", "ASSEMBLY", "--split", "-10", "INPUT"], "Error: the value for --split must be a positive integer"),
+    (["--min_length", "1000", "--window_size", "0", "INPUT"], "Error: the value for --window_size must be a positive integer"),
+    (["--min_length", "1000", "--window_size", "-10", "INPUT"], "Error: the value for --window_size must be a positive integer"),
+    (["-l", "-10", "INPUT"], "Error: the value for --min_length must be a positive integer"),
+    (["-L", "-10", "INPUT"], "Error: the value for --max_length must be a positive integer"),
+    (["-q", "0", "INPUT"], "Error: the value for --min_mean_q must be greater than 0"),
+    (["--length_weight", "-1", "--target_bases", "5", "INPUT"], "received invalid value type"),
+    (["--target_bases", "12x", "INPUT"], "received invalid value '12x'"),
+    (["--target_bases=100", "INPUT"], "Flag could not be matched"),
+]
+
+
+@pytest.mark.parametrize("argv,msg", CASES)
+def test_error_messages(argv, msg):
+    argv = [INPUT if a == "INPUT" else ASM if a == "ASSEMBLY" else a for a in argv]
+    rc, out, err = run(*argv)
+    assert rc == 1 and msg in err and out == b""
+
+
+def test_help_and_version():
+    rc, out, err = run()
+    assert rc == 0 and "usage:" in err and "Filtlong:" in err
+    rc, out, err = run("--help")
+    assert rc == 0 and "usage:" in err
+    rc, out, err = run("--version")
+    assert rc == 0 and out == b"Filtlong v0.3.1\n"

@@ -1,0 +1,92 @@
+"""End-to-end through the C++ command line on the GPU: stdout must be BYTE-IDENTICAL to the reference binary's
+(sha256 recorded in tests/golden/e2e.json by tests/golden/make_golden.py) and the stderr summary lines equal."""
+import hashlib
+import json
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+import _cases
+import _e2e_checks
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "filtlong_amd", "bin", "filtlong")
+FIX = _cases.FIXTURES
+
+
+def run(args, cwd):
+    p = subprocess.run([BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=cwd,
+                       env=dict(os.environ, LANG="C", LC_ALL="C"))
+    err = p.stderr.decode(errors="replace")
+    keep = [l.strip() for l in err.replace("\r", "\n").split("\n")
+            if any(t in l for t in ("target:", "keeping", "not enough", "already fall", "after ", "Error", "16-mers"))]
+    return p.returncode, p.stdout, keep, err
+
+
+def test_cli_matches_reference_binary_byte_for_byte():
+    gold = _e2e_checks.load_e2e()
+    inp = _e2e_checks.Inputs()
+    with tempfile.TemporaryDirectory() as td:
+        def w(name, data):
+            path = os.path.join(td, name)
+            open(path, "wb").write(data)
+            return path
+        fa = w("ref.fasta", _cases.fasta_bytes(inp.contigs))
+        p1 = w("sr_1.fastq", _cases.fastq_bytes(inp.sr[0]))
+        p2 = w("sr_2.fastq", _cases.fastq_bytes(inp.sr[1]))
+        pin = w("synth_phred.fastq", _cases.long_fastq_bytes(inp.preads))
+        kin = w("synth_kmer.fastq", _cases.long_fastq_bytes(inp.kreads))
+        n = 0
+        for key, g in sorted(gold.items()):
+            parts = key.split("|")
+            args = list(g["args"])
+            # the golden argv holds the generator's temp paths; map them back by flag
+            for i, a in enumerate(args):
+                if a == "-a":
+                    args[i + 1] = os.path.join(FIX, "test_reference.fasta") if parts[0] in ("sort", "trim", "split") else fa
+                elif a == "-1":
+                    args[i + 1] = os.path.join(FIX, "test_reference_1.fastq.gz") if parts[0] in ("sort", "trim", "split") else p1
+                elif a == "-2":
+                    args[i + 1] = os.path.join(FIX, "test_reference_2.fastq.gz") if parts[0] in ("sort", "trim", "split") else p2
+            if key == "bad_fastq":
+                inpath = os.path.join(FIX, "test_bad_fastq.fastq")
+            elif parts[0] in ("sort", "trim", "split"):
+                inpath = os.path.join(FIX, "test_%s.fastq" % parts[0])
+            elif parts[0] == "synth_phred":
+                inpath = pin
+            else:
+                inpath = kin
+            rc, out, keep, err = run(args + [inpath], td)
+            assert rc == g["rc"], (key, err)
+            assert len(out) == g["stdout_len"] and hashlib.sha256(out).hexdigest() == g["stdout_sha256"], key
+            # reference stderr lines hold the generator's temp file names in the hashing section; compare the rest
+            want = [l for l in g["stderr"] if "Hashing" not in l]
+            got = [l for l in keep if "Hashing" not in l]
+            assert got == want, (key, got, want)
+            n += 1
+        assert n == len(gold)
+
+
+def test_cli_fasta_input_and_gz(tmp_path):
+    """FASTA in -> FASTA out with a reference; gzipped input; FASTA without reference is an error."""
+    fx = os.path.join(FIX, "test_sort.fasta")
+    rc, out, keep, err = run(["-a", os.path.join(FIX, "test_reference.fasta"), "--target_bases", "10000", fx], str(tmp_path))
+    assert rc == 0 and out.startswith(b">test_sort_1") and out.count(b">") == 2 and b"+\n" not in out
+    rc, out, keep, err = run(["--target_bases", "10000", fx], str(tmp_path))
+    assert rc == 1 and "Error: FASTA input not supported without an external reference" in err
+    import gzip
+    gz = tmp_path / "in.fastq.gz"
+    gz.write_bytes(gzip.compress(open(os.path.join(FIX, "test_sort.fastq"), "rb").read()))
+    rc, out, keep, err = run(["--target_bases", "5000", str(gz)], str(tmp_path))
+    assert rc == 0 and out.startswith(b"@test_sort_2")
+
+
+def test_cli_verbose_scores(tmp_path):
+    """--verbose final scores (2 decimals): Phred 0.00 / 70.70 / 61.54."""
+    rc, out, keep, err = run(["--target_bases", "100000", "--verbose", os.path.join(FIX, "test_sort.fastq")], str(tmp_path))
+    assert rc == 0
+    rows = {l.split("\t")[0].strip(): l.split("\t") for l in err.split("\n") if l.startswith("test_sort_") and "\t" in l}
+    assert [rows["test_sort_%d" % i][4].strip() for i in (1, 2, 3)] == ["0.00", "70.70", "61.54"]
