@@ -74,6 +74,7 @@ def main():
     import torch
     import torch.distributed as dist
     from filtlong_amd import api, synth
+    from filtlong_amd import dist as fdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -107,8 +108,7 @@ def main():
     d_ord = torch.from_numpy(order.view(np.int32)).to(dev)
     d_ids = torch.arange(first, first + n, dtype=torch.int64, device=dev)
     # packed per-read record buffer [mean f64 | window f64 | length i32 | passed u8] -> one all-gather
-    rec_bytes = 21 * n
-    d_rec = torch.zeros(rec_bytes, dtype=torch.uint8, device=dev)
+    d_rec = fdist.alloc_records(n, dev)
     p_mean = d_rec.data_ptr()
     p_win = p_mean + 8 * n
     p_len = p_mean + 16 * n
@@ -121,11 +121,6 @@ def main():
 
     total_n = n * world
     if world > 1:
-        d_all = torch.empty(world * rec_bytes, dtype=torch.uint8, device=dev)
-        g_mean = torch.empty(total_n, dtype=torch.float64, device=dev)
-        g_win = torch.empty(total_n, dtype=torch.float64, device=dev)
-        g_len = torch.empty(total_n, dtype=torch.int32, device=dev)
-        g_pass = torch.empty(total_n, dtype=torch.uint8, device=dev)
         tb = torch.tensor([local_bases], dtype=torch.int64, device=dev)
         dist.all_reduce(tb)
         total_bases = int(tb.item())
@@ -139,14 +134,9 @@ def main():
         ctx.score_reads_dev(d_plane.data_ptr(), plane_bytes, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n,
                             params, p_mean, p_win, p_pass)
         if world > 1:
-            # single RCCL all-gather of the per-read records; every rank then runs the identical global stage
-            dist.all_gather_into_tensor(d_all, d_rec)
-            for r in range(world):
-                b = r * rec_bytes
-                g_mean[r * n:(r + 1) * n].copy_(d_all[b:b + 8 * n].view(torch.float64))
-                g_win[r * n:(r + 1) * n].copy_(d_all[b + 8 * n:b + 16 * n].view(torch.float64))
-                g_len[r * n:(r + 1) * n].copy_(d_all[b + 16 * n:b + 20 * n].view(torch.int32))
-                g_pass[r * n:(r + 1) * n].copy_(d_all[b + 20 * n:b + 21 * n])
+            # ONE RCCL all-gather of the per-read records (filtlong_amd/dist.py); every rank then runs the identical
+            # global stage on the gathered arrays, so the threshold is exact and no second exchange is needed.
+            g_mean, g_win, g_len, g_pass, _counts = fdist.gather_records(d_rec, n)
             torch.cuda.synchronize()
             return ctx.rank_and_cut_dev(total_n, g_mean.data_ptr(), g_win.data_ptr(), g_len.data_ptr(),
                                         g_pass.data_ptr(), target_bases=target, total_bases=total_bases)
