@@ -195,6 +195,19 @@ class Context:
         self._check(self.L.flx_synth_qual_dev(self.h, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n))
 
 
+    def synth_seq_dev(self, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n, d_ref, ref_len):
+        self._check(self.L.flx_synth_seq_dev(self.h, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n, d_ref,
+                                             ref_len))
+
+    def score_kmer_dev(self, kmers, d_plane, plane_bytes, d_offsets, d_lengths, d_order, n, params, scores):
+        """flx_score_batch_dev in k-mer mode; `scores` is a filled _lib.Scores with device pointers."""
+        rc = self.L.flx_score_batch_dev(self.h, kmers.h, d_plane, plane_bytes, d_offsets, d_lengths, d_order, n,
+                                        C.byref(params), C.byref(scores))
+        if rc != 5:
+            self._check(rc)
+        return rc
+
+
 class Kmers:
     """Reference 16-mer set on the device — mirrors the reference's Kmers (src/kmers.h:28-56)."""
 

@@ -43,7 +43,57 @@ __global__ void __launch_bounds__(256) k_synth_qual(uint64_t seed, uint8_t *plan
     }
 }
 
+// Long reads for the k-mer configurations: read = forward substring of the reference genome
+// starting at mix(START) % (ref_len - L), per-read substitution rate (mix(ERATE) % 13) percent applied per base by
+// an integer threshold, and for 30 % of the reads longer than 3000 one 800-base random junk block at
+// 500 + mix(JUNK,1) % (L - 2000)  (exercises window = 0, --trim and --split).
+__global__ void __launch_bounds__(256) k_synth_seq(uint64_t seed, uint8_t *plane, const uint64_t *offsets,
+                                                   const int32_t *lengths, const uint64_t *read_ids, uint64_t n,
+                                                   const uint8_t *ref, uint64_t ref_len) {
+    for (uint64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const uint64_t gid = read_ids ? read_ids[r] : r;
+        const int L = lengths[r];
+        uint8_t *dst = plane + offsets[r];
+        const uint64_t start = ref_len > (uint64_t)L ? mix(seed, 6, gid, 0) % (ref_len - (uint64_t)L) : 0;
+        const uint32_t erate = (uint32_t)(mix(seed, 7, gid, 0) % 13);
+        const bool junk = L > 3000 && (mix(seed, 9, gid, 0) % 10) < 3;
+        const int jstart = junk ? 500 + (int)(mix(seed, 9, gid, 1) % (uint64_t)(L - 2000)) : -1;
+        const int L16 = (L + 15) & ~15;
+        for (int p = threadIdx.x; p < L16; p += 256) {
+            uint8_t c = 0;
+            if (p < L) {
+                if (junk && p >= jstart && p < jstart + 800) {
+                    const uint64_t h = mix(seed, 4, gid, (uint64_t)p >> 5);
+                    c = "ACGT"[(h >> (2 * (p & 31))) & 3];
+                } else {
+                    c = ref[(start + (uint64_t)p) % ref_len];
+                    const uint64_t h = mix(seed, 8, gid, (uint64_t)p >> 2);
+                    const uint32_t f = (uint32_t)(h >> (16 * (p & 3))) & 0xffffu;
+                    if ((f & 0xff) % 100 < erate) c = "ACGT"[(f >> 8) & 3];
+                }
+            }
+            dst[p] = c;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int flx_synth_seq_dev(flx_ctx *ctx, uint64_t seed, void *d_plane, uint64_t plane_bytes, const void *d_offsets,
+                                 const void *d_lengths, const void *d_read_ids, uint64_t n_reads, const void *d_ref,
+                                 uint64_t ref_len) {
+    if (!ctx) return FLX_ERR_INVALID;
+    (void)plane_bytes;
+    if (n_reads == 0) return FLX_OK;
+    if (!d_ref || ref_len == 0) return flx_fail(ctx, FLX_ERR_INVALID, "reference genome required");
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_reads, 65535ull * 16);
+    hipLaunchKernelGGL(k_synth_seq, dim3(grid), dim3(256), 0, ctx->stream, seed, (uint8_t *)d_plane, (const uint64_t *)d_offsets,
+                       (const int32_t *)d_lengths, (const uint64_t *)d_read_ids, n_reads, (const uint8_t *)d_ref, ref_len);
+    FLX_HIP(ctx, hipGetLastError());
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FLX_OK;
+}
 
 extern "C" int flx_synth_qual_dev(flx_ctx *ctx, uint64_t seed, void *d_plane, uint64_t plane_bytes,
                                   const void *d_offsets, const void *d_lengths, const void *d_read_ids,

@@ -64,3 +64,23 @@ def bases_read(stream, read, start, length, seed=SEED):
     h = mix(seed, stream, read, pos >> _M(5))
     idx = (h >> (_M(2) * (pos & _M(31)))) & _M(3)
     return np.frombuffer(b"ACGT", dtype=np.uint8)[idx.astype(np.int64)]
+
+
+def seq_read(read, length, ref, seed=SEED):
+    """k-mer-mode long read (uint8[length]) drawn from reference genome `ref` (uint8 array of ASCII ACGT); same
+    definition as k_synth_seq in csrc/synth.hip."""
+    L = int(length)
+    ref_len = len(ref)
+    start = int(mix(seed, STREAM_START, read, 0) % _M(ref_len - L)) if ref_len > L else 0
+    erate = int(mix(seed, STREAM_ERATE, read, 0) % _M(13))
+    pos = np.arange(L, dtype=np.uint64)
+    out = ref[(start + pos.astype(np.int64)) % ref_len].copy()
+    h = mix(seed, STREAM_SUB, read, pos >> _M(2))
+    f = (h >> (_M(16) * (pos & _M(3)))) & _M(0xFFFF)
+    sub = (f & _M(0xFF)) % _M(100) < _M(erate)
+    out[sub] = np.frombuffer(b"ACGT", dtype=np.uint8)[((f >> _M(8)) & _M(3)).astype(np.int64)][sub]
+    if L > 3000 and int(mix(seed, STREAM_JUNK, read, 0) % _M(10)) < 3:
+        js = 500 + int(mix(seed, STREAM_JUNK, read, 1) % _M(L - 2000))
+        je = min(js + 800, L)
+        out[js:je] = bases_read(STREAM_BASE, read, js, je - js, seed)
+    return out

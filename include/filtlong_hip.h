@@ -202,6 +202,12 @@ int flx_kmerset_contains(const flx_kmerset *set, const uint32_t *kmers, uint64_t
 int flx_synth_qual_dev(flx_ctx *ctx, uint64_t seed, void *d_plane, uint64_t plane_bytes, const void *d_offsets,
                        const void *d_lengths, const void *d_read_ids, uint64_t n_reads);
 
+/* k-mer configurations: reads drawn from a device-resident reference genome (d_ref, ASCII ACGT) with per-read
+ * substitution rates and junk blocks. */
+int flx_synth_seq_dev(flx_ctx *ctx, uint64_t seed, void *d_plane, uint64_t plane_bytes, const void *d_offsets,
+                      const void *d_lengths, const void *d_read_ids, uint64_t n_reads, const void *d_ref,
+                      uint64_t ref_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -155,3 +155,12 @@ def long_fastq_bytes(reads):
     for name, s, q in reads:
         out += [b"@" + name.encode() + b" extra comment", s, b"+", q]
     return b"\n".join(out) + b"\n"
+
+
+def c1_fastq_bytes(n=10_000, length=5000, seed=synth.SEED):
+    """BASELINE.json configs[0] (C1): n reads x 5 kbp, Phred-only, as a FASTQ file (seq is irrelevant in Phred mode)."""
+    seq = (b"ACGT" * (length // 4 + 1))[:length]
+    out = []
+    for i in range(n):
+        out += [("@c1_%d" % i).encode(), seq, b"+", synth.qual_read(i, length, seed).tobytes()]
+    return b"\n".join(out) + b"\n"

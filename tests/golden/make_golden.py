@@ -193,6 +193,13 @@ def main():
                                                                           "70"], td)
             e2e["synth_kmer|%s|split40" % mode] = e2e_case(kin, rargs + ["--trim", "--split", "40", "--min_length",
                                                                         "200", "--target_bases", str(ktot // 3)], td)
+        # BASELINE.json configs[0] (C1): 10k reads x 5 kbp, Phred-only --min_length 1000 --keep_percent 90
+        c1 = os.path.join(td, "c1.fastq")
+        with open(c1, "wb") as f:
+            f.write(_cases.c1_fastq_bytes())
+        r = e2e_case(c1, ["--min_length", "1000", "--keep_percent", "90"], td)
+        r["names"] = r["names"][:20] + ["..."]  # ~9000 names: the stdout digest pins them
+        e2e["c1|min_length1000|keep90"] = r
         with open(os.path.join(HERE, "e2e.json"), "w") as f:
             json.dump(e2e, f, indent=0, sort_keys=True)
     print("golden vectors written to", HERE)

@@ -37,6 +37,7 @@ def test_cli_matches_reference_binary_byte_for_byte():
         fa = w("ref.fasta", _cases.fasta_bytes(inp.contigs))
         p1 = w("sr_1.fastq", _cases.fastq_bytes(inp.sr[0]))
         p2 = w("sr_2.fastq", _cases.fastq_bytes(inp.sr[1]))
+        c1 = w("c1.fastq", _cases.c1_fastq_bytes())
         pin = w("synth_phred.fastq", _cases.long_fastq_bytes(inp.preads))
         kin = w("synth_kmer.fastq", _cases.long_fastq_bytes(inp.kreads))
         n = 0
@@ -53,6 +54,8 @@ def test_cli_matches_reference_binary_byte_for_byte():
                     args[i + 1] = os.path.join(FIX, "test_reference_2.fastq.gz") if parts[0] in ("sort", "trim", "split") else p2
             if key == "bad_fastq":
                 inpath = os.path.join(FIX, "test_bad_fastq.fastq")
+            elif parts[0] == "c1":
+                inpath = c1  # BASELINE.json configs[0]: 10k reads x 5 kbp --min_length 1000 --keep_percent 90
             elif parts[0] in ("sort", "trim", "split"):
                 inpath = os.path.join(FIX, "test_%s.fastq" % parts[0])
             elif parts[0] == "synth_phred":

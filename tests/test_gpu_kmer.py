@@ -150,3 +150,24 @@ def test_e2e_all_goldens(be):
     """Every end-to-end golden of the real reference binary (Phred, -a, -1/-2, --trim, --split, weights, cut-offs)."""
     n = _e2e_checks.check_all(be)
     assert n >= 50
+
+
+def test_device_seq_generator_matches_numpy(ctx):
+    import torch
+    from filtlong_amd import synth
+    ref = synth.bases_read(synth.STREAM_REF, 0, 0, 60000)
+    lens = np.array([16, 200, 3500, 9000, 4097, 31], dtype=np.int32)
+    ids = np.array([0, 7, 11, 123456789, 3, 2], dtype=np.uint64)
+    plane, offsets, _ = api.pack_reads([b"\0" * int(L) for L in lens])
+    d_plane = torch.zeros(plane.nbytes, dtype=torch.uint8, device="cuda")
+    d_off = torch.from_numpy(offsets.astype(np.int64)).cuda()
+    d_len = torch.from_numpy(lens).cuda()
+    d_ids = torch.from_numpy(ids.astype(np.int64)).cuda()
+    d_ref = torch.from_numpy(ref).cuda()
+    torch.cuda.synchronize()
+    ctx.synth_seq_dev(synth.SEED, d_plane.data_ptr(), plane.nbytes, d_off.data_ptr(), d_len.data_ptr(), d_ids.data_ptr(),
+                      len(lens), d_ref.data_ptr(), len(ref))
+    got = d_plane.cpu().numpy()
+    for i, L in enumerate(lens):
+        o = int(offsets[i])
+        assert (got[o:o + L] == synth.seq_read(int(ids[i]), int(L), ref)).all(), i
