@@ -164,3 +164,46 @@ def c1_fastq_bytes(n=10_000, length=5000, seed=synth.SEED):
     for i in range(n):
         out += [("@c1_%d" % i).encode(), seq, b"+", synth.qual_read(i, length, seed).tobytes()]
     return b"\n".join(out) + b"\n"
+
+
+# ------------------------------------------------------------------------------------------------------------
+# engineered Bloom-filter false positive (reference src/kmers.cpp:142-166 + src/bloom_filter.h)
+# ------------------------------------------------------------------------------------------------------------
+BLOOM_SALTS = [0x1B5793D2, 0x81BDFA38, 0xEB8E30D5, 0x45B52496, 0x85C1FE3C, 0x3DACB627, 0x78776869, 0x94A40D1E,
+               0x5F9BB638, 0x40FB59D5, 0x8174BDB2, 0x0B466EAA, 0x209D29A7]
+BLOOM_BITS = 1917295480
+_M32 = 0xFFFFFFFF
+
+
+def bloom_index(kmer, i):
+    s = BLOOM_SALTS[i]
+    h = s ^ (~(((s << 11) & _M32) + (kmer ^ (s >> 5))) & _M32)
+    return (h & _M32) % BLOOM_BITS
+
+
+def bloom_preimage(index, i=0):
+    """A 16-mer whose i-th Bloom hash lands on bit `index` (hash_ap is invertible for 4-byte keys)."""
+    s = BLOOM_SALTS[i]
+    h = index  # index < table size < 2^32, so h = index is a valid hash value
+    x = (~(h ^ s)) & _M32                 # = (s << 11) + (kmer ^ (s >> 5))   (mod 2^32)
+    return (((x - ((s << 11) & _M32)) & _M32) ^ (s >> 5)) & _M32
+
+
+def kmer_to_seq(k):
+    return bytes(b"ACGT"[(k >> (30 - 2 * j)) & 3] for j in range(16))
+
+
+def bloom_fp_case():
+    """Short-read 'files' (lists of 16 bp reads) in which the 16-mer TARGET is seen exactly 3 times but enters the set
+    because every one of its 13 Bloom bits was already set by other 16-mers at its first sighting (so it starts
+    counting at 2), while CONTROL — also seen exactly 3 times — does not.  Returns (file1, file2, target, control)."""
+    target = 0x1B2D3F4A
+    control = 0x6C0FFEE5
+    # helper j reaches the target's j-th bit through a DIFFERENT hash function (salt j+1), so it is another 16-mer
+    helpers = [bloom_preimage(bloom_index(target, j), (j + 1) % 13) for j in range(13)]
+    assert all(bloom_index(h, (j + 1) % 13) == bloom_index(target, j) for j, h in enumerate(helpers))
+    assert target not in helpers and len(set(helpers)) == 13
+    file1 = [kmer_to_seq(h) for h in helpers]                 # first sightings of the helpers: they insert
+    file1 += [kmer_to_seq(target), kmer_to_seq(control)]      # 1st sighting of both
+    file2 = [kmer_to_seq(target), kmer_to_seq(control)] * 2   # 2nd and 3rd sightings
+    return file1, file2, target, control

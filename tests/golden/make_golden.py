@@ -193,6 +193,22 @@ def main():
                                                                           "70"], td)
             e2e["synth_kmer|%s|split40" % mode] = e2e_case(kin, rargs + ["--trim", "--split", "40", "--min_length",
                                                                         "200", "--target_bases", str(ktot // 3)], td)
+        # engineered Bloom false positive (3 sightings are enough when all 13 bits were pre-set; kmers.cpp:148-155)
+        import numpy as np
+        f1, f2, target, control = _cases.bloom_fp_case()
+        b1, b2 = os.path.join(td, "bfp_1.fastq"), os.path.join(td, "bfp_2.fastq")
+        with open(b1, "wb") as f:
+            f.write(_cases.fastq_bytes(f1))
+        with open(b2, "wb") as f:
+            f.write(_cases.fastq_bytes(f2))
+        L = _oracle.lib()
+        q = np.array([target, control, L.flo_start_kmer_rev(_cases.kmer_to_seq(target)),
+                      L.flo_start_kmer_rev(_cases.kmer_to_seq(control))], dtype=np.uint32)
+        _, present, _ = _oracle.ref_probe([], ["--target_bases", "1", "-1", b1, "-2", b2], kmer_queries=q)
+        with open(os.path.join(HERE, "bloom_fp.json"), "w") as f:
+            json.dump({"target": target, "control": control, "present": {str(int(k)): bool(v) for k, v in present.items()}},
+                      f, indent=0, sort_keys=True)
+
         # BASELINE.json configs[0] (C1): 10k reads x 5 kbp, Phred-only --min_length 1000 --keep_percent 90
         c1 = os.path.join(td, "c1.fastq")
         with open(c1, "wb") as f:

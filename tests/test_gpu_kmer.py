@@ -171,3 +171,18 @@ def test_device_seq_generator_matches_numpy(ctx):
     for i, L in enumerate(lens):
         o = int(offsets[i])
         assert (got[o:o + L] == synth.seq_read(int(ids[i]), int(L), ref)).all(), i
+
+
+def test_bloom_false_positive_rule(be):
+    """Engineered Bloom false positive (see tests/test_oracle_golden.py): the device set must contain the 3-sighting
+    16-mer whose bits were pre-set, and not the control — exactly like the real reference (tests/golden/bloom_fp.json)."""
+    gold = json.load(open(os.path.join(_cases.GOLDEN, "bloom_fp.json")))
+    f1, f2, target, control = _cases.bloom_fp_case()
+    ks = be.kmers(short_files=[f1, f2])
+    q = np.array([int(k) for k in gold["present"]], dtype=np.uint32)
+    got = ks.is_kmer_present(q)
+    assert [bool(x) for x in got] == [gold["present"][str(int(k))] for k in q]
+    assert len(ks) == 1
+    # same reads, but the target's first sighting comes BEFORE the helpers: no false positive, empty set
+    ks2 = be.kmers(short_files=[[_cases.kmer_to_seq(target)] + f1[:13], f2[:1] + f2[2:3]])
+    assert len(ks2) == 0 and not ks2.is_kmer_present(np.array([target], dtype=np.uint32))[0]

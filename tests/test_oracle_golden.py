@@ -194,3 +194,17 @@ def test_kmer_set_membership(synth_sets, fixture_sets):
         pres_q = present[np.isin(present, q)]
         assert len(ks) == g["n_present"]
         assert hashlib.sha256(pres_q.tobytes()).hexdigest() == g["present_sha256"]
+
+
+def test_bloom_false_positive_rule():
+    """A 16-mer seen only 3 times enters the set when its 13 Bloom bits were all set by OTHER 16-mers before its first
+    sighting (src/kmers.cpp:148-155); engineered with the invertible 4-byte hash_ap, confirmed by the real reference."""
+    gold = json.load(open(os.path.join(G, "bloom_fp.json")))
+    f1, f2, target, control = _cases.bloom_fp_case()
+    assert gold["present"][str(target)] is True and gold["present"][str(control)] is False
+    ks = _oracle.KmerSet()
+    ks.add_short_reads(f1)
+    ks.add_short_reads(f2)
+    for k, v in gold["present"].items():
+        assert ks.contains(int(k)) == v
+    assert len(ks) == 1
