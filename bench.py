@@ -175,6 +175,12 @@ def main():
         algo_bytes = local_bases + 25 * n
         avg_kernel_ms = k_ms / max(k_n, 1)
         achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 if k_n else 0.0
+        # HBM traffic of one launch from the PMC passes of tools/prof_phred.sh (separate rocprofv3 --pmc runs of this same
+        # C2 command; FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes), only when the workload is the same.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_c2.json")
+        if os.path.exists(tpath) and n == 10_000_000 and not args.fixed_len and args.window_size == 250:
+            traffic = int(json.load(open(tpath))["traffic_bytes"])
         info = ctx.device_info()
         out = {
             "metric": "Mbases/s scored+sorted",
@@ -199,7 +205,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": "flx_score_phred_ring", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_kernel_ms": round(avg_kernel_ms, 3), "launches": int(k_n), "algorithmic_bytes": int(algo_bytes),
             },
             "stage_ms_per_step": {"score_kernel": round(k_ms / args.steps, 3), "sort": round(sort_ms / args.steps, 3),

@@ -109,16 +109,28 @@ __global__ void k_cut_weights(uint64_t n, const uint32_t *sorted_idx, const int3
 // The walk of main.cpp:251-257 keeps a read iff it passed and bases_so_far (before it) < target.  bases_so_far is
 // non-decreasing along the sorted order, so the kept reads are exactly the passed reads up to and including the
 // LAST passed read whose exclusive prefix is below the target.  Find that position (sequential reads only) ...
-__global__ void k_cut_find(uint64_t n, const int64_t *excl, const uint8_t *pre_sorted, int64_t target,
-                           unsigned long long *last_kept_pos_plus1) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long last = 0;
-    if (i < n && pre_sorted[i] && excl[i] < target) last = i + 1;
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long l2 = __shfl_xor(last, o, 64);
-        last = l2 > last ? l2 : last;
+__global__ void __launch_bounds__(64) k_cut_find(uint64_t n, const int64_t *excl, const uint8_t *pre_sorted, int64_t target,
+                                                  unsigned long long *last_kept_pos_plus1) {
+    // single wavefront: binary search for the last position whose exclusive prefix is below the target (excl is
+    // non-decreasing), then step back to the nearest read that had passed before the cut.
+    const int lane = threadIdx.x;
+    uint64_t lo = 0, hi = n;  // first position with excl >= target lies in [lo, hi]
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (excl[mid] < target) lo = mid + 1;
+        else hi = mid;
     }
-    if ((threadIdx.x & 63) == 0 && last) atomicMax(last_kept_pos_plus1, last);
+    // positions [0, lo) have excl < target
+    unsigned long long found = 0;
+    for (uint64_t base = lo; base > 0 && !found;) {
+        const uint64_t start = base > 64 ? base - 64 : 0;
+        const uint64_t i = start + lane;
+        const bool hit = i < base && pre_sorted[i];
+        const unsigned long long m = __ballot(hit);
+        if (m) found = start + (63 - __clzll(m)) + 1;
+        base = start;
+    }
+    if (lane == 0) *last_kept_pos_plus1 = found;
 }
 
 // ... and then mark in READ order, without any scattered access: the sort is stable, so "at or before sorted
@@ -306,7 +318,7 @@ extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean
     hipLaunchKernelGGL(k_cut_weights, dim3(nb), dim3(256), 0, st, n, svals, length, passed, wts, pre_sorted);
     FLX_CHECK(flx_exclusive_scan_i64(ctx, n, wts, excl, sort_tmp, sort_ws));
 
-    hipLaunchKernelGGL(k_cut_find, dim3(nb), dim3(256), 0, st, n, excl, pre_sorted, target, d_acc + 1);
+    hipLaunchKernelGGL(k_cut_find, dim3(1), dim3(64), 0, st, n, excl, pre_sorted, target, d_acc + 1);
     unsigned long long h_acc[3] = {0, 0, 0};
     FLX_HIP(ctx, hipMemcpyAsync(h_acc, d_acc, 24, hipMemcpyDeviceToHost, st));
     FLX_HIP(ctx, hipStreamSynchronize(st));
