@@ -1,6 +1,5 @@
-// rank.hip — seam 3: global statistics, normalisation, final score, device radix sort and the
-// --target_bases / --keep_percent cut.  Replaces reference src/main.cpp:169-261 and
-// Read::set_final_score (src/read.cpp:249-267).
+// rank.hip — seam 3: global statistics, normalisation, final score and the --target_bases / --keep_percent cut.
+// Replaces reference src/main.cpp:169-261 and Read::set_final_score (src/read.cpp:249-267).
 //
 // Exactness plan (DESIGN.md "global stage"):
 //   * min / max / mean / stdev of the mean qualities: the reference folds them serially in reads2
@@ -12,8 +11,18 @@
 //     rounded, so the device's pow may differ in the last ulp.  Final scores are therefore used on the
 //     device only to ORDER reads; the reads whose device score lies within a relative band of the
 //     cut score are re-scored on the host with the host libm ("boundary audit") and the cut is
-//     re-decided among them.  An exact tie straddling the cut falls back to the reference's own
-//     std::sort tie order (host path, rare; report->exact_fallback = 1).
+//     re-decided among them.  NaN scores and exact ties straddling the cut fall back to the reference's
+//     own std::sort order (host path, rare; report->exact_fallback = 1).
+//
+// The cut itself (std::sort by score + serial walk, main.cpp:247-257): the walk keeps a read iff it passed and
+// the bases kept before it are < target, so the kept reads are exactly the passed reads up to and including
+// the first one (in descending-score order, ties in reads2 order) at which the running total reaches the
+// target.  Two device implementations of that:
+//   * SELECT (default): MSD radix selection with weights — 8 histogram passes over the order-preserving 64-bit
+//     keys (one byte per pass, bins hold summed read lengths) locate the crossing key without moving any data;
+//     streaming reads only, which matters when the stage is replicated over 8x the reads after the all-gather.
+//   * SORT (FLX_RANK_SORT=1, and the fallback when the audit band is huge): stable LSD radix sort of
+//     (key, index) + exclusive scan of the lengths in sorted order + binary search (sort.hip).
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -82,7 +91,7 @@ __global__ void k_final_score(uint64_t n, const double *mean_q, const double *wi
     if (final_score) final_score[i] = f;
     if (keys) {
         keys[i] = ~key_ascending(f);  // descending score == ascending key
-        vals[i] = (uint32_t)i;
+        if (vals) vals[i] = (uint32_t)i;
     }
 }
 
@@ -144,6 +153,55 @@ __global__ void k_cut_mark(uint64_t n, const uint64_t *keys_orig, uint64_t key_s
     if (!before) passed[i] = 0;
 }
 
+
+// ---- SELECT path ---------------------------------------------------------------------------------
+// weight histogram of one key byte: bins[b] += length of every PASSED read whose key agrees with `prefix` in its top
+// `prefix_bytes` bytes and whose next byte is b
+__global__ void __launch_bounds__(256) k_select_hist(uint64_t n, const uint64_t *keys, const int32_t *length,
+                                                     const uint8_t *passed, uint64_t prefix, int prefix_bytes,
+                                                     unsigned long long *bins) {
+    __shared__ unsigned long long h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int shift = 56 - 8 * prefix_bytes;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = keys[i];
+        const bool match = prefix_bytes == 0 || (k >> (shift + 8)) == prefix;
+        if (match && passed[i]) {
+            const int len = length[i];
+            if (len > 0) atomicAdd(&h[(k >> shift) & 0xff], (unsigned long long)len);
+        }
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
+}
+
+// every read whose key lies in [k_lo, k_hi] is appended to the band list; the lengths of passed reads with a
+// smaller key (= better score) are summed: that is bases_so_far when the walk enters the band
+__global__ void __launch_bounds__(256) k_select_band(uint64_t n, const uint64_t *keys, const int32_t *length,
+                                                     const uint8_t *passed, uint64_t k_lo, uint64_t k_hi,
+                                                     uint32_t *band_idx, unsigned int *band_n, unsigned int cap,
+                                                     unsigned long long *weight_before) {
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = keys[i];
+        if (k < k_lo) {
+            if (passed[i]) acc += (unsigned long long)length[i];
+        } else if (k <= k_hi) {
+            const unsigned int at = atomicAdd(band_n, 1u);
+            if (at < cap) band_idx[at] = (uint32_t)i;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(weight_before, acc);
+}
+
+// everything at or beyond the band fails; the kept members of the band are switched back on by the host
+__global__ void __launch_bounds__(256) k_select_mark(uint64_t n, const uint64_t *keys, uint64_t k_lo, uint8_t *passed) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && keys[i] >= k_lo) passed[i] = 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -177,13 +235,20 @@ static int64_t compute_target(int target_bases_set, int64_t target_bases, int ke
 static int exact_host_cut(flx_ctx *ctx, uint64_t n, const double *d_mean, const double *d_window,
                           const int32_t *d_length, uint8_t *d_passed, const uint32_t *d_sorted_idx,
                           const uint8_t *d_pre_sorted, const NormArgs &s, int64_t target, flx_cut_report *rep) {
+    // d_sorted_idx / d_pre_sorted != NULL: the SORT path already overwrote d_passed; rebuild the pre-cut flags.
+    // NULL: d_passed still holds the pre-cut flags (SELECT path).
     std::vector<double> mean(n), window(n), fs(n);
     std::vector<int32_t> len(n);
-    std::vector<uint8_t> passed(n), pre(n);
-    std::vector<uint32_t> sidx(n);
-    FLX_HIP(ctx, hipMemcpy(pre.data(), d_pre_sorted, n, hipMemcpyDeviceToHost));
-    FLX_HIP(ctx, hipMemcpy(sidx.data(), d_sorted_idx, n * 4, hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < n; ++i) passed[sidx[i]] = pre[i];  // pass flags as they were before the cut
+    std::vector<uint8_t> passed(n);
+    if (d_sorted_idx) {
+        std::vector<uint8_t> pre(n);
+        std::vector<uint32_t> sidx(n);
+        FLX_HIP(ctx, hipMemcpy(pre.data(), d_pre_sorted, n, hipMemcpyDeviceToHost));
+        FLX_HIP(ctx, hipMemcpy(sidx.data(), d_sorted_idx, n * 4, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; ++i) passed[sidx[i]] = pre[i];
+    } else {
+        FLX_HIP(ctx, hipMemcpy(passed.data(), d_passed, n, hipMemcpyDeviceToHost));
+    }
     FLX_HIP(ctx, hipMemcpy(mean.data(), d_mean, n * 8, hipMemcpyDeviceToHost));
     FLX_HIP(ctx, hipMemcpy(window.data(), d_window, n * 8, hipMemcpyDeviceToHost));
     FLX_HIP(ctx, hipMemcpy(len.data(), d_length, n * 4, hipMemcpyDeviceToHost));
@@ -205,84 +270,156 @@ static int exact_host_cut(flx_ctx *ctx, uint64_t n, const double *d_mean, const 
     return FLX_OK;
 }
 
-extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean_q, const void *d_window_q,
-                                    const void *d_length, void *d_passed, double lw, double mw, double ww,
-                                    int target_bases_set, int64_t target_bases, int keep_percent_set,
-                                    double keep_percent, int64_t total_bases, void *d_final_score,
-                                    flx_cut_report *rep) {
-    if (!ctx) return FLX_ERR_INVALID;
-    if (!rep) return flx_fail(ctx, FLX_ERR_INVALID, "report must not be NULL");
-    memset(rep, 0, sizeof *rep);
-    if (n > 0xffffffffull) return flx_fail(ctx, FLX_ERR_INVALID, "at most 2^32-1 reads");
-    FLX_HIP(ctx, hipSetDevice(ctx->device));
-    const double *mean = (const double *)d_mean_q;
-    const double *window = (const double *)d_window_q;
-    const int32_t *length = (const int32_t *)d_length;
-    uint8_t *passed = (uint8_t *)d_passed;
+// =================================================================================================
+// SELECT path
+// =================================================================================================
+static const int FLX_SELECT_BAND_TOO_LARGE = -1000;
+
+static double key_to_score(uint64_t k) {
+    uint64_t a = ~k;  // ascending key
+    uint64_t b = (a >> 63) ? (a & 0x7fffffffffffffffull) : ~a;
+    double v;
+    memcpy(&v, &b, 8);
+    return v;
+}
+
+static int cut_by_select(flx_ctx *ctx, uint64_t n, const double *mean, const double *window, const int32_t *length,
+                         uint8_t *passed, const NormArgs &s, int64_t target, void *d_final_score, flx_cut_report *rep) {
     hipStream_t st = ctx->stream;
-    const bool cutting = target_bases_set || keep_percent_set;
-
-    // ---- a20: statistics (exact serial folds) -------------------------------------------------
-    flx_stats stats;
-    FLX_CHECK(flx_exact_stats(ctx, n, mean, &stats));
-    NormArgs s;
-    s.qmean = stats.mean;
-    s.qstd = stats.stdev;
-    if (stats.stdev > 0.0) {  // main.cpp:188-195
-        s.zmin = (stats.min - stats.mean) / stats.stdev;
-        const double zmax = (stats.max - stats.mean) / stats.stdev;
-        s.zspan = zmax - s.zmin;
-        rep->max_z = zmax;
-    } else {
-        s.zmin = 1.0;
-        s.zspan = 1.0 - 1.0;
-        rep->max_z = 1.0;
-    }
-    s.lw = lw; s.mw = mw; s.ww = ww;
-    rep->mean_quality = stats.mean;
-    rep->stdev_quality = stats.stdev;
-    rep->min_z = s.zmin;
-
-    // ---- early outs that need no sort ----------------------------------------------------------
-    int64_t target = 0;
-    bool need_sort = false;
-    if (cutting && n) {
-        void *scr;
-        FLX_CHECK(flx_scratch(ctx, 64, &scr));
-        unsigned long long *d_acc = (unsigned long long *)scr;
-        FLX_HIP(ctx, hipMemsetAsync(d_acc, 0, 8, st));
-        flx_time_begin(ctx, "flx_rank_passed_bases");
-        hipLaunchKernelGGL(k_passed_bases, dim3(1024), dim3(256), 0, st, n, length, passed, d_acc);
-        flx_time_end(ctx);
-        unsigned long long passed_bases = 0;
-        FLX_HIP(ctx, hipMemcpyAsync(&passed_bases, d_acc, 8, hipMemcpyDeviceToHost, st));
-        FLX_HIP(ctx, hipStreamSynchronize(st));
-        target = compute_target(target_bases_set, target_bases, keep_percent_set, keep_percent, total_bases);
-        rep->target_bases = target;
-        if (target >= total_bases) rep->outcome = FLX_CUT_NOT_ENOUGH;
-        else if (target >= (int64_t)passed_bases) rep->outcome = FLX_CUT_ALREADY_BELOW;
-        else { rep->outcome = FLX_CUT_SORTED; need_sort = true; }
-    } else if (cutting) {
-        target = compute_target(target_bases_set, target_bases, keep_percent_set, keep_percent, total_bases);
-        rep->target_bases = target;
-        rep->outcome = target >= total_bases ? FLX_CUT_NOT_ENOUGH : FLX_CUT_ALREADY_BELOW;
-    }
-    if (n == 0) return FLX_OK;
-
-    // ---- a21/a22: normalise + final score (+ sort keys) ---------------------------------------
     const unsigned nb = (unsigned)((n + 255) / 256);
-    if (!need_sort) {
-        if (d_final_score) {
-            flx_time_begin(ctx, "flx_rank_final_score");
-            hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s,
-                               (double *)d_final_score, (uint64_t *)nullptr, (uint32_t *)nullptr,
-                               (unsigned int *)nullptr);
-            flx_time_end(ctx);
-            FLX_HIP(ctx, hipStreamSynchronize(st));
-        }
-        return FLX_OK;
-    }
+    const unsigned cap = 1u << 16;
+    const size_t bytes = n * 8 + 256 * 8 * 8 + (size_t)cap * 4 + 1024;
+    void *scr;
+    FLX_CHECK(flx_scratch(ctx, bytes, &scr));
+    char *p = (char *)scr;
+    uint64_t *keys = (uint64_t *)p; p += n * 8;
+    unsigned long long *bins = (unsigned long long *)p; p += 256 * 8 * 8;  // one 256-bin table per pass
+    unsigned long long *d_acc = (unsigned long long *)p; p += 256;
+    uint32_t *band_idx = (uint32_t *)p;
 
+    FLX_HIP(ctx, hipMemsetAsync(bins, 0, 256 * 8 * 8 + 256, st));
+    flx_time_begin(ctx, "flx_rank_final_score");
+    hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s, (double *)d_final_score, keys,
+                       (uint32_t *)nullptr, (unsigned int *)(d_acc + 2));
+    flx_time_end(ctx);
+
+    // ---- 8 weighted histogram passes, most significant byte first ------------------------------------------
+    flx_time_begin(ctx, "flx_rank_select");
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
+    uint64_t prefix = 0;
+    long long remaining = target;  // bases still to be collected inside the current prefix
+    unsigned long long h_nan = 0;
+    for (int pass = 0; pass < 8; ++pass) {
+        unsigned long long *b = bins + 256 * pass;
+        hipLaunchKernelGGL(k_select_hist, dim3(grid), dim3(256), 0, st, n, keys, length, passed, prefix, pass, b);
+        unsigned long long h[256];
+        FLX_HIP(ctx, hipMemcpyAsync(h, b, sizeof h, hipMemcpyDeviceToHost, st));
+        if (pass == 0) FLX_HIP(ctx, hipMemcpyAsync(&h_nan, d_acc + 2, 8, hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+        if (pass == 0 && (h_nan & 1ull)) {
+            // NaN scores (stdev == 0 -> 0/0, main.cpp:192-206, or 0/0 window ratios): the reference's comparator is
+            // inconsistent and its outcome is whatever libstdc++'s introsort does on reads2 order -> host path.
+            flx_time_end(ctx);
+            return exact_host_cut(ctx, n, mean, window, length, passed, nullptr, nullptr, s, target, rep);
+        }
+        int d = 0;
+        long long cum = 0;
+        for (; d < 256; ++d) {
+            if (cum + (long long)h[d] >= remaining) break;
+            cum += (long long)h[d];
+        }
+        if (d == 256) {  // cannot happen when 0 < target < passed_bases
+            flx_time_end(ctx);
+            return flx_fail(ctx, FLX_ERR_STATE, "radix select ran out of weight (target %lld)", (long long)target);
+        }
+        remaining -= cum;
+        prefix = (prefix << 8) | (uint64_t)d;
+    }
+    const uint64_t key_star = prefix;  // key of the read at which the walk reaches the target
+    const double sp = key_to_score(key_star);
+
+    // ---- band around the crossing score: everything the reference might order differently -------------------
+    const double kBand = 1e-11;  // relative; the device pow is good to a few ulp (1e-16), so this is generous
+    const double band = std::fabs(sp) * kBand + 1e-300;
+    const uint64_t k_lo = ~key_ascending(sp + band), k_hi = ~key_ascending(sp - band);  // descending keys: lo = best score
+    hipLaunchKernelGGL(k_select_band, dim3(grid), dim3(256), 0, st, n, keys, length, passed, k_lo, k_hi, band_idx,
+                       (unsigned int *)(d_acc + 3), cap, d_acc + 4);
+    unsigned long long h_acc[2] = {0, 0};
+    FLX_HIP(ctx, hipMemcpyAsync(&h_acc[0], d_acc + 3, 8, hipMemcpyDeviceToHost, st));
+    FLX_HIP(ctx, hipMemcpyAsync(&h_acc[1], d_acc + 4, 8, hipMemcpyDeviceToHost, st));
+    FLX_HIP(ctx, hipStreamSynchronize(st));
+    const unsigned band_n = (unsigned)(h_acc[0] & 0xffffffffull);
+    if (band_n > cap) {  // huge tie group (e.g. millions of duplicate reads): let the sort path handle it
+        flx_time_end(ctx);
+        return FLX_SELECT_BAND_TOO_LARGE;
+    }
+    std::vector<uint32_t> idx(band_n);
+    FLX_HIP(ctx, hipMemcpy(idx.data(), band_idx, (size_t)band_n * 4, hipMemcpyDeviceToHost));
+    std::sort(idx.begin(), idx.end());
+    struct Cand { uint32_t idx; uint64_t key; double score; int32_t len; uint8_t was_passed; };
+    std::vector<Cand> cand(band_n);
+    for (unsigned i = 0; i < band_n; ++i) {
+        Cand &c = cand[i];
+        c.idx = idx[i];
+        double mq, wq;
+        FLX_HIP(ctx, hipMemcpy(&mq, mean + c.idx, 8, hipMemcpyDeviceToHost));
+        FLX_HIP(ctx, hipMemcpy(&wq, window + c.idx, 8, hipMemcpyDeviceToHost));
+        FLX_HIP(ctx, hipMemcpy(&c.len, length + c.idx, 4, hipMemcpyDeviceToHost));
+        FLX_HIP(ctx, hipMemcpy(&c.was_passed, passed + c.idx, 1, hipMemcpyDeviceToHost));
+        FLX_HIP(ctx, hipMemcpy(&c.key, keys + c.idx, 8, hipMemcpyDeviceToHost));
+        c.score = host_final_score(c.len, mq, wq, s);  // host libm: what the reference computes
+    }
+    // exact order inside the band: descending exact score; the device order (key, then reads2 index) breaks the rest
+    std::vector<unsigned> ord(band_n);
+    std::iota(ord.begin(), ord.end(), 0u);
+    std::stable_sort(ord.begin(), ord.end(), [&](unsigned x, unsigned y) {
+        if (cand[x].score != cand[y].score) return cand[x].score > cand[y].score;
+        if (cand[x].key != cand[y].key) return cand[x].key < cand[y].key;
+        return cand[x].idx < cand[y].idx;
+    });
+    long long so_far = (long long)h_acc[1];
+    std::vector<uint8_t> keep(band_n, 0);
+    for (unsigned k = 0; k < band_n; ++k) {
+        Cand &c = cand[ord[k]];
+        if (c.was_passed && so_far < target) { so_far += c.len; keep[ord[k]] = 1; }
+    }
+    // a group of equal exact scores whose passed members got different decisions: only the reference's own std::sort
+    // tie order can say which of them crossed the target
+    bool tie_straddle = false;
+    for (unsigned k = 0; k < band_n;) {
+        unsigned e = k;
+        int kept_n = 0, passed_n = 0;
+        while (e < band_n && cand[ord[e]].score == cand[ord[k]].score) {
+            if (cand[ord[e]].was_passed) { ++passed_n; kept_n += keep[ord[e]]; }
+            ++e;
+        }
+        if (kept_n != 0 && kept_n != passed_n) tie_straddle = true;
+        k = e;
+    }
+    flx_time_end(ctx);
+    if (tie_straddle) return exact_host_cut(ctx, n, mean, window, length, passed, nullptr, nullptr, s, target, rep);
+
+    // ---- mark: better than the band -> unchanged; band and worse -> fail; kept band members -> back on ----------
+    hipLaunchKernelGGL(k_select_mark, dim3(nb), dim3(256), 0, st, n, keys, k_lo, passed);
+    FLX_HIP(ctx, hipStreamSynchronize(st));
+    for (unsigned i = 0; i < band_n; ++i)
+        if (keep[i]) {
+            const uint8_t one = 1;
+            FLX_HIP(ctx, hipMemcpy(passed + cand[i].idx, &one, 1, hipMemcpyHostToDevice));
+        }
+    rep->kept_bases = so_far;  // "keeping N bp", main.cpp:258
+    rep->audited = band_n;
+    FLX_HIP(ctx, hipGetLastError());
+    return FLX_OK;
+}
+
+// =================================================================================================
+// SORT path: radix sort + exclusive scan + binary search, then the boundary audit on the sorted neighbourhood
+// =================================================================================================
+static int cut_by_sort(flx_ctx *ctx, uint64_t n, const double *mean, const double *window, const int32_t *length,
+                       uint8_t *passed, const NormArgs &s, int64_t target, void *d_final_score, flx_cut_report *rep) {
+    hipStream_t st = ctx->stream;
+    const unsigned nb = (unsigned)((n + 255) / 256);
     // scratch layout: keys[2][n] u64 | vals[2][n] u32 | weights[n] i64 | excl[n] i64 | sort workspace
     const size_t sort_ws = flx_radix_sort_workspace(n);
     const size_t bytes = n * (24 + 8 + 8 + 8) + ((n + 255) & ~(size_t)255) + 256 + sort_ws;
@@ -444,6 +581,94 @@ extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean
         rep->kept_bases = so_far;
         return FLX_OK;
     }
+}
+
+
+extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean_q, const void *d_window_q,
+                                    const void *d_length, void *d_passed, double lw, double mw, double ww,
+                                    int target_bases_set, int64_t target_bases, int keep_percent_set,
+                                    double keep_percent, int64_t total_bases, void *d_final_score,
+                                    flx_cut_report *rep) {
+    if (!ctx) return FLX_ERR_INVALID;
+    if (!rep) return flx_fail(ctx, FLX_ERR_INVALID, "report must not be NULL");
+    memset(rep, 0, sizeof *rep);
+    if (n > 0xffffffffull) return flx_fail(ctx, FLX_ERR_INVALID, "at most 2^32-1 reads");
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    const double *mean = (const double *)d_mean_q;
+    const double *window = (const double *)d_window_q;
+    const int32_t *length = (const int32_t *)d_length;
+    uint8_t *passed = (uint8_t *)d_passed;
+    hipStream_t st = ctx->stream;
+    const bool cutting = target_bases_set || keep_percent_set;
+
+    // ---- a20: statistics (exact serial folds) -------------------------------------------------
+    flx_stats stats;
+    FLX_CHECK(flx_exact_stats(ctx, n, mean, &stats));
+    NormArgs s;
+    s.qmean = stats.mean;
+    s.qstd = stats.stdev;
+    if (stats.stdev > 0.0) {  // main.cpp:188-195
+        s.zmin = (stats.min - stats.mean) / stats.stdev;
+        const double zmax = (stats.max - stats.mean) / stats.stdev;
+        s.zspan = zmax - s.zmin;
+        rep->max_z = zmax;
+    } else {
+        s.zmin = 1.0;
+        s.zspan = 1.0 - 1.0;
+        rep->max_z = 1.0;
+    }
+    s.lw = lw; s.mw = mw; s.ww = ww;
+    rep->mean_quality = stats.mean;
+    rep->stdev_quality = stats.stdev;
+    rep->min_z = s.zmin;
+
+    // ---- early outs that need no sort ----------------------------------------------------------
+    int64_t target = 0;
+    bool need_sort = false;
+    if (cutting && n) {
+        void *scr;
+        FLX_CHECK(flx_scratch(ctx, 64, &scr));
+        unsigned long long *d_acc = (unsigned long long *)scr;
+        FLX_HIP(ctx, hipMemsetAsync(d_acc, 0, 8, st));
+        flx_time_begin(ctx, "flx_rank_passed_bases");
+        hipLaunchKernelGGL(k_passed_bases, dim3(1024), dim3(256), 0, st, n, length, passed, d_acc);
+        flx_time_end(ctx);
+        unsigned long long passed_bases = 0;
+        FLX_HIP(ctx, hipMemcpyAsync(&passed_bases, d_acc, 8, hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+        target = compute_target(target_bases_set, target_bases, keep_percent_set, keep_percent, total_bases);
+        rep->target_bases = target;
+        if (target >= total_bases) rep->outcome = FLX_CUT_NOT_ENOUGH;
+        else if (target >= (int64_t)passed_bases) rep->outcome = FLX_CUT_ALREADY_BELOW;
+        else { rep->outcome = FLX_CUT_SORTED; need_sort = true; }
+    } else if (cutting) {
+        target = compute_target(target_bases_set, target_bases, keep_percent_set, keep_percent, total_bases);
+        rep->target_bases = target;
+        rep->outcome = target >= total_bases ? FLX_CUT_NOT_ENOUGH : FLX_CUT_ALREADY_BELOW;
+    }
+    if (n == 0) return FLX_OK;
+
+    // ---- a21/a22: normalise + final score (+ keys) --------------------------------------------
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (!need_sort) {
+        if (d_final_score) {
+            flx_time_begin(ctx, "flx_rank_final_score");
+            hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s,
+                               (double *)d_final_score, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                               (unsigned int *)nullptr);
+            flx_time_end(ctx);
+            FLX_HIP(ctx, hipStreamSynchronize(st));
+        }
+        return FLX_OK;
+    }
+
+    {
+        const char *e = getenv("FLX_RANK_SORT");  // test hook / fallback selector
+        if (e && e[0] == '1') return cut_by_sort(ctx, n, mean, window, length, passed, s, target, d_final_score, rep);
+    }
+    const int rc = cut_by_select(ctx, n, mean, window, length, passed, s, target, d_final_score, rep);
+    if (rc == FLX_SELECT_BAND_TOO_LARGE) return cut_by_sort(ctx, n, mean, window, length, passed, s, target, d_final_score, rep);
+    return rc;
 }
 
 extern "C" int flx_rank_and_cut(flx_ctx *ctx, uint64_t n, const double *mean_q, const double *window_q,

@@ -13,11 +13,18 @@ from filtlong_amd import api
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["select", "sort"])
+def ctx(request):
+    """Both device implementations of the cut: weighted radix SELECT (default) and radix SORT + scan (FLX_RANK_SORT=1)."""
+    import os
+    if request.param == "sort":
+        os.environ["FLX_RANK_SORT"] = "1"
+    else:
+        os.environ.pop("FLX_RANK_SORT", None)
     c = api.Context(0)
     yield c
     c.close()
+    os.environ.pop("FLX_RANK_SORT", None)
 
 
 def random_reads2(n, seed, dup=0):
