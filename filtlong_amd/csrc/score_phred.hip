@@ -20,7 +20,10 @@
 
 namespace {
 
-constexpr int CH = 64;        // bytes staged per read per round
+#ifndef FLX_CH
+#define FLX_CH 64
+#endif
+constexpr int CH = FLX_CH;    // bytes staged per read per round
 constexpr int PPR = CH / 16;  // 16-byte pieces per read per round (= loads per lane per round)
 constexpr int LUT_PAD = 264;  // doubles per table in LDS (257 used)
 

@@ -19,7 +19,8 @@
 //   2. scan:          approximate running sum at every chunk start -> a GUESS of the binade of S there.
 //   3. k_chunk_maps:  one wavefront per chunk composes the integer maps of its 512 elements for the guessed
 //                     binade (ordered wave reduction).
-//   4. k_walk:        one wavefront walks the chunks in order carrying the EXACT S.  A chunk's map is used
+//   3b. k_batch_maps: the maps of 64 consecutive chunks that assume the same binade are composed once more.
+//   4. k_walk:        one wavefront walks the batches (then chunks, then elements) in order carrying the EXACT S.  A chunk's map is used
 //                     only if S really is in the guessed binade at the chunk start and stays there (checked
 //                     on the exact integers); otherwise the chunk is folded serially, element by element.
 //                     So a wrong guess costs time, never correctness.  Binade crossings (~30 per fold),
@@ -200,6 +201,41 @@ __global__ void __launch_bounds__(256) k_chunk_maps(uint64_t n, const double *x,
     }
 }
 
+// second level: one wavefront composes the maps of 64 consecutive chunks when they all assume the same binade
+__global__ void __launch_bounds__(256) k_batch_maps(const ChunkMeta *meta, uint64_t n_chunks, ChunkMeta *batch) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t c0 = b * 64;
+    if (c0 >= n_chunks) return;
+    ChunkMeta mine;
+    mine.a0 = mine.a1 = 0;
+    mine.e = NO_MAP;
+    if (c0 + lane < n_chunks) mine = meta[c0 + lane];
+    const int e0 = __builtin_amdgcn_readfirstlane(mine.e);
+    const bool full = c0 + 64 <= n_chunks;
+    Map2 m;
+    m.a0 = mine.a0;
+    m.a1 = mine.a1;
+    const bool ok = full && e0 != NO_MAP && __all(mine.e == e0);
+    if (ok) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            Map2 nb;
+            nb.a0 = __shfl_down(m.a0, o, 64);
+            nb.a1 = __shfl_down(m.a1, o, 64);
+            if ((lane & (2 * o - 1)) == 0) m = compose(m, nb);
+        }
+    }
+    if (lane == 0) {
+        ChunkMeta out;
+        out.a0 = m.a0;
+        out.a1 = m.a1;
+        out.e = ok ? e0 : NO_MAP;
+        out.pad = 0;
+        batch[b] = out;
+    }
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int src) {
     const long long b = __double_as_longlong(v);
     const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
@@ -207,69 +243,55 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// single wavefront: the exact fold
+// exact application of an integer map to the running sum: returns true and updates S iff S is in binade e and stays there
+__device__ __forceinline__ bool apply_map(double &S, int e, long long a0, long long a1) {
+    const unsigned long long sb = (unsigned long long)__double_as_longlong(S);
+    const int se = (int)((sb >> 52) & 0x7ff) - 1023;
+    if (se != e || (sb >> 63) != 0 || a0 < 0 || a1 < 0) return false;
+    const unsigned long long m = (sb & 0x000fffffffffffffull) | (1ull << 52);
+    const unsigned long long m2 = m + (unsigned long long)((m & 1) ? a1 : a0);
+    if (m2 > (1ull << 53)) return false;  // would leave the binade (reaching 2^(e+1) exactly is still on the grid)
+    if (m2 == (1ull << 53)) S = __longlong_as_double((long long)(((unsigned long long)(e + 1 + 1023)) << 52));
+    else S = __longlong_as_double((long long)((((unsigned long long)(e + 1023)) << 52) | (m2 & 0x000fffffffffffffull)));
+    return true;
+}
+
+// single wavefront: the exact fold.  Three levels: batches of 64 chunks -> chunks of 512 elements -> elements.
 template <typename F>
-__global__ void __launch_bounds__(64) k_walk(uint64_t n, const double *x, F f, const ChunkMeta *meta,
+__global__ void __launch_bounds__(64) k_walk(uint64_t n, const double *x, F f, const ChunkMeta *meta, const ChunkMeta *batch,
                                              uint64_t n_chunks, double *result, unsigned long long *serial_chunks) {
     const int lane = threadIdx.x;
     double S = 0.0;
     unsigned long long n_serial = 0;
-    for (uint64_t cb = 0; cb < n_chunks; cb += 64) {
-        ChunkMeta mine;
-        mine.a0 = mine.a1 = 0;
-        mine.e = NO_MAP;
-        if (cb + lane < n_chunks) mine = meta[cb + lane];
-        const int cnt = (int)((n_chunks - cb) < 64 ? (n_chunks - cb) : 64);
-        // Fast path for the whole batch of 64 chunks: if they all carry a map for the same binade, compose the 64
-        // maps with an ordered wave reduction and apply the result in one step (same exact checks as per chunk).
-        {
-            const int e0 = __builtin_amdgcn_readfirstlane(mine.e);
-            if (cnt == 64 && e0 != NO_MAP && __all(mine.e == e0) && S == S) {
-                Map2 m;
-                m.a0 = mine.a0;
-                m.a1 = mine.a1;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    Map2 nb;
-                    nb.a0 = __shfl_down(m.a0, o, 64);
-                    nb.a1 = __shfl_down(m.a1, o, 64);
-                    if ((lane & (2 * o - 1)) == 0) m = compose(m, nb);
-                }
-                const long long a0 = __double_as_longlong(readlane_f64(__longlong_as_double(m.a0), 0));
-                const long long a1 = __double_as_longlong(readlane_f64(__longlong_as_double(m.a1), 0));
-                const unsigned long long sb = (unsigned long long)__double_as_longlong(S);
-                const int se = (int)((sb >> 52) & 0x7ff) - 1023;
-                if (se == e0 && (sb >> 63) == 0 && a0 >= 0 && a1 >= 0) {
-                    const unsigned long long mm = (sb & 0x000fffffffffffffull) | (1ull << 52);
-                    const unsigned long long m2 = mm + (unsigned long long)((mm & 1) ? a1 : a0);
-                    if (m2 <= (1ull << 53)) {
-                        if (m2 == (1ull << 53)) S = __longlong_as_double((long long)(((unsigned long long)(e0 + 1 + 1023)) << 52));
-                        else S = __longlong_as_double((long long)((((unsigned long long)(e0 + 1023)) << 52) | (m2 & 0x000fffffffffffffull)));
-                        continue;  // next batch
-                    }
-                }
+    const uint64_t n_batches = (n_chunks + 63) / 64;
+    for (uint64_t bb = 0; bb < n_batches && S == S; bb += 64) {
+        ChunkMeta bm;
+        bm.a0 = bm.a1 = 0;
+        bm.e = NO_MAP;
+        if (bb + lane < n_batches) bm = batch[bb + lane];
+        const int bcnt = (int)((n_batches - bb) < 64 ? (n_batches - bb) : 64);
+        for (int kb = 0; kb < bcnt && S == S; ++kb) {  // NaN is absorbing
+            const int be = __builtin_amdgcn_readlane(bm.e, kb);
+            if (be != NO_MAP) {
+                const long long a0 = __double_as_longlong(readlane_f64(__longlong_as_double(bm.a0), kb));
+                const long long a1 = __double_as_longlong(readlane_f64(__longlong_as_double(bm.a1), kb));
+                if (apply_map(S, be, a0, a1)) continue;
             }
-        }
-        for (int k = 0; k < cnt; ++k) {
-            if (S != S) break;  // NaN is absorbing
-            const int e = __builtin_amdgcn_readlane(mine.e, k);
-            bool done = false;
-            if (e != NO_MAP) {
-                const unsigned long long sb = (unsigned long long)__double_as_longlong(S);
-                const int se = (int)((sb >> 52) & 0x7ff) - 1023;
-                if (se == e && (sb >> 63) == 0) {
-                    const unsigned long long m = (sb & 0x000fffffffffffffull) | (1ull << 52);
+            // the batch map does not apply: walk its chunks
+            const uint64_t cb = (bb + kb) * 64;
+            ChunkMeta mine;
+            mine.a0 = mine.a1 = 0;
+            mine.e = NO_MAP;
+            if (cb + lane < n_chunks) mine = meta[cb + lane];
+            const int cnt = (int)((n_chunks - cb) < 64 ? (n_chunks - cb) : 64);
+            for (int k = 0; k < cnt && S == S; ++k) {
+                const int e = __builtin_amdgcn_readlane(mine.e, k);
+                if (e != NO_MAP) {
                     const long long a0 = __double_as_longlong(readlane_f64(__longlong_as_double(mine.a0), k));
                     const long long a1 = __double_as_longlong(readlane_f64(__longlong_as_double(mine.a1), k));
-                    const unsigned long long m2 = m + (unsigned long long)((m & 1) ? a1 : a0);
-                    if (m2 <= (1ull << 53)) {  // never left the binade (reaching 2^(e+1) exactly is still on the grid)
-                        if (m2 == (1ull << 53)) S = __longlong_as_double((long long)(((unsigned long long)(e + 1 + 1023)) << 52));
-                        else S = __longlong_as_double((long long)((((unsigned long long)(e + 1023)) << 52) | (m2 & 0x000fffffffffffffull)));
-                        done = true;
-                    }
+                    if (apply_map(S, e, a0, a1)) continue;
                 }
-            }
-            if (!done) {  // serial, element by element, exactly like the reference loop
+                // serial, element by element, exactly like the reference loop
                 ++n_serial;
                 const uint64_t base = (cb + k) * CHUNK;
                 double v[PER_LANE];
@@ -286,7 +308,6 @@ __global__ void __launch_bounds__(64) k_walk(uint64_t n, const double *x, F f, c
                 }
             }
         }
-        if (S != S) break;
     }
     if (lane == 0) {
         result[0] = S;
@@ -302,7 +323,9 @@ int exact_fold(flx_ctx *ctx, uint64_t n, const double *x, F f, char *ws, double 
     double *chunk_start = chunk_sum + n_chunks;
     double *minmax = chunk_start + n_chunks;
     ChunkMeta *meta = (ChunkMeta *)(minmax + 2 * n_chunks);
-    unsigned char *clean = (unsigned char *)(meta + n_chunks);
+    const uint64_t n_batches = (n_chunks + 63) / 64;
+    ChunkMeta *batch = meta + n_chunks;
+    unsigned char *clean = (unsigned char *)(batch + n_batches);
     char *scan_ws = (char *)(((uintptr_t)(clean + n_chunks) + 255) & ~(uintptr_t)255);
     hipStream_t st = ctx->stream;
     const unsigned nb = (unsigned)((n_chunks + 3) / 4);
@@ -312,7 +335,8 @@ int exact_fold(flx_ctx *ctx, uint64_t n, const double *x, F f, char *ws, double 
     FLX_HIP(ctx, hipMemcpyAsync(chunk_start, chunk_sum, n_chunks * 8, hipMemcpyDeviceToDevice, st));
     FLX_CHECK(flx_exclusive_scan_f64_approx(ctx, n_chunks, chunk_start, scan_ws));
     hipLaunchKernelGGL(k_chunk_maps<F>, dim3(nb), dim3(256), 0, st, n, x, f, chunk_start, chunk_sum, clean, meta);
-    hipLaunchKernelGGL(k_walk<F>, dim3(1), dim3(64), 0, st, n, x, f, meta, n_chunks, d_result, d_serial);
+    hipLaunchKernelGGL(k_batch_maps, dim3((unsigned)((n_batches + 3) / 4)), dim3(256), 0, st, meta, n_chunks, batch);
+    hipLaunchKernelGGL(k_walk<F>, dim3(1), dim3(64), 0, st, n, x, f, meta, batch, n_chunks, d_result, d_serial);
     FLX_HIP(ctx, hipGetLastError());
     return FLX_OK;
 }
@@ -327,7 +351,7 @@ int flx_exact_stats(flx_ctx *ctx, uint64_t n, const double *d_mean_q, flx_stats 
         return FLX_OK;
     }
     const uint64_t n_chunks = (n + CHUNK - 1) / CHUNK;
-    const size_t bytes = n_chunks * (8 + 8 + 16 + sizeof(ChunkMeta) + 1) + 512 + (n_chunks / 2048 + 4096) * 8 * 2 + 4096;
+    const size_t bytes = n_chunks * (8 + 8 + 16 + sizeof(ChunkMeta) + 1) + (n_chunks / 64 + 2) * sizeof(ChunkMeta) + 512 + (n_chunks / 2048 + 4096) * 8 * 2 + 4096;
     void *scr;
     FLX_CHECK(flx_scratch(ctx, bytes, &scr));
     char *ws = (char *)scr;
