@@ -16,6 +16,8 @@ __global__ void k(const double* tab_g, int iters, double* out) {
 #pragma unroll
     for (int i = 0; i < N; ++i) { x = x * 1664525u + 1013904223u; idx[i] = ((x >> 9) & 31) + 33; }
     unsigned long long acc = 0;
+    const unsigned tabreg = (unsigned)__double_as_longlong(tab_g[threadIdx.x & 63]);
+    const unsigned tabreg2 = (unsigned)(__double_as_longlong(tab_g[threadIdx.x & 63]) >> 32);
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -26,6 +28,8 @@ __global__ void k(const double* tab_g, int iters, double* out) {
             else if (MODE == 4) { const ulonglong2 v = ((const ulonglong2*)q)[idx[i]]; acc ^= v.x ^ v.y; }
             else if (MODE == 5) acc ^= ((const uint32_t*)tab_g)[idx[i]];
             else if (MODE == 6) acc ^= __double_as_longlong(tab_g[idx[i]]);
+            else if (MODE == 8) { acc ^= (unsigned)__builtin_amdgcn_ds_bpermute((int)(idx[i] & 63) << 2, (int)tabreg); }
+            else if (MODE == 9) { acc ^= (unsigned)__builtin_amdgcn_ds_bpermute((int)(idx[i] & 63) << 2, (int)tabreg) ^ ((unsigned long long)(unsigned)__builtin_amdgcn_ds_bpermute((int)(idx[i] & 63) << 2, (int)tabreg2) << 32); }
             else { acc ^= __double_as_longlong(q[idx[i]]) ^ __double_as_longlong(q[idx[i] + 264]) ^ __double_as_longlong(tab_g[idx[(i + 1) % N]]); }
         }
 #pragma unroll
@@ -65,6 +69,8 @@ int main() {
         run<5>(tab, wpb, bpc, out, "L1 b32", 1);
         run<6>(tab, wpb, bpc, out, "L1 b64", 1);
         run<7>(tab, wpb, bpc, out, "2x lds b64 + 1x L1 b64", 3);
+        run<8>(tab, wpb, bpc, out, "ds_bpermute_b32", 1);
+        run<9>(tab, wpb, bpc, out, "2x ds_bpermute_b32 (64-bit)", 2);
     }
     return 0;
 }
