@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
                                                               uint32_t *cov, const uint64_t *cov_off, int32_t *count,
                                                               int32_t *first, int32_t *last) {
     __shared__ uint32_t sh_hits[COVER_THREADS];
+    __shared__ uint8_t sh_anchor[COVER_THREADS];
     __shared__ uint32_t sh_carry;
     __shared__ int sh_cnt[COVER_THREADS / 64], sh_first[COVER_THREADS / 64], sh_last[COVER_THREADS / 64];
     for (uint64_t slot = blockIdx.x; slot < n_reads; slot += gridDim.x) {
@@ -61,6 +62,8 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
         for (int sp = n_spans - 1; sp >= 0; --sp) {  // descending: the right neighbour's hits are already known
             const int p0 = sp * COVER_SPAN + t * 16;
             uint32_t hits = 0;
+            uint32_t kmers[16];
+            bool anchor_hit = false;
             if (p0 < L && L >= 16) {
                 // bases [p0-16, p0+16): both loads are 16-byte aligned (read starts are)
                 uint4 a = make_uint4(0, 0, 0, 0);
@@ -70,20 +73,37 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
                 uint32_t k = 0;
 #pragma unroll
                 for (int j = 1; j < 16; ++j) k = (k << 2) | code_fwd((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
-                uint32_t kmers[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     k = (k << 2) | code_fwd((w[4 + (j >> 2)] >> (8 * (j & 3))) & 0xffu);
                     kmers[j] = k;  // 16-mer ending at position p0 + j
                 }
-                uint32_t words[16];
+                // Anchor first: the 16-mer ending at p0+15 spans exactly this thread's 16 bases, so if it is present they
+                // are all covered and the other 15 lookups of the block cannot change them.  Those 15 are needed only
+                // when this anchor misses (own bases) or the LEFT neighbour's anchor misses (its bases reach up to
+                // p0-1 and can be covered by 16-mers ending at p0 .. p0+14).  Every hit that can influence a coverage
+                // bit is still evaluated, so the result is identical; on clean reads it is 1 lookup per 16 bases
+                // instead of 16 — the bitmap lookups are bound by the fabric's random-request rate.
+                const int ia = p0 + 15;
+                const bool a_valid = ia < L;
+                const bool a_hit = a_valid && ((bitmap[kmers[15] >> 5] >> (kmers[15] & 31)) & 1u);
+                anchor_hit = a_hit;
+                if (a_hit) hits = 1u << 15;
+            }
+            sh_anchor[t] = anchor_hit ? 1 : 0;
+            __syncthreads();
+            if (p0 < L && L >= 16) {
+                const bool left_hit = (t > 0) ? (sh_anchor[t - 1] != 0) : false;  // first thread of a span: assume a miss
+                if (!anchor_hit || !left_hit) {
+                    uint32_t words[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) words[j] = bitmap[kmers[j] >> 5];  // 16 independent lookups in flight
+                    for (int j = 0; j < 15; ++j) words[j] = bitmap[kmers[j] >> 5];  // 15 independent lookups in flight
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int i = p0 + j;
-                    const bool valid = i >= 15 && i < L;
-                    if (valid && ((words[j] >> (kmers[j] & 31)) & 1u)) hits |= 1u << j;
+                    for (int j = 0; j < 15; ++j) {
+                        const int i = p0 + j;
+                        const bool valid = i >= 15 && i < L;
+                        if (valid && ((words[j] >> (kmers[j] & 31)) & 1u)) hits |= 1u << j;
+                    }
                 }
             }
             sh_hits[t] = hits;
