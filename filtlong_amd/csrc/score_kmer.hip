@@ -255,12 +255,55 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
         ++nchild;
     };
 
-    // trailing stream: word index / bit offset of position (j - ws), advanced in lock step with j
-    uint32_t lead_w = 0, trail_w = 0;
-    for (int j = 0; j < Lmax; ++j) {
-        if ((j & 31) == 0) lead_w = (j < L) ? row[j >> 5] : 0u;
+    // Two word streams over the read's coverage row — the leading edge (position j) and the trailing edge (position
+    // j - ws) — each kept two 32-bit words ahead so the (uncoalesced, one row per lane) loads overlap the serial math.
+    const int n_words = (L + 31) >> 5;
+    auto ld = [&](int wi) -> uint32_t { return (wi < n_words) ? row[wi] : 0u; };
+    uint32_t lead_w = ld(0), lead_n1 = ld(1), lead_n2 = ld(2);
+    uint32_t trail_w = ld(0), trail_n1 = ld(1), trail_n2 = ld(2);
+    int Lmin = live ? L : 0x7fffffff;
+    for (int o = 32; o > 0; o >>= 1) Lmin = min(Lmin, __shfl_xor(Lmin, o, 64));
+    const unsigned int d_lo = (unsigned int)(__double_as_longlong(delta) & 0xffffffffll);
+    const unsigned int d_hi = (unsigned int)(__double_as_longlong(delta) >> 32);
+    for (int j0 = 0; j0 < Lmax; j0 += 32) {
+      if (j0 > 0) {
+          lead_w = lead_n1;
+          lead_n1 = lead_n2;
+          lead_n2 = ld((j0 >> 5) + 2);
+      }
+      if (MODE == 0 && j0 >= ws && j0 + 32 <= Lmin) {
+          // ---- steady state, parent only: 32 positions, every lane active, no per-bit control flow ----
+          const int tj0 = j0 - ws, sh = tj0 & 31;
+          uint32_t tw;
+          if (sh == 0) {
+              if (tj0 > 0) { trail_w = trail_n1; trail_n1 = trail_n2; trail_n2 = ld((tj0 >> 5) + 2); }
+              tw = trail_w;
+          } else {
+              tw = __builtin_amdgcn_alignbit(trail_n1, trail_w, (unsigned)sh);
+              trail_w = trail_n1; trail_n1 = trail_n2; trail_n2 = ld((tj0 >> 5) + 3);
+          }
+          P.cnt += __popc(lead_w);
+#pragma unroll
+          for (int i = 0; i < 32; ++i) {
+              const int ml = __builtin_amdgcn_sbfe((int)lead_w, i, 1);  // 0 or -1
+              const int mt = __builtin_amdgcn_sbfe((int)tw, i, 1);
+              const double dl = __hiloint2double((int)(d_hi & (unsigned)ml), (int)(d_lo & (unsigned)ml));
+              const double dt = __hiloint2double((int)(d_hi & (unsigned)mt), (int)(d_lo & (unsigned)mt));
+              P.w -= dt;
+              P.w += dl;
+              P.mn = fmin(P.mn, P.w);
+          }
+          continue;
+      }
+      for (int jj = 0; jj < 32; ++jj) {
+        const int j = j0 + jj;
+        if (j >= Lmax) break;
         const int tj = j - ws;
-        if (tj >= 0 && ((tj & 31) == 0 || j == ws)) trail_w = (tj < L) ? row[tj >> 5] : 0u;
+        if (tj > 0 && (tj & 31) == 0) {
+            trail_w = trail_n1;
+            trail_n1 = trail_n2;
+            trail_n2 = ld((tj >> 5) + 2);
+        }
         const bool act = j < L;
         const uint32_t b = act ? ((lead_w >> (j & 31)) & 1u) : 0u;
         const uint32_t tb = (act && tj >= 0) ? ((trail_w >> (tj & 31)) & 1u) : 0u;
@@ -308,6 +351,7 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
                 }
             }
         }
+      }
     }
     if (!live) return;
 
