@@ -13,6 +13,8 @@
 
 #include <algorithm>
 #include <climits>
+#include <deque>
+#include <string_view>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -246,13 +248,47 @@ static ParsingResult parse_args(int argc, char **argv, Args &a) {
 // '@'; the name ends at the first whitespace, the rest of the header line is the comment; sequence lines run until a
 // line whose first character is '>', '+' or '@'; after '+' the quality is read line by line until it is at least as
 // long as the sequence; a trailing '\r' is dropped from every line; empty lines are skipped.
+struct View {  // a piece of the input buffer (or of the side arena for multi-line records); never owns memory
+    const char *p = nullptr;
+    size_t n = 0;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    std::string str() const { return std::string(p ? p : "", n); }
+    std::string_view sv() const { return std::string_view(p ? p : "", n); }
+};
+static std::ostream &operator<<(std::ostream &os, const View &v) { return os.write(v.p ? v.p : "", (std::streamsize)v.n); }
+
 struct Record {
-    std::string name, comment;
-    std::string seq, qual;
+    View name, comment, seq, qual;
     bool is_fastq = false;
 };
 
+// Whole file into memory.  Plain files are read directly (page cache speed); gzip goes through zlib.
 static bool slurp(const std::string &path, std::string &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    unsigned char magic[2] = {0, 0};
+    const size_t got = fread(magic, 1, 2, f);
+    const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    if (!gz) {
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        if (sz > 0) {
+            out.resize((size_t)sz);
+            size_t at = 0;
+            while (at < (size_t)sz) {
+                const size_t r = fread(&out[at], 1, (size_t)sz - at, f);
+                if (r == 0) break;
+                at += r;
+            }
+            out.resize(at);
+            fclose(f);
+            return true;
+        }
+        // size unknown (pipe / special file): fall through to the streaming reader
+    }
+    fclose(f);
     gzFile fp = gzopen(path.c_str(), "r");
     if (!fp) return false;
     gzbuffer(fp, 1 << 20);
@@ -267,25 +303,46 @@ static bool slurp(const std::string &path, std::string &out) {
     return true;
 }
 
+// Record views point into the buffer; only multi-line sequences / qualities are copied (into `arena`).
 struct Parser {
     const std::string &d;
+    std::deque<std::string> &arena;
     size_t pos = 0;
     int last_char = 0;
-    explicit Parser(const std::string &data) : d(data) {}
+    Parser(const std::string &data, std::deque<std::string> &side) : d(data), arena(side) {}
     int getc() { return pos < d.size() ? (unsigned char)d[pos++] : -1; }
-    // appends the rest of the current line (without '\n', trailing '\r' dropped when the line has > 1 chars so far)
-    // returns false if nothing at all could be read (EOF)
-    bool get_line(std::string &s, bool append) {
-        if (!append) s.clear();
-        if (pos >= d.size()) return false;
-        const size_t nl = d.find('\n', pos);
-        const size_t end = nl == std::string::npos ? d.size() : nl;
-        s.append(d, pos, end - pos);
-        pos = nl == std::string::npos ? d.size() : nl + 1;
-        if (s.size() > 1 && s.back() == '\r') s.pop_back();
+    // rest of the current line as a view [from, end-of-line), consuming the newline; false at EOF
+    bool rest_of_line(size_t from, View &v) {
+        if (from > d.size()) return false;
+        const void *nlp = pos < d.size() ? memchr(d.data() + pos, '\n', d.size() - pos) : nullptr;
+        const size_t end = nlp ? (size_t)((const char *)nlp - d.data()) : d.size();
+        v.p = d.data() + from;
+        v.n = end - from;
+        pos = nlp ? end + 1 : d.size();
         return true;
     }
-    // returns length >= 0, -1 at EOF, -2 on truncated / mismatching quality
+    // kseq's ks_getuntil2(KS_SEP_LINE, append): append the rest of the line to the accumulating field `v`
+    // (first line: a view; later lines: copied into the arena); a trailing '\r' is dropped when the field has > 1 chars
+    void append_line(View &v, bool &owned, size_t first_from) {
+        View line;
+        if (v.n == 0 && !owned) {
+            rest_of_line(first_from, v);
+        } else {
+            if (!owned) {
+                arena.emplace_back(v.p, v.n);
+                owned = true;
+            }
+            rest_of_line(first_from, line);
+            arena.back().append(line.p, line.n);
+            v.p = arena.back().data();
+            v.n = arena.back().size();
+        }
+        if (v.n > 1 && v.p[v.n - 1] == '\r') {
+            --v.n;
+            if (owned) arena.back().pop_back();
+        }
+    }
+    // returns length >= 0, -1 at EOF, -2 on truncated / mismatching quality   (src/kseq.h:176-224)
     long long next(Record &r) {
         int c;
         if (last_char == 0) {
@@ -293,26 +350,33 @@ struct Parser {
             if (c < 0) return -1;
             last_char = c;
         }
-        r.comment.clear(); r.seq.clear(); r.qual.clear(); r.name.clear();
-        // name: up to the first whitespace
+        r = Record();
         if (pos >= d.size()) return -1;
         size_t e = pos;
-        while (e < d.size() && !isspace((unsigned char)d[e])) ++e;
-        r.name.assign(d, pos, e - pos);
+        while (e < d.size() && !isspace((unsigned char)d[e])) ++e;  // the name ends at the first whitespace
+        r.name.p = d.data() + pos;
+        r.name.n = e - pos;
         c = e < d.size() ? (unsigned char)d[e] : -1;
         pos = e < d.size() ? e + 1 : e;
-        if (c != '\n' && c >= 0) get_line(r.comment, false);
+        if (c != '\n' && c >= 0) {
+            rest_of_line(pos, r.comment);
+            if (r.comment.n > 1 && r.comment.p[r.comment.n - 1] == '\r') --r.comment.n;
+        }
+        bool seq_owned = false, qual_owned = false;
         while ((c = getc()) >= 0 && c != '>' && c != '+' && c != '@') {
             if (c == '\n') continue;
-            r.seq.push_back((char)c);
-            get_line(r.seq, true);
+            append_line(r.seq, seq_owned, pos - 1);  // the line starts at the character just consumed
         }
         if (c == '>' || c == '@') last_char = c;
         r.is_fastq = (c == '+');
         if (!r.is_fastq) { if (c < 0) last_char = 0; return (long long)r.seq.size(); }
         while ((c = getc()) >= 0 && c != '\n') {}
         if (c == -1) return -2;
-        while (get_line(r.qual, true) && r.qual.size() < r.seq.size()) {}
+        for (;;) {
+            if (pos >= d.size()) break;
+            append_line(r.qual, qual_owned, pos);
+            if (r.qual.size() >= r.seq.size()) break;
+        }
         last_char = 0;
         if (r.seq.size() != r.qual.size()) return -2;
         return (long long)r.seq.size();
@@ -320,6 +384,17 @@ struct Parser {
 };
 
 // ------------------------------------------------------------------------------------------------ helpers
+#include <chrono>
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static bool g_timing = false;
+static double g_t0 = 0;
+static void stage(const char *what) {  // FLX_CLI_TIMING=1: per-stage wall clock on stderr (not part of the reference surface)
+    if (!g_timing) return;
+    const double t = now_s();
+    fprintf(stderr, "[timing] %-28s %8.3f s\n", what, t - g_t0);
+    g_t0 = t;
+}
+
 static int fail_flx(flx_ctx *ctx, const char *what) {
     std::cerr << "Error: " << what << ": " << flx_last_error(ctx) << "\n";
     return 1;
@@ -334,15 +409,16 @@ static int load_reference(const std::string &filename, std::vector<std::string> 
     std::string data;
     int n = 0;
     long long bases = 0;
+    std::deque<std::string> arena;
     if (slurp(filename, data)) {
-        Parser p(data);
+        Parser p(data, arena);
         Record r;
         long long l;
         while ((l = p.next(r)) >= 0) {  // errors end the loop silently, like src/kmers.cpp:91-94
             ++n;
             if (r.seq.size() < 16) continue;
             bases += (long long)r.seq.size();
-            seqs.push_back(r.seq);
+            seqs.push_back(r.seq.str());
         }
     }
     print_hash_progress(filename, bases);
@@ -374,6 +450,8 @@ int main(int argc, char **argv) {
     if (pr == VERSION) { std::cout << "Filtlong v" << PROGRAM_VERSION << "\n"; return 0; }
 
     std::cerr << "\n";
+    g_timing = getenv("FLX_CLI_TIMING") != nullptr;
+    g_t0 = now_s();
     flx_ctx *ctx = nullptr;
     {
         const char *dev = getenv("FLX_DEVICE");
@@ -383,6 +461,7 @@ int main(int argc, char **argv) {
         }
     }
 
+    stage("context");
     // ---- reference 16-mers (src/main.cpp:51-59, src/kmers.cpp:50-72) --------------------------------------
     flx_kmerset *kmers = nullptr;
     bool kmers_empty = true;
@@ -422,17 +501,20 @@ int main(int argc, char **argv) {
         kmers_empty = flx_kmerset_size(kmers) == 0;
     }
 
+    stage("reference 16-mers");
     // ---- pass 1: parse, checks (src/main.cpp:63-130) -----------------------------------------------------
     if (!args.verbose) std::cerr << "Scoring long reads\n";
     std::string data;
     if (!slurp(args.input_reads, data)) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
+    stage("read input file");
     std::vector<Record> recs;
     long long total_bases = 0, last_progress = 0;
     bool any_fasta = false, any_fastq = false;
+    std::deque<std::string> arena;  // multi-line records only
     {
-        Parser p(data);
+        Parser p(data, arena);
         Record r;
-        std::unordered_set<std::string> names;
+        std::unordered_set<std::string_view> names;
         for (;;) {
             const long long l = p.next(r);
             if (l == -1) break;
@@ -451,7 +533,7 @@ int main(int argc, char **argv) {
                 std::cerr << "\n\n" << "Error: FASTA input not supported without an external reference" << "\n";
                 return 1;
             }
-            if (!names.insert(r.name).second) { std::cerr << "Error: duplicate read name: " << r.name << "\n"; return 1; }
+            if (!names.insert(r.name.sv()).second) { std::cerr << "Error: duplicate read name: " << r.name << "\n"; return 1; }
             recs.push_back(r);
             if (total_bases - last_progress >= 483611) {
                 last_progress = total_bases;
@@ -459,12 +541,11 @@ int main(int argc, char **argv) {
             }
         }
     }
-    data.clear();
-    data.shrink_to_fit();
     if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)recs.size()) << " reads (" << int_to_string(total_bases) << " bp)";
     std::cerr << "\n";
     const bool fasta_output = any_fasta, fastq_output = any_fastq;
 
+    stage("parse");
     // ---- pack and score (replaces one Read::Read per record, src/main.cpp:108) ---------------------------
     const uint64_t n = recs.size();
     std::vector<int32_t> lengths(n);
@@ -474,12 +555,13 @@ int main(int argc, char **argv) {
     flx_plane_layout(lengths.data(), n, offsets.data(), &plane_bytes);
     std::vector<uint8_t> plane(plane_bytes, 0);
     for (uint64_t i = 0; i < n; ++i) {
-        const std::string &src = kmers_empty ? recs[i].qual : recs[i].seq;  // Phred mode reads qual, k-mer mode reads seq
-        if (!src.empty()) memcpy(plane.data() + offsets[i], src.data(), src.size());
+        const View &src = kmers_empty ? recs[i].qual : recs[i].seq;  // Phred mode reads qual, k-mer mode reads seq
+        if (!src.empty()) memcpy(plane.data() + offsets[i], src.p, src.size());
     }
     std::vector<uint32_t> order(n ? n : 1);
     flx_length_order(lengths.data(), n, order.data());
 
+    stage("pack + order");
     flx_params prm;
     memset(&prm, 0, sizeof prm);
     prm.window_size = (int32_t)args.window_size;
@@ -512,6 +594,7 @@ int main(int argc, char **argv) {
     }
     (void)n_children;
 
+    stage("score (H2D + kernels + D2H)");
     // ---- reads2: children replace their parents in place (src/main.cpp:138-147) -----------------------------
     struct Out { uint64_t rec; int start, end; bool child; std::string name; };
     std::vector<Out> reads2;
@@ -521,12 +604,12 @@ int main(int argc, char **argv) {
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t a = child_off[i], b = child_off[i + 1];
         if (a == b) {
-            reads2.push_back({i, 0, lengths[i], false, recs[i].name});
+            reads2.push_back({i, 0, lengths[i], false, recs[i].name.str()});
             r2_mean.push_back(mean_q[i]); r2_window.push_back(window_q[i]); r2_len.push_back(lengths[i]); r2_pass.push_back(passed[i]);
         } else {
             for (uint64_t k = a; k < b; ++k) {
                 const int s = c_ranges[2 * k], e = c_ranges[2 * k + 1];
-                reads2.push_back({i, s, e, true, recs[i].name + "_" + std::to_string(s + 1) + "-" + std::to_string(e)});  // read.cpp:135-136
+                reads2.push_back({i, s, e, true, recs[i].name.str() + "_" + std::to_string(s + 1) + "-" + std::to_string(e)});  // read.cpp:135-136
                 r2_mean.push_back(c_mean[k]); r2_window.push_back(c_window[k]); r2_len.push_back(e - s); r2_pass.push_back(c_passed[k]);
             }
         }
@@ -599,6 +682,7 @@ int main(int argc, char **argv) {
         std::cerr << "\n";
     }
 
+    stage("rank and cut");
     // ---- output in input order (src/main.cpp:263-313) -----------------------------------------------------
     std::cerr << "Outputting passed long reads\n";
     std::string out;
@@ -610,19 +694,20 @@ int main(int argc, char **argv) {
         if (o.child && o.end - o.start <= 0) continue;
         out += fasta_output ? '>' : '@';
         out += o.name;
-        if (!r.comment.empty()) { out += ' '; out += r.comment; }
+        if (!r.comment.empty()) { out += ' '; out.append(r.comment.p, r.comment.n); }
         out += '\n';
-        out.append(r.seq, (size_t)o.start, (size_t)(o.end - o.start));
+        out.append(r.seq.p + o.start, (size_t)(o.end - o.start));
         out += '\n';
         if (fastq_output) {
             out += "+\n";
-            out.append(r.qual, (size_t)o.start, (size_t)(o.end - o.start));
+            out.append(r.qual.p + o.start, (size_t)(o.end - o.start));
             out += '\n';
         }
         if (out.size() > (1u << 24)) { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
     }
     fwrite(out.data(), 1, out.size(), stdout);
     fflush(stdout);
+    stage("output");
 
     if (kmers) flx_kmerset_destroy(kmers);
     flx_ctx_destroy(ctx);

@@ -207,3 +207,20 @@ def bloom_fp_case():
     file1 += [kmer_to_seq(target), kmer_to_seq(control)]      # 1st sighting of both
     file2 = [kmer_to_seq(target), kmer_to_seq(control)] * 2   # 2nd and 3rd sightings
     return file1, file2, target, control
+
+
+def odd_fastq_bytes(reads, width=61):
+    """The same records in the formats klib's kseq tolerates (reference src/kseq.h:176-224): sequences and qualities
+    wrapped over several lines, CRLF line ends on some records, blank lines between records, tabs before comments."""
+    out = bytearray()
+    for i, (name, s, q) in enumerate(reads):
+        nl = b"\r\n" if i % 2 else b"\n"
+        out += b"@" + name.encode() + (b"\tcomment with spaces" if i % 3 == 0 else b"") + nl
+        for j in range(0, len(s), width):
+            out += s[j:j + width] + nl
+        out += b"+" + (name.encode() if i % 4 == 1 else b"") + nl
+        for j in range(0, len(q), width + 7):
+            out += q[j:j + width + 7] + nl
+        if i % 5 == 2:
+            out += b"\n"
+    return bytes(out)

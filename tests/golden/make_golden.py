@@ -178,6 +178,10 @@ def main():
             e2e["synth_phred|t%.2f" % frac] = e2e_case(pin, ["--target_bases", str(int(tot * frac))], td)
         for kp in (10, 50, 90):
             e2e["synth_phred|p%d" % kp] = e2e_case(pin, ["--keep_percent", str(kp), "--min_length", "300"], td)
+        oin = os.path.join(td, "odd.fastq")  # multi-line records, CRLF, blank lines (kseq grammar)
+        with open(oin, "wb") as f:
+            f.write(_cases.odd_fastq_bytes(preads))
+        e2e["odd_format|t0.50"] = e2e_case(oin, ["--target_bases", str(tot // 2)], td)
         e2e["synth_phred|weights"] = e2e_case(pin, ["--keep_percent", "60", "--length_weight", "2.5",
                                                     "--mean_q_weight", "0.5", "--window_q_weight", "3"], td)
         e2e["synth_phred|cutoffs"] = e2e_case(pin, ["--min_mean_q", "90", "--min_window_q", "80", "--max_length",

@@ -39,6 +39,7 @@ def test_cli_matches_reference_binary_byte_for_byte():
         p2 = w("sr_2.fastq", _cases.fastq_bytes(inp.sr[1]))
         c1 = w("c1.fastq", _cases.c1_fastq_bytes())
         pin = w("synth_phred.fastq", _cases.long_fastq_bytes(inp.preads))
+        oin = w("odd.fastq", _cases.odd_fastq_bytes(inp.preads))
         kin = w("synth_kmer.fastq", _cases.long_fastq_bytes(inp.kreads))
         n = 0
         for key, g in sorted(gold.items()):
@@ -54,6 +55,8 @@ def test_cli_matches_reference_binary_byte_for_byte():
                     args[i + 1] = os.path.join(FIX, "test_reference_2.fastq.gz") if parts[0] in ("sort", "trim", "split") else p2
             if key == "bad_fastq":
                 inpath = os.path.join(FIX, "test_bad_fastq.fastq")
+            elif parts[0] == "odd_format":
+                inpath = oin  # multi-line FASTQ, CRLF, blank lines: the kseq record grammar (src/kseq.h:176-224)
             elif parts[0] == "c1":
                 inpath = c1  # BASELINE.json configs[0]: 10k reads x 5 kbp --min_length 1000 --keep_percent 90
             elif parts[0] in ("sort", "trim", "split"):
