@@ -6,6 +6,7 @@ reference: ``Kmers`` (src/kmers.h:28-56), per-read scoring = the batched ``Read:
 All compute happens in the HIP library; there is no CPU fallback here.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -69,9 +70,15 @@ class Context:
         if rc:
             raise FlxError(rc, self.L.flx_last_error(None).decode())
         self.h = h
+        self._sets = []  # weak references to the Kmers created on this context (destroyed before the context)
 
     def close(self):
         if self.h:
+            for ref in self._sets:
+                ks = ref()
+                if ks is not None:
+                    ks.close()
+            self._sets = []
             self.L.flx_ctx_destroy(self.h)
             self.h = None
 
@@ -217,6 +224,7 @@ class Kmers:
         ctx._check(ctx.L.flx_kmerset_create(ctx.h, C.byref(h)))
         self.h = h
         self._final = False
+        ctx._sets.append(weakref.ref(self))
 
     def _add(self, fn, seqs):
         seqs = [bytes(s) for s in seqs]
@@ -255,7 +263,8 @@ class Kmers:
 
     def close(self):
         if self.h:
-            self.ctx.L.flx_kmerset_destroy(self.h)
+            if self.ctx.h:  # a set never outlives its context (Context.close() closes its sets first)
+                self.ctx.L.flx_kmerset_destroy(self.h)
             self.h = None
 
     def __del__(self):

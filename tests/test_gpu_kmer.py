@@ -186,3 +186,33 @@ def test_bloom_false_positive_rule(be):
     # same reads, but the target's first sighting comes BEFORE the helpers: no false positive, empty set
     ks2 = be.kmers(short_files=[[_cases.kmer_to_seq(target)] + f1[:13], f2[:1] + f2[2:3]])
     assert len(ks2) == 0 and not ks2.is_kmer_present(np.array([target], dtype=np.uint32))[0]
+
+
+def test_long_reads_vs_oracle(be, synth):
+    """Reads far longer than one coverage span (4096 positions) and than the window: 30-120 kbp reads stitched from the
+    reference with substitutions and junk, plain and with --trim --split."""
+    from filtlong_amd import synth as S
+    rng = np.random.RandomState(3)
+    ref = np.frombuffer(b"".join(synth["contigs"]), dtype=np.uint8)
+    reads = []
+    for i, L in enumerate([30000, 65536, 65537, 100001, 120000, 4096, 4097, 8192]):
+        r = np.concatenate([ref, ref, ref])[:L].copy() if L > len(ref) else ref[:L].copy()
+        if L > len(ref):  # tile the reference to reach the length
+            r = np.resize(ref, L).copy()
+        sub = rng.random_sample(L) < 0.03
+        r[sub] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.randint(0, 4, int(sub.sum()))]
+        for _ in range(3):
+            js = int(rng.randint(0, L - 900)); jl = int(rng.randint(20, 900))
+            r[js:js + jl] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.randint(0, 4, jl)]
+        reads.append(("long%d" % i, r.tobytes(), S.qual_read(i, L).tobytes()))
+    orc = _oracle.KmerSet(); orc.add_assembly(synth["contigs"])
+    for pkw in (dict(), dict(trim=True, split=300), dict(split=64, window_size=1000)):
+        got = be.score(reads, pkw, synth["asm"])
+        p = _oracle.make_params(**pkw)
+        for (name, s, q), o in zip(reads, got):
+            w = _oracle.score_read(s, q, p, orc, cap=65536)
+            assert w["mean_q"] == o["mean_q"] and w["window_q"] == o["window_q"], (name, pkw)
+            assert (w["first"], w["last"], w["passed"]) == (o["first"], o["last"], o["passed"])
+            assert w["child_ranges"] == o["child_ranges"], (name, pkw)
+            for wc, oc in zip(w["children"], o["children"]):
+                assert wc["mean_q"] == oc["mean_q"] and wc["window_q"] == oc["window_q"] and wc["passed"] == oc["passed"]

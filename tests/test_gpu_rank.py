@@ -147,3 +147,33 @@ def test_exact_serial_statistics_hard_cases(ctx):
     nan_case = rng.uniform(0, 100, 5000); nan_case[1234] = np.nan
     got = ctx.rank_and_cut(nan_case, nan_case, np.full(5000, 100, np.int32), np.ones(5000, np.uint8))["report"]
     assert np.isnan(got.mean_quality) and np.isnan(got.stdev_quality)
+
+
+def test_empty_and_single(ctx):
+    e = np.zeros(0)
+    got = ctx.rank_and_cut(e, e, np.zeros(0, np.int32), np.zeros(0, np.uint8), target_bases=100, total_bases=0)
+    assert len(got["passed"]) == 0 and got["report"].outcome == 1   # target >= total_bases: "not enough reads"
+    compare(ctx, np.array([88.0]), np.array([80.0]), np.array([5000], np.int32), np.array([1], np.uint8), target_bases=1)
+
+
+def test_runs_on_callers_stream():
+    """flx_ctx_set_stream: the library enqueues on the caller's HIP stream (here a torch stream); results unchanged."""
+    import torch
+    from filtlong_amd import synth
+    c = api.Context(0)
+    st = torch.cuda.Stream()
+    c.set_stream(st.cuda_stream)
+    n = 2000
+    lens = np.maximum(synth.lengths(n, first=5) // 5, 1)
+    quals = [synth.qual_read(5 + i, int(L)).tobytes() for i, L in enumerate(lens)]
+    plane, offsets, lengths = api.pack_reads(quals)
+    out = c.score_reads(plane, offsets, lengths, api.make_params(), order=api.length_order(lengths))
+    p = _oracle.make_params()
+    want = np.array([_oracle.score_read(None, q, p)["window_q"] for q in quals[:200]])
+    assert (out["window_q"][:200].view(np.uint64) == want.view(np.uint64)).all()
+    tot = int(lengths.astype(np.int64).sum())
+    got = c.rank_and_cut(out["mean_q"], out["window_q"], lengths, out["passed"], target_bases=tot // 3)
+    ref = _oracle.rank_and_cut(out["mean_q"], out["window_q"], lengths, out["passed"], target_bases=tot // 3)
+    assert (got["passed"] == ref["passed"]).all()
+    c.set_stream(None)
+    c.close()
