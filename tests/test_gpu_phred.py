@@ -110,3 +110,27 @@ def test_device_generator_matches_numpy(ctx):
         o = int(offsets[i])
         assert (got[o:o + L] == synth.qual_read(int(ids[i]), int(L))).all(), i
         assert (got[o + L:o + ((L + 15) & ~15)] == 0).all()
+
+
+def test_randomised_configurations_vs_oracle(ctx):
+    """40 random (window_size, cut-offs, batch shape) configurations: window sizes around every 16/64-byte boundary and up
+    to the ring/direct switch, batches smaller than a wave, reads shorter than the window, unsorted order."""
+    rng = np.random.RandomState(2024)
+    ws_pool = [1, 2, 15, 16, 17, 31, 32, 48, 63, 64, 65, 127, 128, 129, 192, 249, 250, 251, 255, 256, 257, 320, 511, 512,
+               1000, 1999, 2000, 2047, 2048, 2100, 3000]
+    for trial in range(40):
+        ws = int(ws_pool[rng.randint(len(ws_pool))]) if trial % 4 else int(rng.randint(1, 2600))
+        n = int(rng.choice([1, 3, 63, 64, 65, 130, 300]))
+        lens = rng.randint(0, int(rng.choice([40, 300, 3000, 9000])), n)
+        reads = [("t%d_%d" % (trial, i), b"", synth.qual_read(trial * 1000 + i, int(L), 5).tobytes()) for i, L in enumerate(lens)]
+        pkw = dict(window_size=ws)
+        if trial % 3 == 0:
+            pkw.update(min_length=int(rng.randint(1, 500)), min_window_q=float(rng.uniform(40, 95)))
+        if trial % 5 == 0:
+            pkw.update(max_length=int(rng.randint(100, 5000)), min_mean_q=float(rng.uniform(60, 95)))
+        p = _oracle.make_params(**pkw)
+        want = [_oracle.score_read(None, q, p) for _, _, q in reads]
+        o = score_hip(ctx, reads, pkw, use_order=bool(trial % 2))
+        assert_same_f64(o["mean_q"], np.array([w["mean_q"] for w in want]), "trial %d ws %d mean" % (trial, ws))
+        assert_same_f64(o["window_q"], np.array([w["window_q"] for w in want]), "trial %d ws %d window" % (trial, ws))
+        assert (o["passed"] == np.array([w["passed"] for w in want], dtype=np.uint8)).all(), (trial, pkw)
