@@ -27,8 +27,14 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/filtlong_hip.h"
 
@@ -263,54 +269,90 @@ struct Record {
     bool is_fastq = false;
 };
 
-// Whole file into memory.  Plain files are read directly (page cache speed); gzip goes through zlib.
-static bool slurp(const std::string &path, std::string &out) {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    unsigned char magic[2] = {0, 0};
-    const size_t got = fread(magic, 1, 2, f);
-    const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
-    if (!gz) {
-        fseek(f, 0, SEEK_END);
-        const long sz = ftell(f);
-        fseek(f, 0, SEEK_SET);
-        if (sz > 0) {
-            out.resize((size_t)sz);
-            size_t at = 0;
-            while (at < (size_t)sz) {
-                const size_t r = fread(&out[at], 1, (size_t)sz - at, f);
-                if (r == 0) break;
-                at += r;
-            }
-            out.resize(at);
-            fclose(f);
-            return true;
-        }
-        // size unknown (pipe / special file): fall through to the streaming reader
-    }
-    fclose(f);
-    gzFile fp = gzopen(path.c_str(), "r");
-    if (!fp) return false;
-    gzbuffer(fp, 1 << 20);
-    std::vector<char> buf(1 << 22);
-    for (;;) {
-        const int n = gzread(fp, buf.data(), (unsigned)buf.size());
-        if (n < 0) { gzclose(fp); return false; }
-        if (n == 0) break;
-        out.append(buf.data(), (size_t)n);
-    }
-    gzclose(fp);
-    return true;
+// ---- host threads for the two byte-moving stages (page-in of the input, packing the read plane) ------------------------
+static unsigned host_threads() {
+    const char *e = getenv("FLX_CLI_THREADS");
+    if (e && atoi(e) > 0) return (unsigned)atoi(e);
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(16u, hw ? hw : 1u));
 }
+
+template <class F>
+static void parallel_for(size_t n_parts, F &&body) {  // body(part) for part in [0, n_parts), on up to host_threads() threads
+    const unsigned t = (unsigned)std::min<size_t>(host_threads(), n_parts);
+    if (t <= 1) { for (size_t i = 0; i < n_parts; ++i) body(i); return; }
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < t; ++k)
+        th.emplace_back([&, k] { for (size_t i = k; i < n_parts; i += t) body(i); });
+    for (auto &x : th) x.join();
+}
+
+// The whole input, addressable.  Plain files are mapped (no copy; pages are faulted in by several threads); gzip and
+// pipes are inflated / read into memory through zlib, as the reference's kseq does (src/kseq.h:87-110).
+struct Input {
+    const char *p = nullptr;
+    size_t n = 0;
+    void *map = nullptr;
+    size_t map_len = 0;
+    std::string owned;
+    Input() = default;
+    Input(const Input &) = delete;
+    Input &operator=(const Input &) = delete;
+    ~Input() { if (map) munmap(map, map_len); }
+    const char *data() const { return p; }
+    size_t size() const { return n; }
+
+    bool open(const std::string &path) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        unsigned char magic[2] = {0, 0};
+        struct stat st;
+        const bool regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0;
+        const bool gz = regular && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (regular && !gz) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                ::close(fd);
+                map = m; map_len = (size_t)st.st_size;
+                p = (const char *)m; n = map_len;
+                madvise(m, map_len, MADV_WILLNEED);
+                const size_t part = 64u << 20;
+                const size_t parts = (n + part - 1) / part;
+                std::vector<unsigned> sink(parts, 0);
+                parallel_for(parts, [&](size_t i) {  // touch one byte per page so the page-table fill runs on all threads
+                    unsigned acc = 0;
+                    const size_t end = std::min(n, (i + 1) * part);
+                    for (size_t at = i * part; at < end; at += 4096) acc += (unsigned char)p[at];
+                    sink[i] = acc;
+                });
+                return true;
+            }
+        }
+        ::close(fd);
+        gzFile fp = gzopen(path.c_str(), "r");  // transparent for uncompressed streams too
+        if (!fp) return false;
+        gzbuffer(fp, 1 << 20);
+        std::vector<char> buf(1 << 22);
+        for (;;) {
+            const int got = gzread(fp, buf.data(), (unsigned)buf.size());
+            if (got < 0) { gzclose(fp); return false; }
+            if (got == 0) break;
+            owned.append(buf.data(), (size_t)got);
+        }
+        gzclose(fp);
+        p = owned.data(); n = owned.size();
+        return true;
+    }
+};
 
 // Record views point into the buffer; only multi-line sequences / qualities are copied (into `arena`).
 struct Parser {
-    const std::string &d;
+    const Input &d;
     std::deque<std::string> &arena;
     size_t pos = 0;
     int last_char = 0;
-    Parser(const std::string &data, std::deque<std::string> &side) : d(data), arena(side) {}
-    int getc() { return pos < d.size() ? (unsigned char)d[pos++] : -1; }
+    Parser(const Input &data, std::deque<std::string> &side) : d(data), arena(side) {}
+    int getc() { return pos < d.size() ? (unsigned char)d.p[pos++] : -1; }
     // rest of the current line as a view [from, end-of-line), consuming the newline; false at EOF
     bool rest_of_line(size_t from, View &v) {
         if (from > d.size()) return false;
@@ -353,10 +395,10 @@ struct Parser {
         r = Record();
         if (pos >= d.size()) return -1;
         size_t e = pos;
-        while (e < d.size() && !isspace((unsigned char)d[e])) ++e;  // the name ends at the first whitespace
+        while (e < d.size() && !isspace((unsigned char)d.p[e])) ++e;  // the name ends at the first whitespace
         r.name.p = d.data() + pos;
         r.name.n = e - pos;
-        c = e < d.size() ? (unsigned char)d[e] : -1;
+        c = e < d.size() ? (unsigned char)d.p[e] : -1;
         pos = e < d.size() ? e + 1 : e;
         if (c != '\n' && c >= 0) {
             rest_of_line(pos, r.comment);
@@ -406,11 +448,11 @@ static void print_hash_progress(const std::string &filename, long long base_coun
 
 // reads one reference file; returns the number of sequences (counting those < 16 bp, src/kmers.cpp:96-100)
 static int load_reference(const std::string &filename, std::vector<std::string> &seqs) {
-    std::string data;
+    Input data;
     int n = 0;
     long long bases = 0;
     std::deque<std::string> arena;
-    if (slurp(filename, data)) {
+    if (data.open(filename)) {
         Parser p(data, arena);
         Record r;
         long long l;
@@ -504,8 +546,8 @@ int main(int argc, char **argv) {
     stage("reference 16-mers");
     // ---- pass 1: parse, checks (src/main.cpp:63-130) -----------------------------------------------------
     if (!args.verbose) std::cerr << "Scoring long reads\n";
-    std::string data;
-    if (!slurp(args.input_reads, data)) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
+    Input data;
+    if (!data.open(args.input_reads)) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
     stage("read input file");
     std::vector<Record> recs;
     long long total_bases = 0, last_progress = 0;
@@ -553,10 +595,22 @@ int main(int argc, char **argv) {
     std::vector<uint64_t> offsets(n ? n : 1);
     uint64_t plane_bytes = 0;
     flx_plane_layout(lengths.data(), n, offsets.data(), &plane_bytes);
-    std::vector<uint8_t> plane(plane_bytes, 0);
-    for (uint64_t i = 0; i < n; ++i) {
-        const View &src = kmers_empty ? recs[i].qual : recs[i].seq;  // Phred mode reads qual, k-mer mode reads seq
-        if (!src.empty()) memcpy(plane.data() + offsets[i], src.p, src.size());
+    // anonymous mapping: zero pages (the alignment padding stays 0), first touched by the packing threads themselves
+    const size_t plane_len = std::max<uint64_t>(plane_bytes, 16);
+    void *plane_map = mmap(nullptr, plane_len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (plane_map == MAP_FAILED) { std::cerr << "Error: out of memory packing " << plane_bytes << " bytes\n"; return 1; }
+    uint8_t *plane = (uint8_t *)plane_map;
+    {
+        const size_t parts = n ? std::min<uint64_t>(n, (uint64_t)host_threads() * 8) : 0;
+        parallel_for(parts, [&](size_t k) {  // byte-balanced slices of the read range
+            const uint64_t lo_b = plane_bytes / parts * k, hi_b = k + 1 == parts ? plane_bytes : plane_bytes / parts * (k + 1);
+            const uint64_t lo = std::lower_bound(offsets.begin(), offsets.begin() + n, lo_b) - offsets.begin();
+            const uint64_t hi = k + 1 == parts ? n : std::lower_bound(offsets.begin(), offsets.begin() + n, hi_b) - offsets.begin();
+            for (uint64_t i = lo; i < hi; ++i) {
+                const View &src = kmers_empty ? recs[i].qual : recs[i].seq;  // Phred mode reads qual, k-mer mode reads seq
+                if (!src.empty()) memcpy(plane + offsets[i], src.p, src.size());
+            }
+        });
     }
     std::vector<uint32_t> order(n ? n : 1);
     flx_length_order(lengths.data(), n, order.data());
@@ -585,7 +639,7 @@ int main(int argc, char **argv) {
         sc.first = first.data(); sc.last = last.data(); sc.child_offsets = child_off.data();
         sc.child_ranges = c_ranges.data(); sc.child_mean_q = c_mean.data(); sc.child_window_q = c_window.data();
         sc.child_passed = c_passed.data(); sc.child_capacity = cap;
-        const int rc = flx_score_batch(ctx, kmers_empty ? nullptr : kmers, plane.data(), plane_bytes, offsets.data(), lengths.data(),
+        const int rc = flx_score_batch(ctx, kmers_empty ? nullptr : kmers, plane, plane_bytes, offsets.data(), lengths.data(),
                                        order.data(), n, &prm, &sc);
         if (rc == FLX_ERR_CAPACITY && sc.n_children > cap) { cap = sc.n_children; continue; }
         if (rc != FLX_OK) return fail_flx(ctx, "scoring");
@@ -593,6 +647,7 @@ int main(int argc, char **argv) {
         break;
     }
     (void)n_children;
+    munmap(plane_map, plane_len);
 
     stage("score (H2D + kernels + D2H)");
     // ---- reads2: children replace their parents in place (src/main.cpp:138-147) -----------------------------
