@@ -69,6 +69,14 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--window-size", type=int, default=250)
+    ap.add_argument("--global-stage", choices=("sharded", "replicated"), default="sharded",
+                    help="N > 1: all-gather the mean qualities and select with all-reduced histograms (default), or "
+                         "all-gather the full per-read records and replicate the single-GPU stage")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
+                                                       "one-GPU functional test of the N > 1 path)")
+    ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, collectives) even "
+                                                              "with one rank: exercises the RCCL calls on a 1-GPU box")
+    ap.add_argument("--dump-flags", default="", help="write this rank's final pass flags to <path>.rank<r>.npy (tests)")
     args = ap.parse_args()
 
     import torch
@@ -82,13 +90,21 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    if world > 1:
+    device_index = local_rank % max(torch.cuda.device_count(), 1)  # == local_rank except in the one-GPU gloo test
+    torch.cuda.set_device(device_index)
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(args.backend)
 
-    ctx = api.Context(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ctx = api.Context(device_index)
+    dev = torch.device("cuda", device_index)
     n = args.reads
     first = rank * n
 
@@ -113,15 +129,16 @@ def main():
     p_win = p_mean + 8 * n
     p_len = p_mean + 16 * n
     p_pass = p_mean + 20 * n
-    d_rec[16 * n:20 * n].view(torch.int32).copy_(d_len)
+    t_mean, t_win, t_len, t_pass = fdist.record_views(d_rec, n)
+    t_len.copy_(d_len)
     torch.cuda.synchronize()
     ctx.synth_qual_dev(synth.SEED, d_plane.data_ptr(), plane_bytes, d_off.data_ptr(), d_len.data_ptr(),
                        d_ids.data_ptr(), n)
     del d_ids
 
     total_n = n * world
-    if world > 1:
-        tb = torch.tensor([local_bases], dtype=torch.int64, device=dev)
+    if multi:
+        tb = torch.tensor([local_bases], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tb)
         total_bases = int(tb.item())
     else:
@@ -133,18 +150,25 @@ def main():
     def step():
         ctx.score_reads_dev(d_plane.data_ptr(), plane_bytes, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n,
                             params, p_mean, p_win, p_pass)
-        if world > 1:
-            # ONE RCCL all-gather of the per-read records (filtlong_amd/dist.py); every rank then runs the identical
-            # global stage on the gathered arrays, so the threshold is exact and no second exchange is needed.
+        if multi and args.global_stage == "sharded":
+            # ONE RCCL all-gather of the mean qualities (the statistics fold over all of them in file order); final
+            # scores and the cut are computed on the local reads, the selection's histograms all-reduced
+            # (filtlong_amd/dist.py, flx_rank_and_cut_sharded_dev).
+            return fdist.sharded_rank_and_cut(ctx, t_mean, t_win, t_len, t_pass, target_bases=target,
+                                              total_bases=total_bases)
+        if multi:
+            # ONE RCCL all-gather of the full per-read records; every rank then runs the identical single-GPU stage.
             g_mean, g_win, g_len, g_pass, _counts = fdist.gather_records(d_rec, n)
             torch.cuda.synchronize()
-            return ctx.rank_and_cut_dev(total_n, g_mean.data_ptr(), g_win.data_ptr(), g_len.data_ptr(),
-                                        g_pass.data_ptr(), target_bases=target, total_bases=total_bases)
+            rep = ctx.rank_and_cut_dev(total_n, g_mean.data_ptr(), g_win.data_ptr(), g_len.data_ptr(),
+                                       g_pass.data_ptr(), target_bases=target, total_bases=total_bases)
+            t_pass.copy_(g_pass[rank * n:(rank + 1) * n])
+            return rep
         return ctx.rank_and_cut_dev(n, p_mean, p_win, p_len, p_pass, target_bases=target, total_bases=total_bases)
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -158,8 +182,8 @@ def main():
         rep = step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if multi:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
@@ -200,7 +224,10 @@ def main():
                     "{:,}".format(n), ("fixed %d bp" % args.fixed_len) if args.fixed_len else "gamma(k=4) mean 10 kbp",
                     target, args.target_frac * 100, "; C2" if (n == 10_000_000 and not args.fixed_len) else ""),
                 "reads_total": total_n, "bases_total": total_bases, "window_size": args.window_size,
-                "parallelism": "reads sharded by count, 1 RCCL all-gather of per-read records" if world > 1 else "1 GPU",
+                "parallelism": ("1 GPU" if not multi else
+                                "reads sharded by count; 1 RCCL all-gather of mean qualities + all-reduced selection histograms"
+                                if args.global_stage == "sharded" else
+                                "reads sharded by count; 1 RCCL all-gather of per-read records, global stage replicated"),
                 "device": info["name"],
             },
             "roofline": {
@@ -217,7 +244,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_reads)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if args.dump_flags:
+        torch.cuda.synchronize()
+        np.save("%s.rank%d.npy" % (args.dump_flags, rank), t_pass.cpu().numpy())
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

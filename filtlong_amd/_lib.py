@@ -20,10 +20,15 @@ ABI_SYMBOLS = [
     "flx_abi_version", "flx_version", "flx_ctx_create", "flx_ctx_destroy", "flx_last_error", "flx_ctx_set_stream",
     "flx_ctx_synchronize", "flx_ctx_device_info", "flx_timing_enable", "flx_timing_reset", "flx_timing_get",
     "flx_plane_layout", "flx_length_order", "flx_score_batch", "flx_score_batch_dev", "flx_rank_and_cut",
-    "flx_rank_and_cut_dev", "flx_kmerset_create", "flx_kmerset_destroy", "flx_kmerset_add_assembly",
+    "flx_rank_and_cut_dev", "flx_rank_and_cut_sharded_dev", "flx_kmerset_create", "flx_kmerset_destroy", "flx_kmerset_add_assembly",
     "flx_kmerset_add_short_reads", "flx_kmerset_finalize", "flx_kmerset_size", "flx_kmerset_contains",
     "flx_synth_qual_dev", "flx_synth_seq_dev",
 ]
+
+
+# flx_allreduce_u64_fn: int (*)(void *user, uint64_t *buf, uint64_t count)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64)
+NEED_REPLICATED = 100  # flx_status FLX_NEED_REPLICATED
 
 
 class Params(C.Structure):
@@ -116,6 +121,8 @@ def load():
     rank_args = [vp, u64, vp, vp, vp, vp, dbl, dbl, dbl, i32, i64, i32, dbl, i64, vp, C.POINTER(CutReport)]
     L.flx_rank_and_cut.argtypes = rank_args
     L.flx_rank_and_cut_dev.argtypes = rank_args
+    L.flx_rank_and_cut_sharded_dev.argtypes = [vp, u64, vp, u64, u64, vp, vp, vp, dbl, dbl, dbl, i32, C.c_int64, i32, dbl,
+                                               C.c_int64, vp, i32, i32, ALLREDUCE_FN, vp, C.POINTER(CutReport)]
     L.flx_kmerset_create.argtypes = [vp, C.POINTER(vp)]
     L.flx_kmerset_destroy.argtypes = [vp]
     L.flx_kmerset_destroy.restype = None

@@ -198,6 +198,34 @@ class Context:
                                                 int(total_bases), d_final_score, C.byref(rep)))
         return rep
 
+    def rank_and_cut_sharded_dev(self, n_total, d_mean_q_all, first, n_local, d_window_q, d_length, d_passed, rank, world,
+                                 reduce=None, length_weight=1.0, mean_q_weight=1.0, window_q_weight=1.0,
+                                 target_bases=None, keep_percent=None, total_bases=0, d_final_score=None):
+        """flx_rank_and_cut_sharded_dev.  `reduce(buf)` receives a writable numpy uint64 view of the library's host
+        buffer and must replace it by its sum over all ranks (filtlong_amd.dist.make_reduce builds one over
+        torch.distributed).  Returns (report, need_replicated)."""
+        rep = CutReport()
+
+        def _cb(_user, buf, count):
+            try:
+                import numpy as _np
+                reduce(_np.ctypeslib.as_array(buf, shape=(int(count),)))
+                return 0
+            except Exception:  # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = _lib.ALLREDUCE_FN(_cb) if reduce is not None else C.cast(None, _lib.ALLREDUCE_FN)
+        rc = self.L.flx_rank_and_cut_sharded_dev(self.h, n_total, d_mean_q_all, first, n_local, d_window_q, d_length, d_passed,
+                                                 length_weight, mean_q_weight, window_q_weight,
+                                                 1 if target_bases is not None else 0, int(target_bases or 0),
+                                                 1 if keep_percent is not None else 0, float(keep_percent or 0.0),
+                                                 int(total_bases), d_final_score, rank, world, cb, None, C.byref(rep))
+        if rc == _lib.NEED_REPLICATED:
+            return rep, True
+        self._check(rc)
+        return rep, False
+
     def synth_qual_dev(self, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n):
         self._check(self.L.flx_synth_qual_dev(self.h, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n))
 

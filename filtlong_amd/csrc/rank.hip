@@ -275,6 +275,22 @@ static int exact_host_cut(flx_ctx *ctx, uint64_t n, const double *d_mean, const 
 // =================================================================================================
 static const int FLX_SELECT_BAND_TOO_LARGE = -1000;
 
+// One rank's view when the global stage is sharded (flx_rank_and_cut_sharded_dev): the statistics are global, the
+// final scores / keys / pass flags are those of the local reads2 entries [first, first + n), and every quantity the
+// selection needs from the other ranks is a SUM of 64-bit integers, obtained through the caller's all-reduce.
+struct Shard {
+    flx_allreduce_u64_fn reduce = nullptr;  // NULL: single rank, nothing to exchange
+    void *user = nullptr;
+    uint64_t first = 0;
+    int rank = 0, world = 1;
+    bool sharded() const { return reduce != nullptr; }
+    int sum(flx_ctx *ctx, uint64_t *buf, uint64_t count) const {
+        if (!reduce) return FLX_OK;
+        if (reduce(user, buf, count) != 0) return flx_fail(ctx, FLX_ERR_STATE, "all-reduce callback failed");
+        return FLX_OK;
+    }
+};
+
 static double key_to_score(uint64_t k) {
     uint64_t a = ~k;  // ascending key
     uint64_t b = (a >> 63) ? (a & 0x7fffffffffffffffull) : ~a;
@@ -284,13 +300,14 @@ static double key_to_score(uint64_t k) {
 }
 
 static int cut_by_select(flx_ctx *ctx, uint64_t n, const double *mean, const double *window, const int32_t *length,
-                         uint8_t *passed, const NormArgs &s, int64_t target, void *d_final_score, flx_cut_report *rep) {
+                         uint8_t *passed, const NormArgs &s, int64_t target, void *d_final_score, flx_cut_report *rep,
+                         const Shard &sh = Shard()) {
     hipStream_t st = ctx->stream;
     const unsigned nb = (unsigned)((n + 255) / 256);
     const unsigned cap = 1u << 16;
     const size_t bytes = n * 8 + 256 * 8 * 8 + (size_t)cap * 4 + 1024;
     void *scr;
-    FLX_CHECK(flx_scratch(ctx, bytes, &scr));
+    FLX_CHECK(flx_scratch(ctx, bytes ? bytes : 1024, &scr));
     char *p = (char *)scr;
     uint64_t *keys = (uint64_t *)p; p += n * 8;
     unsigned long long *bins = (unsigned long long *)p; p += 256 * 8 * 8;  // one 256-bin table per pass
@@ -299,27 +316,31 @@ static int cut_by_select(flx_ctx *ctx, uint64_t n, const double *mean, const dou
 
     FLX_HIP(ctx, hipMemsetAsync(bins, 0, 256 * 8 * 8 + 256, st));
     flx_time_begin(ctx, "flx_rank_final_score");
-    hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s, (double *)d_final_score, keys,
-                       (uint32_t *)nullptr, (unsigned int *)(d_acc + 2));
+    if (n)
+        hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s, (double *)d_final_score, keys,
+                           (uint32_t *)nullptr, (unsigned int *)(d_acc + 2));
     flx_time_end(ctx);
 
     // ---- 8 weighted histogram passes, most significant byte first ------------------------------------------
     flx_time_begin(ctx, "flx_rank_select");
-    const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, 2048));
     uint64_t prefix = 0;
     long long remaining = target;  // bases still to be collected inside the current prefix
     unsigned long long h_nan = 0;
     for (int pass = 0; pass < 8; ++pass) {
         unsigned long long *b = bins + 256 * pass;
         hipLaunchKernelGGL(k_select_hist, dim3(grid), dim3(256), 0, st, n, keys, length, passed, prefix, pass, b);
-        unsigned long long h[256];
-        FLX_HIP(ctx, hipMemcpyAsync(h, b, sizeof h, hipMemcpyDeviceToHost, st));
+        unsigned long long h[257];
+        FLX_HIP(ctx, hipMemcpyAsync(h, b, 256 * 8, hipMemcpyDeviceToHost, st));
         if (pass == 0) FLX_HIP(ctx, hipMemcpyAsync(&h_nan, d_acc + 2, 8, hipMemcpyDeviceToHost, st));
         FLX_HIP(ctx, hipStreamSynchronize(st));
-        if (pass == 0 && (h_nan & 1ull)) {
+        h[256] = pass == 0 ? (h_nan & 1ull) : 0;  // the NaN flag rides along with the first histogram
+        FLX_CHECK(sh.sum(ctx, (uint64_t *)h, 257));
+        if (pass == 0 && h[256]) {
             // NaN scores (stdev == 0 -> 0/0, main.cpp:192-206, or 0/0 window ratios): the reference's comparator is
             // inconsistent and its outcome is whatever libstdc++'s introsort does on reads2 order -> host path.
             flx_time_end(ctx);
+            if (sh.sharded()) return FLX_NEED_REPLICATED;
             return exact_host_cut(ctx, n, mean, window, length, passed, nullptr, nullptr, s, target, rep);
         }
         int d = 0;
@@ -348,26 +369,58 @@ static int cut_by_select(flx_ctx *ctx, uint64_t n, const double *mean, const dou
     FLX_HIP(ctx, hipMemcpyAsync(&h_acc[0], d_acc + 3, 8, hipMemcpyDeviceToHost, st));
     FLX_HIP(ctx, hipMemcpyAsync(&h_acc[1], d_acc + 4, 8, hipMemcpyDeviceToHost, st));
     FLX_HIP(ctx, hipStreamSynchronize(st));
-    const unsigned band_n = (unsigned)(h_acc[0] & 0xffffffffull);
-    if (band_n > cap) {  // huge tie group (e.g. millions of duplicate reads): let the sort path handle it
-        flx_time_end(ctx);
-        return FLX_SELECT_BAND_TOO_LARGE;
+    const unsigned local_n = (unsigned)(h_acc[0] & 0xffffffffull);
+    // band sizes of every rank (own slot filled, the rest zero) + the weight in front of the band, in one sum
+    std::vector<uint64_t> counts((size_t)sh.world + 1, 0);
+    counts[sh.rank] = local_n;
+    counts[sh.world] = h_acc[1];
+    FLX_CHECK(sh.sum(ctx, counts.data(), counts.size()));
+    uint64_t band_total = 0, my_at = 0;
+    for (int r = 0; r < sh.world; ++r) {
+        if (r == sh.rank) my_at = band_total;
+        band_total += counts[r];
     }
-    std::vector<uint32_t> idx(band_n);
-    FLX_HIP(ctx, hipMemcpy(idx.data(), band_idx, (size_t)band_n * 4, hipMemcpyDeviceToHost));
+    const long long weight_before = (long long)counts[sh.world];
+    if (band_total > cap) {  // huge tie group (e.g. millions of duplicate reads): let the sort path handle it
+        flx_time_end(ctx);
+        return sh.sharded() ? FLX_NEED_REPLICATED : FLX_SELECT_BAND_TOO_LARGE;
+    }
+    const unsigned band_n = (unsigned)band_total;
+    std::vector<uint32_t> idx(local_n);
+    if (local_n) FLX_HIP(ctx, hipMemcpy(idx.data(), band_idx, (size_t)local_n * 4, hipMemcpyDeviceToHost));
     std::sort(idx.begin(), idx.end());
-    struct Cand { uint32_t idx; uint64_t key; double score; int32_t len; uint8_t was_passed; };
+    struct Cand { uint64_t idx; uint64_t key; double score; int32_t len; uint8_t was_passed; };
+    // five words per candidate: global reads2 index, key, exact score bits, length, pre-cut flag
+    std::vector<uint64_t> wire((size_t)band_n * 5, 0);
+    for (unsigned i = 0; i < local_n; ++i) {
+        const uint32_t li = idx[i];
+        double mq, wq;
+        int32_t len;
+        uint8_t was;
+        uint64_t key;
+        FLX_HIP(ctx, hipMemcpy(&mq, mean + li, 8, hipMemcpyDeviceToHost));
+        FLX_HIP(ctx, hipMemcpy(&wq, window + li, 8, hipMemcpyDeviceToHost));
+        FLX_HIP(ctx, hipMemcpy(&len, length + li, 4, hipMemcpyDeviceToHost));
+        FLX_HIP(ctx, hipMemcpy(&was, passed + li, 1, hipMemcpyDeviceToHost));
+        FLX_HIP(ctx, hipMemcpy(&key, keys + li, 8, hipMemcpyDeviceToHost));
+        const double sc = host_final_score(len, mq, wq, s);  // host libm: what the reference computes
+        uint64_t *w = &wire[(my_at + i) * 5];
+        w[0] = sh.first + li;
+        w[1] = key;
+        memcpy(&w[2], &sc, 8);
+        w[3] = (uint64_t)(uint32_t)len;
+        w[4] = was;
+    }
+    FLX_CHECK(sh.sum(ctx, wire.data(), wire.size()));
     std::vector<Cand> cand(band_n);
     for (unsigned i = 0; i < band_n; ++i) {
+        const uint64_t *w = &wire[(size_t)i * 5];
         Cand &c = cand[i];
-        c.idx = idx[i];
-        double mq, wq;
-        FLX_HIP(ctx, hipMemcpy(&mq, mean + c.idx, 8, hipMemcpyDeviceToHost));
-        FLX_HIP(ctx, hipMemcpy(&wq, window + c.idx, 8, hipMemcpyDeviceToHost));
-        FLX_HIP(ctx, hipMemcpy(&c.len, length + c.idx, 4, hipMemcpyDeviceToHost));
-        FLX_HIP(ctx, hipMemcpy(&c.was_passed, passed + c.idx, 1, hipMemcpyDeviceToHost));
-        FLX_HIP(ctx, hipMemcpy(&c.key, keys + c.idx, 8, hipMemcpyDeviceToHost));
-        c.score = host_final_score(c.len, mq, wq, s);  // host libm: what the reference computes
+        c.idx = w[0];
+        c.key = w[1];
+        memcpy(&c.score, &w[2], 8);
+        c.len = (int32_t)(uint32_t)w[3];
+        c.was_passed = (uint8_t)w[4];
     }
     // exact order inside the band: descending exact score; the device order (key, then reads2 index) breaks the rest
     std::vector<unsigned> ord(band_n);
@@ -377,7 +430,7 @@ static int cut_by_select(flx_ctx *ctx, uint64_t n, const double *mean, const dou
         if (cand[x].key != cand[y].key) return cand[x].key < cand[y].key;
         return cand[x].idx < cand[y].idx;
     });
-    long long so_far = (long long)h_acc[1];
+    long long so_far = weight_before;
     std::vector<uint8_t> keep(band_n, 0);
     for (unsigned k = 0; k < band_n; ++k) {
         Cand &c = cand[ord[k]];
@@ -397,15 +450,18 @@ static int cut_by_select(flx_ctx *ctx, uint64_t n, const double *mean, const dou
         k = e;
     }
     flx_time_end(ctx);
-    if (tie_straddle) return exact_host_cut(ctx, n, mean, window, length, passed, nullptr, nullptr, s, target, rep);
+    if (tie_straddle) {
+        if (sh.sharded()) return FLX_NEED_REPLICATED;
+        return exact_host_cut(ctx, n, mean, window, length, passed, nullptr, nullptr, s, target, rep);
+    }
 
     // ---- mark: better than the band -> unchanged; band and worse -> fail; kept band members -> back on ----------
-    hipLaunchKernelGGL(k_select_mark, dim3(nb), dim3(256), 0, st, n, keys, k_lo, passed);
+    if (n) hipLaunchKernelGGL(k_select_mark, dim3(nb), dim3(256), 0, st, n, keys, k_lo, passed);
     FLX_HIP(ctx, hipStreamSynchronize(st));
-    for (unsigned i = 0; i < band_n; ++i)
-        if (keep[i]) {
+    for (unsigned i = 0; i < local_n; ++i)  // this rank's members sit at [my_at, my_at + local_n) of the global band
+        if (keep[my_at + i]) {
             const uint8_t one = 1;
-            FLX_HIP(ctx, hipMemcpy(passed + cand[i].idx, &one, 1, hipMemcpyHostToDevice));
+            FLX_HIP(ctx, hipMemcpy(passed + (cand[my_at + i].idx - sh.first), &one, 1, hipMemcpyHostToDevice));
         }
     rep->kept_bases = so_far;  // "keeping N bp", main.cpp:258
     rep->audited = band_n;
@@ -584,26 +640,19 @@ static int cut_by_sort(flx_ctx *ctx, uint64_t n, const double *mean, const doubl
 }
 
 
-extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean_q, const void *d_window_q,
-                                    const void *d_length, void *d_passed, double lw, double mw, double ww,
-                                    int target_bases_set, int64_t target_bases, int keep_percent_set,
-                                    double keep_percent, int64_t total_bases, void *d_final_score,
-                                    flx_cut_report *rep) {
-    if (!ctx) return FLX_ERR_INVALID;
-    if (!rep) return flx_fail(ctx, FLX_ERR_INVALID, "report must not be NULL");
-    memset(rep, 0, sizeof *rep);
-    if (n > 0xffffffffull) return flx_fail(ctx, FLX_ERR_INVALID, "at most 2^32-1 reads");
-    FLX_HIP(ctx, hipSetDevice(ctx->device));
-    const double *mean = (const double *)d_mean_q;
-    const double *window = (const double *)d_window_q;
-    const int32_t *length = (const int32_t *)d_length;
-    uint8_t *passed = (uint8_t *)d_passed;
+// Global stage on one rank's view: statistics over ALL reads2 entries (mean_all[0, n_total)), everything else on the
+// local entries [sh.first, sh.first + n).  Single rank: n == n_total, sh.first == 0, no exchange.
+static int rank_and_cut_impl(flx_ctx *ctx, uint64_t n_total, const double *mean_all, uint64_t n, const double *window,
+                             const int32_t *length, uint8_t *passed, double lw, double mw, double ww,
+                             int target_bases_set, int64_t target_bases, int keep_percent_set, double keep_percent,
+                             int64_t total_bases, void *d_final_score, flx_cut_report *rep, const Shard &sh) {
+    const double *mean = mean_all + sh.first;
     hipStream_t st = ctx->stream;
     const bool cutting = target_bases_set || keep_percent_set;
 
     // ---- a20: statistics (exact serial folds) -------------------------------------------------
     flx_stats stats;
-    FLX_CHECK(flx_exact_stats(ctx, n, mean, &stats));
+    FLX_CHECK(flx_exact_stats(ctx, n_total, mean_all, &stats));
     NormArgs s;
     s.qmean = stats.mean;
     s.qstd = stats.stdev;
@@ -625,7 +674,7 @@ extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean
     // ---- early outs that need no sort ----------------------------------------------------------
     int64_t target = 0;
     bool need_sort = false;
-    if (cutting && n) {
+    if (cutting && n_total) {
         void *scr;
         FLX_CHECK(flx_scratch(ctx, 64, &scr));
         unsigned long long *d_acc = (unsigned long long *)scr;
@@ -636,6 +685,9 @@ extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean
         unsigned long long passed_bases = 0;
         FLX_HIP(ctx, hipMemcpyAsync(&passed_bases, d_acc, 8, hipMemcpyDeviceToHost, st));
         FLX_HIP(ctx, hipStreamSynchronize(st));
+        uint64_t pb = passed_bases;
+        FLX_CHECK(sh.sum(ctx, &pb, 1));
+        passed_bases = pb;
         target = compute_target(target_bases_set, target_bases, keep_percent_set, keep_percent, total_bases);
         rep->target_bases = target;
         if (target >= total_bases) rep->outcome = FLX_CUT_NOT_ENOUGH;
@@ -646,12 +698,12 @@ extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean
         rep->target_bases = target;
         rep->outcome = target >= total_bases ? FLX_CUT_NOT_ENOUGH : FLX_CUT_ALREADY_BELOW;
     }
-    if (n == 0) return FLX_OK;
+    if (n_total == 0) return FLX_OK;
 
     // ---- a21/a22: normalise + final score (+ keys) --------------------------------------------
     const unsigned nb = (unsigned)((n + 255) / 256);
     if (!need_sort) {
-        if (d_final_score) {
+        if (d_final_score && n) {
             flx_time_begin(ctx, "flx_rank_final_score");
             hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s,
                                (double *)d_final_score, (uint64_t *)nullptr, (uint32_t *)nullptr,
@@ -664,11 +716,52 @@ extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean
 
     {
         const char *e = getenv("FLX_RANK_SORT");  // test hook / fallback selector
-        if (e && e[0] == '1') return cut_by_sort(ctx, n, mean, window, length, passed, s, target, d_final_score, rep);
+        if (e && e[0] == '1') {
+            if (sh.sharded()) return FLX_NEED_REPLICATED;  // the sort path wants every record on one device
+            return cut_by_sort(ctx, n, mean, window, length, passed, s, target, d_final_score, rep);
+        }
     }
-    const int rc = cut_by_select(ctx, n, mean, window, length, passed, s, target, d_final_score, rep);
+    const int rc = cut_by_select(ctx, n, mean, window, length, passed, s, target, d_final_score, rep, sh);
     if (rc == FLX_SELECT_BAND_TOO_LARGE) return cut_by_sort(ctx, n, mean, window, length, passed, s, target, d_final_score, rep);
     return rc;
+}
+
+extern "C" int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean_q, const void *d_window_q,
+                                    const void *d_length, void *d_passed, double lw, double mw, double ww,
+                                    int target_bases_set, int64_t target_bases, int keep_percent_set,
+                                    double keep_percent, int64_t total_bases, void *d_final_score,
+                                    flx_cut_report *rep) {
+    if (!ctx) return FLX_ERR_INVALID;
+    if (!rep) return flx_fail(ctx, FLX_ERR_INVALID, "report must not be NULL");
+    memset(rep, 0, sizeof *rep);
+    if (n > 0xffffffffull) return flx_fail(ctx, FLX_ERR_INVALID, "at most 2^32-1 reads");
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    return rank_and_cut_impl(ctx, n, (const double *)d_mean_q, n, (const double *)d_window_q, (const int32_t *)d_length,
+                             (uint8_t *)d_passed, lw, mw, ww, target_bases_set, target_bases, keep_percent_set,
+                             keep_percent, total_bases, d_final_score, rep, Shard());
+}
+
+extern "C" int flx_rank_and_cut_sharded_dev(flx_ctx *ctx, uint64_t n_total, const void *d_mean_q_all, uint64_t first,
+                                            uint64_t n_local, const void *d_window_q, const void *d_length,
+                                            void *d_passed, double lw, double mw, double ww, int target_bases_set,
+                                            int64_t target_bases, int keep_percent_set, double keep_percent,
+                                            int64_t total_bases, void *d_final_score, int rank, int world,
+                                            flx_allreduce_u64_fn reduce, void *user, flx_cut_report *rep) {
+    if (!ctx) return FLX_ERR_INVALID;
+    if (!rep) return flx_fail(ctx, FLX_ERR_INVALID, "report must not be NULL");
+    memset(rep, 0, sizeof *rep);
+    if (n_total > 0xffffffffull) return flx_fail(ctx, FLX_ERR_INVALID, "at most 2^32-1 reads");
+    if (first > n_total || n_local > n_total - first) return flx_fail(ctx, FLX_ERR_INVALID, "shard [first, first + n_local) outside [0, n_total)");
+    if (world < 1 || rank < 0 || rank >= world) return flx_fail(ctx, FLX_ERR_INVALID, "bad rank / world");
+    if (world > 1 && !reduce) return flx_fail(ctx, FLX_ERR_INVALID, "world > 1 needs an all-reduce callback");
+    if (n_total && !d_mean_q_all) return flx_fail(ctx, FLX_ERR_INVALID, "NULL mean array");
+    if (n_local && (!d_window_q || !d_length || !d_passed)) return flx_fail(ctx, FLX_ERR_INVALID, "NULL local array");
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    Shard sh;
+    sh.reduce = reduce; sh.user = user; sh.first = first; sh.rank = rank; sh.world = world;
+    return rank_and_cut_impl(ctx, n_total, (const double *)d_mean_q_all, n_local, (const double *)d_window_q,
+                             (const int32_t *)d_length, (uint8_t *)d_passed, lw, mw, ww, target_bases_set, target_bases,
+                             keep_percent_set, keep_percent, total_bases, d_final_score, rep, sh);
 }
 
 extern "C" int flx_rank_and_cut(flx_ctx *ctx, uint64_t n, const double *mean_q, const double *window_q,

@@ -44,7 +44,9 @@ enum flx_status {
     FLX_ERR_NOMEM = 3,       /* host or device allocation failed              */
     FLX_ERR_STATE = 4,       /* call order violated (e.g. set not finalized)  */
     FLX_ERR_CAPACITY = 5,    /* caller-provided output capacity too small     */
-    FLX_ERR_NO_DEVICE = 6    /* no usable gfx950 device                       */
+    FLX_ERR_NO_DEVICE = 6,   /* no usable gfx950 device                       */
+    FLX_NEED_REPLICATED = 100 /* flx_rank_and_cut_sharded_dev only: not an error — nothing was modified; gather all
+                                records and call flx_rank_and_cut_dev instead (NaN scores / ties straddling the cut) */
 };
 
 typedef struct flx_ctx flx_ctx;
@@ -173,6 +175,28 @@ int flx_rank_and_cut_dev(flx_ctx *ctx, uint64_t n, const void *d_mean_q, const v
                          const void *d_length, void *d_passed, double length_weight, double mean_q_weight,
                          double window_q_weight, int target_bases_set, int64_t target_bases, int keep_percent_set,
                          double keep_percent, int64_t total_bases, void *d_final_score, flx_cut_report *report);
+
+/* The same stage with the reads2 entries sharded over `world` ranks (one process per GPU).  The
+ * statistics of src/main.cpp:170-196 are order-dependent folds over ALL mean qualities, so d_mean_q_all holds every
+ * rank's mean qualities in global reads2 order (the one array that has to be all-gathered: 8 bytes per entry).
+ * Everything else stays local: d_window_q / d_length / d_passed / d_final_score describe this rank's entries
+ * [first, first + n_local) only.  The cut (src/main.cpp:247-257) is a weighted selection: per key byte a 256-bin
+ * histogram of summed read lengths, whose global value is the SUM over ranks — the only exchange the selection
+ * needs.  `reduce(user, buf, count)` must replace buf[0..count) (host memory) by its element-wise sum over all
+ * ranks and return 0; it is called the same number of times with the same counts on every rank (about a dozen
+ * calls of <= 2 KB + one of 40 bytes per boundary-audit candidate).  NULL is allowed when world == 1.
+ * Returns FLX_OK with this rank's final pass flags in d_passed (report fields are global), or
+ * FLX_NEED_REPLICATED — on every rank alike, before anything was modified — when the exact outcome needs the
+ * reference's own std::sort over all records (NaN scores, equal scores straddling the cut, or FLX_RANK_SORT=1):
+ * gather the records and call flx_rank_and_cut_dev. */
+typedef int (*flx_allreduce_u64_fn)(void *user, uint64_t *buf, uint64_t count);
+
+int flx_rank_and_cut_sharded_dev(flx_ctx *ctx, uint64_t n_total, const void *d_mean_q_all, uint64_t first,
+                                 uint64_t n_local, const void *d_window_q, const void *d_length, void *d_passed,
+                                 double length_weight, double mean_q_weight, double window_q_weight,
+                                 int target_bases_set, int64_t target_bases, int keep_percent_set, double keep_percent,
+                                 int64_t total_bases, void *d_final_score, int rank, int world,
+                                 flx_allreduce_u64_fn reduce, void *user, flx_cut_report *report);
 
 /* ------------------------------------------------------------------------------------------
  * seam 1 — reference 16-mer set   (replaces Kmers, src/kmers.cpp:28-172 + src/bloom_filter.h)

@@ -78,3 +78,32 @@ def test_shard_range_partitions_file_order():
         assert edges[0][0] == 0 and edges[-1][1] == n
         assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
         assert max(h - l for l, h in edges) - min(h - l for l, h in edges) <= 1
+
+
+def _means_worker(rank, world, port, sizes, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.RandomState(5)
+        allm = rng.uniform(50, 99, sum(sizes))
+        lo = sum(sizes[:rank])
+        g, counts = fdist.gather_means(torch.from_numpy(allm[lo:lo + sizes[rank]].copy()))
+        assert counts == list(sizes)
+        assert (g.numpy().view(np.uint64) == allm.view(np.uint64)).all()
+        # the callback handed to the C ABI: an in-place sum over ranks of a host uint64 buffer (wrap-around included)
+        red = fdist.make_reduce()
+        buf = np.array([rank + 1, 2 ** 63 + 5, 0 if rank else 0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
+        red(buf)
+        want = np.array([3, (2 * (2 ** 63 + 5)) % 2 ** 64, 0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
+        assert (buf == want).all(), buf
+        np.save(os.path.join(out_dir, "ok%d.npy" % rank), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sizes", [(500, 500), (300, 701), (0, 64)])
+def test_gather_means_and_reduce_callback(tmp_path, sizes):
+    port = _free_port()
+    mp.spawn(_means_worker, args=(2, port, sizes, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d.npy" % r)) for r in range(2))
