@@ -1,0 +1,94 @@
+"""The command line's concurrent FASTA/FASTQ parse (filtlong_amd/cli/main.cpp: parse_parallel) must give exactly the
+records of its sequential kseq-compatible parser (reference src/kseq.h:176-224) — or decline and fall back.  Runs
+without a GPU through the binary's FLX_CLI_PARSE_ONLY hook."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "filtlong_amd", "bin", "filtlong")
+
+
+def digest(path, mode, threads=4):
+    env = dict(os.environ, FLX_CLI_PARSE_ONLY=mode, FLX_CLI_PARALLEL_PARSE_MIN="1", FLX_CLI_THREADS=str(threads), LANG="C", LC_ALL="C")
+    p = subprocess.run([BIN, "--target_bases", "1", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    out = p.stdout.decode().strip()
+    fields = out.split()
+    return out.replace(" parallel 1 ", " parallel 0 "), fields[fields.index("parallel") + 1] == "1"
+
+
+def random_fastq(rng, n, style):
+    out = bytearray()
+    for i in range(n):
+        L = int(rng.choice([0, 1, 5, 60, 61, 200, 1500])) if style != "plain" else int(rng.randint(1, 400))
+        seq = bytes(rng.choice(list(b"ACGTN"), size=L).astype(np.uint8))
+        # qualities drawn from the full printable range: lines starting with '@', '+' and '>' do occur
+        qual = bytes(rng.randint(33, 127, size=L).astype(np.uint8))
+        if style == "atq" and L:
+            qual = b"@" + qual[1:]
+        nl = b"\r\n" if style == "crlf" else b"\n"
+        out += b"@r%d" % i + (b" some comment" if i % 3 == 0 else b"") + nl
+        if style == "multiline" and L > 70:
+            for j in range(0, L, 70):
+                out += seq[j:j + 70] + nl
+        else:
+            out += seq + nl
+        out += b"+" + (b"r%d" % i if i % 5 == 0 else b"") + nl
+        if style == "multiline" and L > 70:
+            for j in range(0, L, 70):
+                out += qual[j:j + 70] + nl
+        else:
+            out += qual + nl
+        if style == "blank" and i % 4 == 0:
+            out += nl
+    return bytes(out)
+
+
+@pytest.mark.parametrize("style", ["plain", "atq", "crlf", "multiline", "blank", "mixedlen"])
+@pytest.mark.parametrize("threads", [2, 3, 7, 16])
+def test_parallel_parse_equals_sequential(tmp_path, style, threads):
+    rng = np.random.RandomState(hash((style, threads)) % 2 ** 31)
+    for rep in range(3):
+        data = random_fastq(rng, int(rng.randint(1, 400)), style)
+        path = str(tmp_path / ("in_%s_%d.fastq" % (style, rep)))
+        open(path, "wb").write(data)
+        seq, _ = digest(path, "seq", threads)
+        par, accepted = digest(path, "par", threads)
+        assert seq == par, (style, threads, rep, accepted)
+        # truncated anywhere: same records and the same error status either way
+        cut = int(rng.randint(1, len(data)))
+        open(path, "wb").write(data[:cut])
+        seq, _ = digest(path, "seq", threads)
+        par, accepted = digest(path, "par", threads)
+        assert seq == par, (style, threads, rep, "truncated at %d" % cut, accepted)
+
+
+def test_parallel_parse_is_taken_on_plain_fastq_and_fasta(tmp_path):
+    rng = np.random.RandomState(1)
+    path = str(tmp_path / "plain.fastq")
+    open(path, "wb").write(random_fastq(rng, 500, "plain"))
+    seq, _ = digest(path, "seq")
+    par, accepted = digest(path, "par", 8)
+    assert accepted and seq == par
+    fa = str(tmp_path / "x.fasta")
+    contigs = _cases.synth_reference(n_contigs=40, contig_len=500)
+    open(fa, "wb").write(_cases.fasta_bytes(contigs, width=60))
+    seq, _ = digest(fa, "seq")
+    par, accepted = digest(fa, "par", 8)
+    assert accepted and seq == par
+
+
+def test_reference_fixture_files(tmp_path):
+    for name in sorted(os.listdir(_cases.FIXTURES)):
+        if name.endswith(".gz"):
+            continue
+        path = os.path.join(_cases.FIXTURES, name)
+        for t in (2, 5):
+            seq, _ = digest(path, "seq", t)
+            par, _ = digest(path, "par", t)
+            assert seq == par, name
