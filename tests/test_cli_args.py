@@ -52,6 +52,13 @@ CASES = [
     (["--length_weight", "-1", "--target_bases", "5", "INPUT"], "received invalid value type"),
     (["--target_bases", "12x", "INPUT"], "received invalid value '12x'"),
     (["--target_bases=100", "INPUT"], "Flag could not be matched"),
+    # unit suffixes (reference test/test_unit_suffixes.py:157-209)
+    (["--target_bases", "10xyz", "INPUT"], "invalid value"),
+    (["--target_bases", "k", "INPUT"], "invalid value"),
+    (["--target_bases", "-10k", "INPUT"], "Error: the value for --target_bases must be a positive integer"),
+    (["--min_length", "-5kb", "INPUT"], "Error: the value for --min_length must be a positive integer"),
+    (["-l", "-10k", "INPUT"], "Error: the value for --min_length must be a positive integer"),
+    (["-L", "-5kb", "INPUT"], "Error: the value for --max_length must be a positive integer"),
 ]
 
 

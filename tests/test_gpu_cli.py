@@ -96,3 +96,27 @@ def test_cli_verbose_scores(tmp_path):
     assert rc == 0
     rows = {l.split("\t")[0].strip(): l.split("\t") for l in err.split("\n") if l.startswith("test_sort_") and "\t" in l}
     assert [rows["test_sort_%d" % i][4].strip() for i in (1, 2, 3)] == ["0.00", "70.70", "61.54"]
+
+
+def test_cli_unit_suffixes(tmp_path):
+    """The reference's test/test_unit_suffixes.py:39-205, success cases: k/kb/m/mb/g/gb, case-insensitive, decimals, on
+    every flag that takes them; the stderr target line shows the expanded value (C locale here: no grouping)."""
+    fq = os.path.join(FIX, "test_sort.fastq")
+    asm = os.path.join(FIX, "test_reference.fasta")
+    for val, shown in (("10k", "10000"), ("10kb", "10000"), ("1g", "1000000000"), ("1gb", "1000000000"), ("0.01m", "10000"),
+                       ("0.01mb", "10000"), ("10K", "10000"), ("10KB", "10000"), ("0.01M", "10000"), ("0.01MB", "10000"),
+                       ("3.5mb", "3500000"), ("1kb", "1000"), ("1k", "1000"), ("3.5k", "3500"), ("10000", "10000")):
+        rc, out, keep, err = run(["--target_bases", val, fq], str(tmp_path))
+        assert rc == 0 and ("target: %s bp" % shown) in err, (val, err)
+    same = None
+    for flags, n_out in ((["--min_length", "1k"], 3), (["--min_length", "1g"], 0), (["--max_length", "10k"], 3),
+                         (["--max_length", "1gb"], 3), (["-l", "5k"], 3), (["-L", "10k"], 3),
+                         (["-a", asm, "--split", "1k"], None), (["-a", asm, "--split", "1g"], None)):
+        rc, out, keep, err = run(flags + [fq], str(tmp_path))
+        assert rc == 0, (flags, err)
+        if n_out is not None:
+            assert out.count(b"\n@test_sort_") + out.startswith(b"@test_sort_") == n_out, flags
+    # a suffix is the same run as the plain number
+    a = run(["--target_bases", "10k", fq], str(tmp_path))[1]
+    b = run(["--target_bases", "10000", fq], str(tmp_path))[1]
+    assert a == b and len(a) > 0
