@@ -256,32 +256,46 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
     };
 
     // Two word streams over the read's coverage row — the leading edge (position j) and the trailing edge (position
-    // j - ws) — each kept two 32-bit words ahead so the (uncoalesced, one row per lane) loads overlap the serial math.
+    // j - ws).  Each lane walks its own row, so a 4-byte load would still pull a whole 64-byte sector through the fabric
+    // (16x amplification: the rows of all resident lanes do not fit L1/L2 together).  The streams therefore move in
+    // 16-byte blocks (rows are 16-byte aligned and padded), one block ahead of their use.
     const int n_words = (L + 31) >> 5;
-    auto ld = [&](int wi) -> uint32_t { return (wi < n_words) ? row[wi] : 0u; };
-    uint32_t lead_w = ld(0), lead_n1 = ld(1), lead_n2 = ld(2);
-    uint32_t trail_w = ld(0), trail_n1 = ld(1), trail_n2 = ld(2);
+    struct WStream { uint4 cur, nxt; int blk; };
+    auto ldq = [&](int b) -> uint4 {
+        return (b * 4 < n_words) ? *reinterpret_cast<const uint4 *>(row + 4 * (size_t)b) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto advance = [&](WStream &st, int b) {  // streams only move forward, one block at a time
+        if (b != st.blk) {
+            st.cur = st.nxt;
+            st.blk = b;
+            st.nxt = ldq(b + 1);
+        }
+    };
+    auto word = [&](const WStream &st, int wi) -> uint32_t {  // wi inside block st.blk or st.blk + 1
+        const uint4 &q = ((wi >> 2) == st.blk) ? st.cur : st.nxt;
+        const int c = wi & 3;
+        const uint32_t v = c == 0 ? q.x : c == 1 ? q.y : c == 2 ? q.z : q.w;
+        return wi < n_words ? v : 0u;  // the padding of the last block is not coverage
+    };
+    WStream lead = {ldq(0), ldq(1), 0};
+    WStream trail = lead;
+    uint32_t lead_w = word(lead, 0), trail_w = lead_w;
     int Lmin = live ? L : 0x7fffffff;
     for (int o = 32; o > 0; o >>= 1) Lmin = min(Lmin, __shfl_xor(Lmin, o, 64));
     const unsigned int d_lo = (unsigned int)(__double_as_longlong(delta) & 0xffffffffll);
     const unsigned int d_hi = (unsigned int)(__double_as_longlong(delta) >> 32);
     for (int j0 = 0; j0 < Lmax; j0 += 32) {
-      if (j0 > 0) {
-          lead_w = lead_n1;
-          lead_n1 = lead_n2;
-          lead_n2 = ld((j0 >> 5) + 2);
+      {
+          const int wi = j0 >> 5;
+          advance(lead, wi >> 2);
+          lead_w = word(lead, wi);
       }
       if (MODE == 0 && j0 >= ws && j0 + 32 <= Lmin) {
           // ---- steady state, parent only: 32 positions, every lane active, no per-bit control flow ----
-          const int tj0 = j0 - ws, sh = tj0 & 31;
-          uint32_t tw;
-          if (sh == 0) {
-              if (tj0 > 0) { trail_w = trail_n1; trail_n1 = trail_n2; trail_n2 = ld((tj0 >> 5) + 2); }
-              tw = trail_w;
-          } else {
-              tw = __builtin_amdgcn_alignbit(trail_n1, trail_w, (unsigned)sh);
-              trail_w = trail_n1; trail_n1 = trail_n2; trail_n2 = ld((tj0 >> 5) + 3);
-          }
+          const int tj0 = j0 - ws, sh = tj0 & 31, twi = tj0 >> 5;
+          advance(trail, twi >> 2);
+          const uint32_t t0 = word(trail, twi);
+          const uint32_t tw = sh ? __builtin_amdgcn_alignbit(word(trail, twi + 1), t0, (unsigned)sh) : t0;
           P.cnt += __popc(lead_w);
 #pragma unroll
           for (int i = 0; i < 32; ++i) {
@@ -299,10 +313,9 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
         const int j = j0 + jj;
         if (j >= Lmax) break;
         const int tj = j - ws;
-        if (tj > 0 && (tj & 31) == 0) {
-            trail_w = trail_n1;
-            trail_n1 = trail_n2;
-            trail_n2 = ld((tj >> 5) + 2);
+        if (tj >= 0 && ((tj & 31) == 0 || jj == 0)) {
+            advance(trail, tj >> 7);
+            trail_w = word(trail, tj >> 5);
         }
         const bool act = j < L;
         const uint32_t b = act ? ((lead_w >> (j & 31)) & 1u) : 0u;
