@@ -87,3 +87,103 @@ def test_c2_full_size_properties():
     assert (mean2.view(np.uint64) == mean.view(np.uint64)).all() and (win2.view(np.uint64) == win.view(np.uint64)).all()
     assert (passed2 == passed).all() and rep2.kept_bases == rep.kept_bases
     ctx.close()
+
+
+@pytest.mark.parametrize("short_reads", [False, True], ids=["C3-assembly", "C4-short-reads"])
+def test_kmer_mode_mid_size_properties(short_reads):
+    """BASELINE.json configs[2]/[3] (k-mer mode, `--trim --split 500` for C4) at 2x10^5 reads / 2x10^9 bases against a
+    1 Mbp reference: the oracle builds the same 16-mer set and re-scores a sample of reads bit for bit (mean, window,
+    first/last, every child); the rest is checked structurally (children ordered, disjoint, inside the read, CSR sums)."""
+    import torch
+    from filtlong_amd import _lib
+    ctx = api.Context(0)
+    dev = torch.device("cuda", 0)
+    n, ref_len = 200_000, 1_000_000
+    ref = synth.bases_read(synth.STREAM_REF, 0, 0, ref_len)
+    ks = api.Kmers(ctx)
+    oset = _oracle.KmerSet()
+    if short_reads:
+        npairs = ref_len // 5  # 40x of error-free 100 bp pairs
+        starts = (synth.mix(synth.SEED, synth.STREAM_START, np.arange(npairs, dtype=np.uint64) + np.uint64(1 << 40), 0)
+                  % np.uint64(ref_len - 450)).astype(np.int64)
+        comp = np.zeros(256, dtype=np.uint8)
+        comp[list(b"ACGT")] = list(b"TGCA")
+        r1 = [ref[s:s + 100].tobytes() for s in starts]
+        r2 = [comp[ref[s + 350:s + 450]][::-1].tobytes() for s in starts]
+        ks.add_read_fastqs([r1, r2])
+        oset.add_short_reads(r1)
+        oset.add_short_reads(r2)
+    else:
+        ks.add_assembly_fasta([ref.tobytes()])
+        oset.add_assembly([ref.tobytes()])
+    ks.finalize()
+    assert len(ks) == len(oset) > 0.9 * ref_len
+
+    lengths = synth.lengths(n)
+    offsets = np.zeros(n, dtype=np.uint64)
+    pb = C.c_uint64()
+    ctx.L.flx_plane_layout(lengths.ctypes.data, n, offsets.ctypes.data, C.byref(pb))
+    order = api.length_order(lengths)
+    d_plane = torch.empty(pb.value, dtype=torch.uint8, device=dev)
+    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    d_len = torch.from_numpy(lengths).to(dev)
+    d_ord = torch.from_numpy(order.view(np.int32)).to(dev)
+    d_ref = torch.from_numpy(ref).to(dev)
+    d_ids = torch.arange(n, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx.synth_seq_dev(synth.SEED, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ids.data_ptr(), n,
+                      d_ref.data_ptr(), ref_len)
+    pkw = dict(trim=True, split=500) if short_reads else dict()
+    params = api.make_params(**pkw)
+    cap = 4 * n
+    t = {k: torch.zeros(sz, dtype=dt, device=dev) for k, sz, dt in (
+        ("mean", n, torch.float64), ("win", n, torch.float64), ("pass", n, torch.uint8), ("first", n, torch.int32),
+        ("last", n, torch.int32), ("coff", n + 1, torch.int64), ("crng", 2 * cap, torch.int32), ("cmean", cap, torch.float64),
+        ("cwin", cap, torch.float64), ("cpass", cap, torch.uint8))}
+    torch.cuda.synchronize()
+    s = _lib.Scores()
+    s.mean_q, s.window_q, s.passed, s.first, s.last = (t["mean"].data_ptr(), t["win"].data_ptr(), t["pass"].data_ptr(),
+                                                      t["first"].data_ptr(), t["last"].data_ptr())
+    s.child_offsets, s.child_ranges, s.child_mean_q, s.child_window_q, s.child_passed = (
+        t["coff"].data_ptr(), t["crng"].data_ptr(), t["cmean"].data_ptr(), t["cwin"].data_ptr(), t["cpass"].data_ptr())
+    s.child_capacity = cap
+    rc = ctx.score_kmer_dev(ks, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n, params, s)
+    assert rc == 0
+    torch.cuda.synchronize()
+    mean, win, first, last = (t[k].cpu().numpy() for k in ("mean", "win", "first", "last"))
+    coff = t["coff"].cpu().numpy()
+    nchild = int(s.n_children)
+    crng = t["crng"].cpu().numpy()[:2 * nchild].reshape(-1, 2)
+    cmean, cwin, cpass = (t[k].cpu().numpy()[:nchild] for k in ("cmean", "cwin", "cpass"))
+
+    # structure
+    assert coff[0] == 0 and coff[-1] == nchild and (np.diff(coff) >= 0).all()
+    if not short_reads:
+        assert nchild == 0
+    else:
+        assert nchild > n // 10
+        owner = np.repeat(np.arange(n), np.diff(coff))
+        assert (crng[:, 0] >= 0).all() and (crng[:, 1] > crng[:, 0]).all() and (crng[:, 1] <= lengths[owner]).all()
+        same = owner[1:] == owner[:-1]
+        assert (crng[1:, 0][same] > crng[:-1, 1][same]).all()  # ordered, separated by a bad range
+    assert ((mean >= 0) & (mean <= 100)).all() and ((win >= 0) & (win <= 100.000001)).all()
+    cov = first >= 0
+    assert (last[cov] > first[cov]).all() and (last[cov] <= lengths[cov]).all() and (mean[~cov] == 0).all()
+
+    # sampled exactness against the oracle (same generator on the host)
+    rng = np.random.RandomState(3)
+    sample = np.unique(np.concatenate([rng.randint(0, n, 50), order[:3], order[-3:]]))
+    p = _oracle.make_params(**pkw)
+    for i in sample:
+        L = int(lengths[i])
+        seq = synth.seq_read(int(i), L, ref).tobytes()
+        w = _oracle.score_read(seq, None, p, kmerset=oset)
+        assert w["mean_q"] == mean[i] and w["window_q"] == win[i], int(i)
+        assert w["first"] == first[i] and w["last"] == last[i], int(i)
+        a, b = int(coff[i]), int(coff[i + 1])
+        assert len(w["children"]) == b - a, int(i)
+        for k, ch in enumerate(w["children"]):
+            assert w["child_ranges"][k] == (int(crng[a + k, 0]), int(crng[a + k, 1])), (int(i), k)
+            assert ch["mean_q"] == cmean[a + k] and ch["window_q"] == cwin[a + k] and ch["passed"] == cpass[a + k], (int(i), k)
+    ks.close()
+    ctx.close()
