@@ -108,6 +108,19 @@ __global__ void __launch_bounds__(256) k_add_reference(const uint8_t *bases, con
     }
 }
 
+// every set bit of the exact bitmap sets its hashed bit of the prefilter
+__global__ void __launch_bounds__(256) k_build_prefilter(const uint32_t *bm, uint64_t n_words, uint32_t *pre) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t w = bm[i];
+        while (w) {
+            const int b = __ffs(w) - 1;
+            w &= w - 1;
+            const uint32_t h = flx_prefilter_hash((uint32_t)(i << 5) | (uint32_t)b);
+            atomicOr(&pre[h >> 5], 1u << (h & 31));
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_popcount(const uint32_t *bm, uint64_t n_words, unsigned long long *out) {
     unsigned long long acc = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x)
@@ -229,6 +242,7 @@ struct flx_kmerset {
     uint32_t *present = nullptr;        // 512 MiB
     uint32_t *asm_only = nullptr;       // copy of `present` taken when the first short reads arrive (512 MiB)
     uint32_t *seen1 = nullptr, *seen2 = nullptr, *seen3 = nullptr;
+    uint32_t *prefilter = nullptr;      // 2 MiB, built at finalize (kmerset.h)
     // short-read sequences kept on the device until finalize (only replayed if Bloom candidates exist)
     struct Batch {
         uint8_t *bases;
@@ -243,6 +257,7 @@ struct flx_kmerset {
 
 bool flx_kmerset_is_final(const flx_kmerset *set) { return set->final_; }
 const uint32_t *flx_kmerset_bitmap(const flx_kmerset *set) { return set->present; }
+const uint32_t *flx_kmerset_prefilter(const flx_kmerset *set) { return set->prefilter; }
 
 extern "C" int flx_kmerset_create(flx_ctx *ctx, flx_kmerset **out) {
     if (!ctx || !out) return FLX_ERR_INVALID;
@@ -273,7 +288,7 @@ extern "C" void flx_kmerset_destroy(flx_kmerset *s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     free_batches(s);
-    for (uint32_t *p : {s->present, s->asm_only, s->seen1, s->seen2, s->seen3})
+    for (uint32_t *p : {s->present, s->asm_only, s->seen1, s->seen2, s->seen3, s->prefilter})
         if (p) (void)hipFree(p);
     delete s;
 }
@@ -526,6 +541,16 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
     FLX_HIP(ctx, hipMemcpyAsync(&sz, scr, 8, hipMemcpyDeviceToHost, st));
     FLX_HIP(ctx, hipStreamSynchronize(st));
     s->size = sz;
+    // prefilter: worth its L2 footprint while it stays sparse (expected density 1 - exp(-size / 2^24) < ~0.8)
+    const char *pf_env = getenv("FLX_KMER_PREFILTER");  // "0" disables (A/B measurements)
+    const bool pf_off = pf_env && pf_env[0] == '0';
+    if (!pf_off && sz > 0 && sz < (3ull << (kPrefilterBits - 1))) {
+        const size_t pf_bytes = (size_t)1 << (kPrefilterBits - 3);
+        FLX_HIP(ctx, hipMalloc((void **)&s->prefilter, pf_bytes));
+        FLX_HIP(ctx, hipMemsetAsync(s->prefilter, 0, pf_bytes, st));
+        hipLaunchKernelGGL(k_build_prefilter, dim3(8192), dim3(256), 0, st, s->present, kBitmapWords, s->prefilter);
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+    }
     s->final_ = true;
     return FLX_OK;
 }

@@ -42,7 +42,7 @@ constexpr int COVER_SPAN = COVER_THREADS * 16;  // positions per workgroup itera
 __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *plane, const uint64_t *offsets,
                                                               const int32_t *lengths, const uint32_t *order,
                                                               uint64_t n_reads, const uint32_t *bitmap,
-                                                              uint32_t *cov, const uint64_t *cov_off, int32_t *count,
+                                                              const uint32_t *prefilter, uint32_t *cov, const uint64_t *cov_off, int32_t *count,
                                                               int32_t *first, int32_t *last) {
     __shared__ uint32_t sh_hits[COVER_THREADS];
     __shared__ uint8_t sh_anchor[COVER_THREADS];
@@ -86,7 +86,12 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
                 // instead of 16 — the bitmap lookups are bound by the fabric's random-request rate.
                 const int ia = p0 + 15;
                 const bool a_valid = ia < L;
-                const bool a_hit = a_valid && ((bitmap[kmers[15] >> 5] >> (kmers[15] & 31)) & 1u);
+                bool a_maybe = a_valid;
+                if (a_valid && prefilter) {  // L2-resident superset filter: a clear bit answers "absent" without the far lookup
+                    const uint32_t h = flx_prefilter_hash(kmers[15]);
+                    a_maybe = (prefilter[h >> 5] >> (h & 31)) & 1u;
+                }
+                const bool a_hit = a_maybe && ((bitmap[kmers[15] >> 5] >> (kmers[15] & 31)) & 1u);
                 anchor_hit = a_hit;
                 if (a_hit) hits = 1u << 15;
             }
@@ -95,9 +100,18 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
             if (p0 < L && L >= 16) {
                 const bool left_hit = (t > 0) ? (sh_anchor[t - 1] != 0) : false;  // first thread of a span: assume a miss
                 if (!anchor_hit || !left_hit) {
-                    uint32_t words[16];
+                    uint32_t maybe = 0x7fffu;  // bit j: the 16-mer ending at p0 + j may be present
+                    if (prefilter) {
+                        uint32_t pw[15];
 #pragma unroll
-                    for (int j = 0; j < 15; ++j) words[j] = bitmap[kmers[j] >> 5];  // 15 independent lookups in flight
+                        for (int j = 0; j < 15; ++j) pw[j] = prefilter[flx_prefilter_hash(kmers[j]) >> 5];  // L2 hits, all in flight
+                        maybe = 0;
+#pragma unroll
+                        for (int j = 0; j < 15; ++j) maybe |= ((pw[j] >> (flx_prefilter_hash(kmers[j]) & 31)) & 1u) << j;
+                    }
+                    uint32_t words[15];
+#pragma unroll
+                    for (int j = 0; j < 15; ++j) words[j] = ((maybe >> j) & 1u) ? bitmap[kmers[j] >> 5] : 0u;  // independent, in flight
 #pragma unroll
                     for (int j = 0; j < 15; ++j) {
                         const int i = p0 + j;
@@ -445,7 +459,7 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
         const unsigned grid = (unsigned)std::min<uint64_t>(n_reads, 1u << 20);
         flx_time_begin(ctx, "flx_score_kmer_cover");
         hipLaunchKernelGGL(k_kmer_cover, dim3(grid), dim3(COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
-                           flx_kmerset_bitmap(set), d_cov.as<uint32_t>(), d_covoff.as<uint64_t>(), d_cnt.as<int32_t>(), first,
+                           flx_kmerset_bitmap(set), flx_kmerset_prefilter(set), d_cov.as<uint32_t>(), d_covoff.as<uint64_t>(), d_cnt.as<int32_t>(), first,
                            last);
         flx_time_end(ctx);
     }
