@@ -223,7 +223,10 @@ __device__ __forceinline__ double window_result(const FoldArgs &a, int len, int 
     return 100.0 * mn;
 }
 
-// MODE 0: parent only (no --trim/--split).  MODE 1: count children.  MODE 2: emit children.
+// MODE 0: parent only (no --trim/--split).  MODE 1: parent + count children, bit by bit.  MODE 2: emit children.
+// MODE 3: parent + count children at WORD level — a zero run can only be a bad range if it starts at position 0, reaches
+// the end of the read, or is at least --split long; with --split >= 32 (or unset) every such run crosses a 32-bit word
+// boundary, so the runs that lie inside one word never matter and the parent keeps MODE 0's branch-free steady state.
 template <int MODE>
 __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
     const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -304,7 +307,28 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
           advance(lead, wi >> 2);
           lead_w = word(lead, wi);
       }
-      if (MODE == 0 && j0 >= ws && j0 + 32 <= Lmin) {
+      if (MODE == 3 && j0 < L) {
+          const int v = min(32, L - j0);  // valid bits of this word
+          const uint32_t w = v < 32 ? (lead_w & ((1u << v) - 1u)) : lead_w;
+          if (j0 == 0 && !(w & 1u)) zs = 0;  // the read starts inside a zero run
+          if (w != 0) {
+              if (zs >= 0) {  // the run [zs, j) that reached this word ends at its first covered base
+                  const int j = j0 + __ffs(w) - 1;
+                  const bool bad = (split_set && j - zs >= split) || (trim && zs == 0);
+                  if (bad) {
+                      any_bad = true;
+                      if (zs > cs) ++nchild;
+                      cs = j;
+                  }
+                  zs = -1;
+              }
+              const int top = 32 - __clz(w);  // one past the last covered base of the word
+              if (top < v) zs = j0 + top;     // the word ends inside a new zero run
+          } else if (zs < 0) {
+              zs = j0;
+          }
+      }
+      if ((MODE == 0 || MODE == 3) && j0 >= ws && j0 + 32 <= Lmin) {
           // ---- steady state, parent only: 32 positions, every lane active, no per-bit control flow ----
           const int tj0 = j0 - ws, sh = tj0 & 31, twi = tj0 >> 5;
           advance(trail, twi >> 2);
@@ -348,7 +372,7 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
                 P.w += dl;
                 if (P.w < P.mn) P.mn = P.w;
             }
-            if (MODE != 0) {
+            if (MODE == 1 || MODE == 2) {
                 // ---- zero runs -> bad ranges -> children (src/read.cpp:89-141) ----
                 if (b == 0 && zs < 0) {
                     zs = j;
@@ -395,7 +419,7 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
         if (any_bad) emit_child(cs, end, C);
         else nchild = 0;
     }
-    if (MODE == 1) a.n_child[rid] = nchild;
+    if (MODE == 1 || MODE == 3) a.n_child[rid] = nchild;
     if (MODE != 2) {
         const double mean = 100.0 * (double)a.count[rid] / (double)L;  // exact: the qualities are 0.0 / 1.0
         const double window = window_result(a, L, P.cnt, P.mn);
@@ -506,7 +530,10 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     FLX_HIP(ctx, hipMemsetAsync(d_nchild.p, 0, (n_reads + 1) * 4, st));
     a.n_child = d_nchild.as<uint32_t>();
     flx_time_begin(ctx, "flx_score_kmer_fold");
-    hipLaunchKernelGGL(k_kmer_fold<1>, dim3(nb), dim3(256), 0, st, a);
+    if (params->split_set && params->split < 32)
+        hipLaunchKernelGGL(k_kmer_fold<1>, dim3(nb), dim3(256), 0, st, a);  // runs inside one word can be bad ranges
+    else
+        hipLaunchKernelGGL(k_kmer_fold<3>, dim3(nb), dim3(256), 0, st, a);
     flx_time_end(ctx);
     // child_offsets = exclusive scan of the counts (n + 1 entries; the last one is the total)
     hipLaunchKernelGGL(k_widen_u32_i64, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, st, n_reads + 1,
