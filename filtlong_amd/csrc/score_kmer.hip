@@ -224,6 +224,7 @@ __device__ __forceinline__ double window_result(const FoldArgs &a, int len, int 
 }
 
 // MODE 0: parent only (no --trim/--split).  MODE 1: parent + count children, bit by bit.  MODE 2: emit children.
+// MODE 4: emit children with the zero-run events found at word level and a branch-light bit loop (same condition as 3).
 // MODE 3: parent + count children at WORD level — a zero run can only be a bad range if it starts at position 0, reaches
 // the end of the read, or is at least --split long; with --split >= 32 (or unset) every such run crosses a 32-bit word
 // boundary, so the runs that lie inside one word never matter and the parent keeps MODE 0's branch-free steady state.
@@ -251,14 +252,14 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
     int zs = -1;            // start of the current zero run (-1: none)
     bool any_bad = false;
     uint32_t nchild = 0;
-    const uint64_t cbase = (MODE == 2 && live) ? a.child_offsets[rid] : 0;
+    const uint64_t cbase = ((MODE == 2 || MODE == 4) && live) ? a.child_offsets[rid] : 0;
     const bool split_set = a.p.split_set != 0;
     const bool trim = a.p.trim != 0;
     const int split = a.p.split;
 
     auto emit_child = [&](int start, int end, const Win &st) {
         if (end <= start) return;
-        if (MODE == 2) {
+        if (MODE == 2 || MODE == 4) {
             const int len = end - start;
             const double mean = 100.0 * (double)st.cnt / (double)len;
             const double window = window_result(a, len, st.cnt, st.mn);
@@ -306,6 +307,72 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
           const int wi = j0 >> 5;
           advance(lead, wi >> 2);
           lead_w = word(lead, wi);
+      }
+      if (MODE == 4) {
+          // ---- children only: events per word, then 32 predicated positions ----
+          int ev_end = -1, ev_zs = 0, snap = -1;
+          if (j0 < L) {
+              const int v = min(32, L - j0);
+              const uint32_t w = v < 32 ? (lead_w & ((1u << v) - 1u)) : lead_w;
+              if (j0 == 0 && !(w & 1u)) zs = 0;  // S is still the initial (empty) state
+              if (w != 0) {
+                  if (zs >= 0) {
+                      const int f = __ffs(w) - 1;
+                      const bool bad = (split_set && j0 + f - zs >= split) || (trim && zs == 0);
+                      if (bad) { ev_end = f; ev_zs = zs; }
+                      zs = -1;
+                  }
+                  const int top = 32 - __clz(w);
+                  if (top < v) { zs = j0 + top; snap = top; }
+              } else if (zs < 0) {
+                  zs = j0;
+                  snap = 0;
+              }
+          }
+          // trailing window of the 32 positions (positions before the read count as uncovered; they are never used,
+          // a child's trailing edge lies inside the child)
+          const int tj0 = j0 - ws;
+          uint32_t tw = 0;
+          if (tj0 > -32) {
+              const int twi = tj0 >> 5, sh = tj0 & 31;  // twi == -1 for the word that straddles position 0
+              if (twi >= 0) advance(trail, twi >> 2);
+              const uint32_t lo = twi >= 0 ? word(trail, twi) : 0u;
+              tw = sh ? __builtin_amdgcn_alignbit(word(trail, twi + 1), lo, (unsigned)sh) : lo;
+          }
+#pragma unroll
+          for (int i = 0; i < 32; ++i) {
+              const int j = j0 + i;
+              if (i == ev_end) {  // a bad range ended here: the child [cs, ev_zs) is complete, a new one starts at j
+                  any_bad = true;
+                  emit_child(cs, ev_zs, S);
+                  cs = j;
+                  C.cnt = 0;
+                  C.w = 0.0;
+                  C.mn = 0.0;
+              }
+              if (i == snap) {  // state of the current child at the start of a zero run that may turn out bad
+                  S.cnt = C.cnt;
+                  S.mn = C.mn;
+              }
+              const bool act = j < L;
+              const int k = j - cs;
+              const int ml = __builtin_amdgcn_sbfe((int)lead_w, i, 1);  // 0 or -1 (bits beyond L are 0)
+              const int mt = __builtin_amdgcn_sbfe((int)tw, i, 1);
+              C.cnt -= ml;
+              if (act && k == ws - 1) {
+                  C.w = (double)C.cnt / a.ws_d;
+                  C.mn = C.w;
+              }
+              const bool steady = act && k >= ws;
+              const int ms = steady ? -1 : 0;
+              const double dl = __hiloint2double((int)(d_hi & (unsigned)(ml & ms)), (int)(d_lo & (unsigned)(ml & ms)));
+              const double dt = __hiloint2double((int)(d_hi & (unsigned)(mt & ms)), (int)(d_lo & (unsigned)(mt & ms)));
+              C.w -= dt;  // exact no-ops outside the steady state
+              C.w += dl;
+              const double m2 = fmin(C.mn, C.w);
+              C.mn = steady ? m2 : C.mn;
+          }
+          continue;
       }
       if (MODE == 3 && j0 < L) {
           const int v = min(32, L - j0);  // valid bits of this word
@@ -420,7 +487,7 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
         else nchild = 0;
     }
     if (MODE == 1 || MODE == 3) a.n_child[rid] = nchild;
-    if (MODE != 2) {
+    if (MODE != 2 && MODE != 4) {
         const double mean = 100.0 * (double)a.count[rid] / (double)L;  // exact: the qualities are 0.0 / 1.0
         const double window = window_result(a, L, P.cnt, P.mn);
         a.mean_q[rid] = mean;
@@ -530,7 +597,10 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     FLX_HIP(ctx, hipMemsetAsync(d_nchild.p, 0, (n_reads + 1) * 4, st));
     a.n_child = d_nchild.as<uint32_t>();
     flx_time_begin(ctx, "flx_score_kmer_fold");
-    if (params->split_set && params->split < 32)
+    // FLX_KMER_FOLD=bits forces the bit-level passes (tests compare the two implementations on every read)
+    const char *fold_env = getenv("FLX_KMER_FOLD");
+    const bool bit_level = (params->split_set && params->split < 32) || (fold_env && strcmp(fold_env, "bits") == 0);
+    if (bit_level)
         hipLaunchKernelGGL(k_kmer_fold<1>, dim3(nb), dim3(256), 0, st, a);  // runs inside one word can be bad ranges
     else
         hipLaunchKernelGGL(k_kmer_fold<3>, dim3(nb), dim3(256), 0, st, a);
@@ -549,7 +619,10 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     if (total_children > 0) {
         a.child_offsets = out->child_offsets;
         flx_time_begin(ctx, "flx_score_kmer_fold");
-        hipLaunchKernelGGL(k_kmer_fold<2>, dim3(nb), dim3(256), 0, st, a);
+        if (bit_level)
+            hipLaunchKernelGGL(k_kmer_fold<2>, dim3(nb), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL(k_kmer_fold<4>, dim3(nb), dim3(256), 0, st, a);
         flx_time_end(ctx);
     }
     FLX_HIP(ctx, hipGetLastError());

@@ -150,6 +150,27 @@ def test_kmer_mode_mid_size_properties(short_reads):
     rc = ctx.score_kmer_dev(ks, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n, params, s)
     assert rc == 0
     torch.cuda.synchronize()
+    if short_reads:
+        # the word-level child passes (default) and the bit-level ones (FLX_KMER_FOLD=bits) are two implementations of
+        # src/read.cpp:86-141: they must agree on every one of the 2x10^5 reads and ~2x10^5 children
+        import os
+        word_level = {k: v.clone() for k, v in t.items()}
+        n_word = int(s.n_children)
+        os.environ["FLX_KMER_FOLD"] = "bits"
+        try:
+            for v in t.values():
+                v.zero_()
+            torch.cuda.synchronize()
+            assert ctx.score_kmer_dev(ks, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n,
+                                      params, s) == 0
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["FLX_KMER_FOLD"]
+        assert int(s.n_children) == n_word
+        for k in ("mean", "win", "pass", "first", "last", "coff"):
+            assert torch.equal(t[k].view(torch.uint8), word_level[k].view(torch.uint8)), k
+        for k, per in (("crng", 2), ("cmean", 1), ("cwin", 1), ("cpass", 1)):
+            assert torch.equal(t[k][:per * n_word].view(torch.uint8), word_level[k][:per * n_word].view(torch.uint8)), k
     mean, win, first, last = (t[k].cpu().numpy() for k in ("mean", "win", "first", "last"))
     coff = t["coff"].cpu().numpy()
     nchild = int(s.n_children)
