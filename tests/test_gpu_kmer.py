@@ -216,3 +216,27 @@ def test_long_reads_vs_oracle(be, synth):
             assert w["child_ranges"] == o["child_ranges"], (name, pkw)
             for wc, oc in zip(w["children"], o["children"]):
                 assert wc["mean_q"] == oc["mean_q"] and wc["window_q"] == oc["window_q"] and wc["passed"] == oc["passed"]
+
+
+def test_prefilter_and_fold_variants_give_identical_results(be, synth, monkeypatch):
+    """The L2 prefilter (kmerset finalize) and the word-level child passes are pure accelerations: without the prefilter
+    (FLX_KMER_PREFILTER=0, the path large sets take) and with the bit-level fold (FLX_KMER_FOLD=bits) every output field
+    of the synthetic k-mer reads is the same."""
+    reads = _cases.kmer_reads(synth["contigs"])
+    pkw = dict(trim=True, split=100)
+    base = be.score(reads, pkw, be.kmers(assembly=synth["contigs"]))
+    monkeypatch.setenv("FLX_KMER_PREFILTER", "0")
+    monkeypatch.setenv("FLX_KMER_FOLD", "bits")
+    alt = be.score(reads, pkw, be.kmers(assembly=synth["contigs"]))
+    def bits(v):  # NaN-safe, bit-exact comparison key (a zero-length read has NaN qualities)
+        if isinstance(v, float):
+            return np.float64(v).view(np.uint64).item()
+        if isinstance(v, dict):
+            return {k: bits(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [bits(x) for x in v]
+        return v
+
+    assert len(base) == len(alt)
+    for (name, _s, _q), a, b in zip(reads, base, alt):
+        assert bits(a) == bits(b), name
