@@ -16,6 +16,8 @@
 // Arithmetic: per base one 8-byte LDS lookup of Q[c] = 1 - 10^(-(c-33)/10) and two of D[c] = Q[c]/ws
 // (tables built on the host with the host libm; see flx_ctx.hip) and four dependent FP64 ops
 // (sum += Q; w -= D_old; w += D_new; min).  No pow, no division, no 8 B/base quality vector.
+#include <algorithm>
+
 #include "flx_internal.h"
 
 namespace {
@@ -44,6 +46,8 @@ struct PhredArgs {
     double *mean_q;
     double *window_q;
     uint8_t *passed;
+    unsigned int *ticket;  // ring kernel: next group of 64 reads (persistent waves)
+    unsigned int n_groups; // ceil(n_reads / 64)
 };
 
 __device__ __forceinline__ int wave_max(int v) {
@@ -197,7 +201,15 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredAr
     unsigned char *ring = rings + (size_t)wave * 64 * stride;
     unsigned char *my_row = ring + lane * stride;
 
-    const uint64_t slot = ((uint64_t)blockIdx.x * WAVES + wave) * 64 + lane;
+    // Persistent waves: one workgroup per CU for the whole launch; every wave takes the next group of 64 reads (in
+    // processing order, i.e. longest first) from a ticket counter, so a wave that finishes starts its next group at once
+    // instead of the CU draining and relaunching a whole workgroup (and the tables are staged once).
+  for (;;) {
+    unsigned int group = 0;
+    if (lane == 0) group = atomicAdd(a.ticket, 1u);
+    group = (unsigned int)__builtin_amdgcn_readfirstlane((int)group);
+    if (group >= a.n_groups) break;
+    const uint64_t slot = (uint64_t)group * 64 + lane;
     const bool live = slot < a.n_reads;
     uint32_t rid = 0;
     int L = 0;
@@ -211,7 +223,7 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredAr
     const int Lmin = wave_min(L);
     if (Lmax == 0) {
         if (live) finish_read(a, rid, L, 0.0, 0.0);
-        return;
+        continue;
     }
 
     // staging map: load m of this lane fetches piece k of read r
@@ -381,6 +393,8 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredAr
     }
 
     if (live) finish_read(a, rid, L, f.s, f.mn);
+    __builtin_amdgcn_wave_barrier();  // the ring rows are reused by the next group
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,7 +481,15 @@ int flx_launch_score_phred(flx_ctx *ctx, const uint8_t *d_plane, uint64_t plane_
         a.n_slots = (int)n_slots;
         a.stride = (int)(slots16 * 16);
         const size_t lds = (size_t)waves * ring_bytes;  // dynamic part; the tables are static LDS
-        const unsigned grid = (unsigned)((n_waves + waves - 1) / waves);
+        // persistent workgroups: as many as can be resident (LDS allows floor(budget / per-group) per CU), capped by the work
+        const unsigned per_cu = (unsigned)std::max<size_t>(1, kLdsBudget / (lds + kLutBytes));
+        const unsigned resident = (unsigned)ctx->prop.multiProcessorCount * per_cu;
+        const unsigned grid = (unsigned)std::min<uint64_t>((n_waves + waves - 1) / waves, resident);
+        void *scr;
+        FLX_CHECK(flx_scratch(ctx, 64, &scr));
+        FLX_HIP(ctx, hipMemsetAsync(scr, 0, 4, ctx->stream));
+        a.ticket = (unsigned int *)scr;
+        a.n_groups = (unsigned int)n_waves;
 #define FLX_LAUNCH_RING(W)                                                                                    \
     case W: {                                                                                                 \
         auto kern = flx_score_phred_ring<W>;                                                                  \
@@ -490,6 +512,8 @@ int flx_launch_score_phred(flx_ctx *ctx, const uint8_t *d_plane, uint64_t plane_
     } else {
         a.n_slots = 0;
         a.stride = 0;
+        a.ticket = nullptr;
+        a.n_groups = 0;
         const unsigned grid = (unsigned)((n_reads + 255) / 256);
         flx_time_begin(ctx, "flx_score_phred_direct");
         hipLaunchKernelGGL(flx_score_phred_direct, dim3(grid), dim3(256), 0, ctx->stream, a);
