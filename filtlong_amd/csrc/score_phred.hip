@@ -277,6 +277,7 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredAr
     __builtin_amdgcn_wave_barrier();
 
     int lslot = 0;      // ring slot of the current round
+    uint4 xc = make_uint4(0, 0, 0, 0);  // last trailing ring piece of the previous steady round
     int tro = -1;       // ring byte offset of the trailing edge of the NEXT body piece; -1 = not tracking
     int tro_pos = -1;   // stream position tro belongs to
 
@@ -291,23 +292,32 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_ring(const PhredAr
 
         if (r_hi <= Lmin && r_lo >= ws) {
             // ---------------- whole round in the steady state ----------------
-            if (tro_pos != r_lo - ws) tro = ring_off(r_lo - ws);
+            const bool chained = tro_pos == r_lo - ws;  // the previous round was a steady one too
+            if (!chained) tro = ring_off(r_lo - ws);
             uint4 lead[PPR];
 #pragma unroll
             for (int kk = 0; kk < PPR; ++kk) lead[kk] = *reinterpret_cast<const uint4 *>(lead_p + kk * 16);
             // Trailing bytes of the round: PPR + 1 ALIGNED 16-byte ring pieces (conflict-free b128 rows), then a
             // funnel shift by the constant (tro & 15).  Dword-granular reads would be 4-way bank conflicted
-            // because every row stride is a multiple of 16 bytes.
+            // because every row stride is a multiple of 16 bytes.  The last piece of a round is the first of the
+            // next one (the ring write in between touches the slot behind it), so a chained round reads only PPR.
             uint32_t x[(PPR + 1) * 4];
             {
                 int o = tro & ~15;
-#pragma unroll
-                for (int kk = 0; kk <= PPR; ++kk) {
+                if (chained) {
+                    x[0] = xc.x; x[1] = xc.y; x[2] = xc.z; x[3] = xc.w;
+                } else {
                     const uint4 v = *reinterpret_cast<const uint4 *>(my_row + o);
-                    x[4 * kk + 0] = v.x; x[4 * kk + 1] = v.y; x[4 * kk + 2] = v.z; x[4 * kk + 3] = v.w;
+                    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+                }
+#pragma unroll
+                for (int kk = 1; kk <= PPR; ++kk) {
                     o += 16;
                     if (o >= ring_len) o -= ring_len;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(my_row + o);
+                    x[4 * kk + 0] = v.x; x[4 * kk + 1] = v.y; x[4 * kk + 2] = v.z; x[4 * kk + 3] = v.w;
                 }
+                xc = make_uint4(x[4 * PPR + 0], x[4 * PPR + 1], x[4 * PPR + 2], x[4 * PPR + 3]);
             }
             uint32_t tw[PPR][4];
             const uint32_t bsh = (uint32_t)tro & 3u;
