@@ -6,6 +6,7 @@ reference: ``Kmers`` (src/kmers.h:28-56), per-read scoring = the batched ``Read:
 All compute happens in the HIP library; there is no CPU fallback here.
 """
 import ctypes as C
+import traceback
 import weakref
 
 import numpy as np
@@ -208,11 +209,9 @@ class Context:
 
         def _cb(_user, buf, count):
             try:
-                import numpy as _np
-                reduce(_np.ctypeslib.as_array(buf, shape=(int(count),)))
+                reduce(np.ctypeslib.as_array(buf, shape=(int(count),)))
                 return 0
             except Exception:  # an exception must not unwind through the C frames
-                import traceback
                 traceback.print_exc()
                 return 1
         cb = _lib.ALLREDUCE_FN(_cb) if reduce is not None else C.cast(None, _lib.ALLREDUCE_FN)
