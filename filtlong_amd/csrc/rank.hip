@@ -285,7 +285,7 @@ struct Shard {
     int rank = 0, world = 1;
     bool sharded() const { return reduce != nullptr; }
     int sum(flx_ctx *ctx, uint64_t *buf, uint64_t count) const {
-        if (!reduce) return FLX_OK;
+        if (!reduce || count == 0) return FLX_OK;  // (an empty exchange is empty on every rank)
         if (reduce(user, buf, count) != 0) return flx_fail(ctx, FLX_ERR_STATE, "all-reduce callback failed");
         return FLX_OK;
     }
