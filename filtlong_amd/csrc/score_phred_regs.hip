@@ -1,0 +1,435 @@
+// score_phred_regs.hip — Phred-only per-read scoring, register-history kernel (the default fast path).
+//
+// Same arithmetic as score_phred.hip (reference src/read.cpp:35-39, 208-236, 64-73; one lane folds one read strictly left
+// to right, tables built with the host libm), different data movement:
+//
+//   * the last `window_size` bytes of every read live in the lane's REGISTERS (a ring of 16-byte pieces, statically
+//     indexed: the loop is unrolled over one ring revolution), not in LDS.  The register file is the largest on-chip
+//     store of a CU (512 KiB vs 160 KiB of LDS); with the history out of LDS a wave needs 4 KiB of LDS instead of
+//     21 KiB, so 12-16 waves fit a CU instead of 7 — and ds_read_b64 table gathers only reach the LDS's rate
+//     (1.0 ns per wave-gather per CU instead of 1.6) from 3-4 waves per SIMD (profiles/r02_microbench.txt).
+//   * the plane is still read exactly once: per round a wave moves 64 contiguous bytes of each of its 64 reads
+//     HBM -> LDS with four `global_load_lds_dwordx4` (no staging VGPRs, no ds_write), into one 4 KiB slot whose rows are
+//     rotated so that every lane then pulls its own 64 bytes with four conflict-free ds_read_b128.  The next
+//     round's DMA is issued as soon as the slot has been read, a whole round of compute ahead.
+//   * per base: 2 address ops, 3 ds_read_b64 gathers, 3 v_add_f64, 1 v_min_f64 — written as asm statements of
+//     4 bases (12 gathers issued back to back, the FP64 chain follows as data arrives); left to hipcc the unrolled
+//     loop gets its gathers hoisted away from the chain and spills.
+//   * optional bank-private tables (FLX_PHRED_TABLES=private): every table entry is replicated once per bank pair
+//     (lane l reads copy l % 32), so a gather never has a bank conflict whatever the quality distribution is
+//     (plain tables: entries e and e+32 collide; a wide Phred range costs up to 1.5x per gather).  128 entries per
+//     table; a read containing a byte >= 128 (not a FASTQ character) is flagged and re-scored by the direct kernel.
+//
+// The window size enters as A = ws / 16 (template parameter: it fixes which ring pieces hold the trailing edge)
+// and B = ws % 16 (run time: a byte funnel).
+#include <algorithm>
+
+#include "flx_internal.h"
+#include "score_phred_common.h"
+
+using namespace flx_phred;
+
+namespace {
+
+template <bool PRIV>
+struct Tab {
+    static constexpr int ROW = PRIV ? 256 : 8;              // bytes between consecutive entries
+    static constexpr int ENTRIES = PRIV ? 129 : LUT_PAD;    // rows per table (incl. the all-zero "no base" entry)
+    static constexpr int BYTES = ROW * ENTRIES;
+    static constexpr int QOFF = 0;                           // LDS byte address of the Q table (dynamic LDS starts at 0)
+    static constexpr int DOFF = BYTES;                       // ... of the D = Q / ws table
+    static constexpr int ZIDX = PRIV ? 128 : 256;            // the entry that holds 0.0 in both tables
+    static constexpr int SLOT0 = 2 * BYTES;                  // first DMA slot (multiple of 16)
+};
+
+// table address of byte SEL of dword x
+template <bool PRIV, int SEL>
+__device__ __forceinline__ uint32_t tab_addr(uint32_t x, uint32_t laneoff) {
+    if (PRIV) {
+        // v_perm_b32: D.b0 = laneoff.b0 (copy select, < 256), D.b1 = x.b[SEL] (entry * 256), D.b2 = D.b3 = 0
+        constexpr uint32_t sel = 0x0c0c0000u | ((4u + SEL) << 8);
+        return __builtin_amdgcn_perm(x, laneoff, sel);
+    }
+    return lut_addr(x, SEL);  // byte * 8, one SDWA shift
+}
+
+// ---- the FP64 folds as asm statements (see the header comment) ---------------------------------------------
+// steady state, 4 bases: s += Q[new]; w -= D[old]; w += D[new]; mn = min(mn, w)     (src/read.cpp:210, 228-231)
+template <int QOFF, int DOFF>
+__device__ __forceinline__ void fold4(uint32_t aj0, uint32_t aj1, uint32_t aj2, uint32_t aj3, uint32_t ai0, uint32_t ai1,
+                                      uint32_t ai2, uint32_t ai3, double &s, double &w, double &mn) {
+    double q0, i0, j0, q1, i1, j1, q2, i2, j2, q3, i3, j3;
+    asm volatile(
+        "ds_read_b64 %3, %15 offset:%23\n\tds_read_b64 %4, %19 offset:%24\n\tds_read_b64 %5, %15 offset:%24\n\t"
+        "ds_read_b64 %6, %16 offset:%23\n\tds_read_b64 %7, %20 offset:%24\n\tds_read_b64 %8, %16 offset:%24\n\t"
+        "ds_read_b64 %9, %17 offset:%23\n\tds_read_b64 %10, %21 offset:%24\n\tds_read_b64 %11, %17 offset:%24\n\t"
+        "ds_read_b64 %12, %18 offset:%23\n\tds_read_b64 %13, %22 offset:%24\n\tds_read_b64 %14, %18 offset:%24\n\t"
+        "s_waitcnt lgkmcnt(11)\n\tv_add_f64 %0, %0, %3\n\t"
+        "s_waitcnt lgkmcnt(10)\n\tv_add_f64 %1, %1, -%4\n\t"
+        "s_waitcnt lgkmcnt(9)\n\tv_add_f64 %1, %1, %5\n\tv_min_f64 %2, %2, %1\n\t"
+        "s_waitcnt lgkmcnt(8)\n\tv_add_f64 %0, %0, %6\n\t"
+        "s_waitcnt lgkmcnt(7)\n\tv_add_f64 %1, %1, -%7\n\t"
+        "s_waitcnt lgkmcnt(6)\n\tv_add_f64 %1, %1, %8\n\tv_min_f64 %2, %2, %1\n\t"
+        "s_waitcnt lgkmcnt(5)\n\tv_add_f64 %0, %0, %9\n\t"
+        "s_waitcnt lgkmcnt(4)\n\tv_add_f64 %1, %1, -%10\n\t"
+        "s_waitcnt lgkmcnt(3)\n\tv_add_f64 %1, %1, %11\n\tv_min_f64 %2, %2, %1\n\t"
+        "s_waitcnt lgkmcnt(2)\n\tv_add_f64 %0, %0, %12\n\t"
+        "s_waitcnt lgkmcnt(1)\n\tv_add_f64 %1, %1, -%13\n\t"
+        "s_waitcnt lgkmcnt(0)\n\tv_add_f64 %1, %1, %14\n\tv_min_f64 %2, %2, %1"
+        : "+v"(s), "+v"(w), "+v"(mn), "=&v"(q0), "=&v"(i0), "=&v"(j0), "=&v"(q1), "=&v"(i1), "=&v"(j1), "=&v"(q2), "=&v"(i2),
+          "=&v"(j2), "=&v"(q3), "=&v"(i3), "=&v"(j3)
+        : "v"(aj0), "v"(aj1), "v"(aj2), "v"(aj3), "v"(ai0), "v"(ai1), "v"(ai2), "v"(ai3), "i"(QOFF), "i"(DOFF));
+}
+// positions before the first full window, 4 bases: s += Q[new]
+template <int QOFF>
+__device__ __forceinline__ void head4(uint32_t aj0, uint32_t aj1, uint32_t aj2, uint32_t aj3, double &s) {
+    double q0, q1, q2, q3;
+    asm volatile(
+        "ds_read_b64 %1, %5 offset:%9\n\tds_read_b64 %2, %6 offset:%9\n\tds_read_b64 %3, %7 offset:%9\n\t"
+        "ds_read_b64 %4, %8 offset:%9\n\t"
+        "s_waitcnt lgkmcnt(3)\n\tv_add_f64 %0, %0, %1\n\ts_waitcnt lgkmcnt(2)\n\tv_add_f64 %0, %0, %2\n\t"
+        "s_waitcnt lgkmcnt(1)\n\tv_add_f64 %0, %0, %3\n\ts_waitcnt lgkmcnt(0)\n\tv_add_f64 %0, %0, %4"
+        : "+v"(s), "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+        : "v"(aj0), "v"(aj1), "v"(aj2), "v"(aj3), "i"(QOFF));
+}
+// single bases, for the one piece that contains position window_size
+template <int QOFF>
+__device__ __forceinline__ void head1(uint32_t aj, double &s) {
+    double q;
+    asm volatile("ds_read_b64 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)\n\tv_add_f64 %0, %0, %1" : "+v"(s), "=&v"(q) : "v"(aj), "i"(QOFF));
+}
+template <int QOFF, int DOFF>
+__device__ __forceinline__ void fold1(uint32_t aj, uint32_t ai, double &s, double &w, double &mn) {
+    double q, i, j;
+    asm volatile(
+        "ds_read_b64 %3, %6 offset:%8\n\tds_read_b64 %4, %7 offset:%9\n\tds_read_b64 %5, %6 offset:%9\n\t"
+        "s_waitcnt lgkmcnt(2)\n\tv_add_f64 %0, %0, %3\n\ts_waitcnt lgkmcnt(1)\n\tv_add_f64 %1, %1, -%4\n\t"
+        "s_waitcnt lgkmcnt(0)\n\tv_add_f64 %1, %1, %5\n\tv_min_f64 %2, %2, %1"
+        : "+v"(s), "+v"(w), "+v"(mn), "=&v"(q), "=&v"(i), "=&v"(j)
+        : "v"(aj), "v"(ai), "i"(QOFF), "i"(DOFF));
+}
+
+// LDS-DMA: 16 bytes per lane from each lane's own global address to LDS address lds_dst + lane * 16
+// (`lds_dst` wave-uniform).  M0 holds the LDS base and is compiler-reserved: set and restored in one statement.
+__device__ __forceinline__ void dma16(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// bytes [16 - B, 32 - B) of the 32 bytes (p0 : p1), B = ws % 16:  fD = (16 - B) / 4, fsh = (16 - B) % 4
+__device__ __forceinline__ void funnel(const uint32_t (&p0)[4], const uint32_t (&p1)[4], int fD, uint32_t fsh, uint32_t (&tw)[4]) {
+    const uint32_t x[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#define FLX_FUN(D) _Pragma("unroll") for (int d = 0; d < 4; ++d) tw[d] = __builtin_amdgcn_alignbyte(x[(D) + d + 1], x[(D) + d], fsh);
+    switch (fD) {  // wave-uniform and constant for the whole launch
+        case 0: FLX_FUN(0) break;
+        case 1: FLX_FUN(1) break;
+        case 2: FLX_FUN(2) break;
+        case 3: FLX_FUN(3) break;
+        default: tw[0] = x[4]; tw[1] = x[5]; tw[2] = x[6]; tw[3] = x[7]; break;  // B == 0
+    }
+#undef FLX_FUN
+}
+
+template <int A, bool PRIV, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) flx_score_phred_regs(const PhredArgs a) {
+    using T = Tab<PRIV>;
+    constexpr int R = ((A + 5 + 3) / 4) * 4;  // ring pieces (16 bytes each): a multiple of the 4 pieces per round, >= A + 5
+    constexpr int RR = R / 4;                 // ring rounds = unroll factor of the main loop
+    constexpr int H = (A + 1 + 3) / 4;        // prologue rounds: they cover pieces 0..A (everything up to position ws)
+    static_assert(H <= RR, "prologue must fit one ring revolution");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // tables (dynamic LDS starts at address 0: this kernel has no static LDS, so the table bases fold into the ds_read
+    // offset fields as compile-time constants)
+    if (PRIV) {
+        for (int i = threadIdx.x; i < 129 * 32; i += WAVES * 64) {
+            const int e = i >> 5;
+            const double q = e < 128 ? a.lut_q[e] : 0.0, d = e < 128 ? a.lut_d[e] : 0.0;
+            *reinterpret_cast<double *>(smem + T::QOFF + i * 8) = q;
+            *reinterpret_cast<double *>(smem + T::DOFF + i * 8) = d;
+        }
+    } else {
+        for (int i = threadIdx.x; i < 257; i += WAVES * 64) {
+            *reinterpret_cast<double *>(smem + T::QOFF + i * 8) = a.lut_q[i];
+            *reinterpret_cast<double *>(smem + T::DOFF + i * 8) = a.lut_d[i];
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    unsigned char *slot = smem + T::SLOT0 + wave * 4096;
+    const uint32_t slot_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(T::SLOT0 + wave * 4096));
+    // Slot layout: row of 64 bytes per read (row = lane that owns the read), the four 16-byte pieces of row r stored
+    // rotated by r >> 2, so that the ds_read_b128 lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... touch 16
+    // distinct bank quads (MI355X_MICROARCH.md §LDS).  The DMA lands lane-linear (lane l -> slot + 1024 m + 16 l), so
+    // the rotation is applied to the SOURCE address: DMA m, lane l carries piece ((l & 3) - (l >> 4)) & 3 of read
+    // 16 m + (l >> 2).
+    const unsigned char *my_row = slot + lane * 64;
+    const int rot = lane >> 2;
+    const uint32_t laneoff = (uint32_t)(lane & 31) * 8u;
+    const uint32_t zaddr = PRIV ? (uint32_t)(T::ZIDX * T::ROW) + laneoff : (uint32_t)(T::ZIDX * T::ROW);
+    const int ws = a.ws;
+    const int B = ws & 15;
+    const int fD = (16 - B) >> 2;
+    const uint32_t fsh = (uint32_t)(16 - B) & 3u;
+    const double ws_d = a.ws_d;
+
+  for (;;) {
+    unsigned int group = 0;
+    if (lane == 0) group = atomicAdd(a.ticket, 1u);
+    group = (unsigned int)__builtin_amdgcn_readfirstlane((int)group);
+    if (group >= a.n_groups) break;
+    const uint64_t gslot = (uint64_t)group * 64 + lane;
+    const bool live = gslot < a.n_reads;
+    uint32_t rid = 0;
+    int L = 0;
+    uint64_t base = 0;
+    if (live) {
+        rid = a.order ? a.order[gslot] : (uint32_t)gslot;
+        L = a.lengths[rid];
+        base = a.offsets[rid];
+    }
+    const int Lmax = wave_max(L);
+    const int Lmin = wave_min(L);
+    if (Lmax == 0) {
+        if (live) finish_read(a, rid, L, 0.0, 0.0);
+        continue;
+    }
+    const int n_rounds = (Lmax + 63) >> 6;
+
+    // DMA map of this lane: for m = 0..3 piece `dq` of read 16 m + (lane >> 2)
+    const int dq = ((lane & 3) - (lane >> 4)) & 3;
+    const uint8_t *gsrc[4];
+    int lim[4];  // the piece exists in round r iff 64 r < lim
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int r = m * 16 + (lane >> 2);
+        const uint32_t lo = __shfl((uint32_t)base, r, 64);
+        const uint32_t hi = __shfl((uint32_t)(base >> 32), r, 64);
+        gsrc[m] = a.plane + ((((uint64_t)hi << 32) | lo) + (uint64_t)(dq * 16));
+        lim[m] = ((__shfl(L, r, 64) + 15) & ~15) - dq * 16;
+    }
+    auto issue_dma = [&](int r) {  // round r of the current group -> the slot (whose previous content has been read)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int o = r * 64;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (o < lim[m]) dma16(gsrc[m] + o, slot_lds + m * 1024);
+    };
+
+    uint32_t ring[R][4];
+#pragma unroll
+    for (int i = 0; i < R; ++i) ring[i][0] = ring[i][1] = ring[i][2] = ring[i][3] = 0;
+    double s = 0.0, w = 0.0, mn = 0.0;
+    uint32_t bad = 0;
+
+    auto load_round = [&](int t0) {  // the slot's 4 pieces -> ring[t0 .. t0 + 3]
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(my_row + (((k + rot) & 3) << 4));
+            ring[t0 + k][0] = v.x; ring[t0 + k][1] = v.y; ring[t0 + k][2] = v.z; ring[t0 + k][3] = v.w;
+            if (PRIV) bad |= v.x | v.y | v.z | v.w;
+        }
+    };
+    // addresses of the 4 bases of dword d; lanes whose read has ended look up the zero entry instead (exact no-op)
+    auto addr4 = [&](uint32_t x, bool masked, int rem, int k0, uint32_t (&o)[4]) {
+        o[0] = tab_addr<PRIV, 0>(x, laneoff);
+        o[1] = tab_addr<PRIV, 1>(x, laneoff);
+        o[2] = tab_addr<PRIV, 2>(x, laneoff);
+        o[3] = tab_addr<PRIV, 3>(x, laneoff);
+        if (masked) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (k0 + i) < rem ? o[i] : zaddr;
+        }
+    };
+    auto head_piece = [&](const uint32_t (&lw)[4], int Tp) {  // all 16 positions < window_size
+        const bool masked = 16 * (Tp + 1) > Lmin;
+        const int rem = L - 16 * Tp;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t aj[4];
+            addr4(lw[d], masked, rem, 4 * d, aj);
+            head4<T::QOFF>(aj[0], aj[1], aj[2], aj[3], s);
+        }
+    };
+    auto steady_piece = [&](const uint32_t (&lw)[4], const uint32_t (&p0)[4], const uint32_t (&p1)[4], int Tp) {
+        const bool masked = 16 * (Tp + 1) > Lmin;
+        const int rem = L - 16 * Tp;
+        uint32_t tw[4];
+        funnel(p0, p1, fD, fsh, tw);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t aj[4], ai[4];
+            addr4(lw[d], masked, rem, 4 * d, aj);
+            addr4(tw[d], masked, rem, 4 * d, ai);
+            fold4<T::QOFF, T::DOFF>(aj[0], aj[1], aj[2], aj[3], ai[0], ai[1], ai[2], ai[3], s, w, mn);
+        }
+    };
+    auto boundary_piece = [&](const uint32_t (&lw)[4], const uint32_t (&p0)[4], const uint32_t (&p1)[4], int Tp) {
+        // piece A: positions 16 A + k; k < B belongs to the first window, k == B - 1 completes it (src/read.cpp:219-224)
+        const int rem = L - 16 * Tp;
+        uint32_t tw[4];
+        funnel(p0, p1, fD, fsh, tw);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t aj[4], ai[4];
+            addr4(lw[d], true, rem, 4 * d, aj);
+            addr4(tw[d], true, rem, 4 * d, ai);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = 4 * d + i;
+                if (k < B) head1<T::QOFF>(aj[i], s);
+                else fold1<T::QOFF, T::DOFF>(aj[i], ai[i], s, w, mn);
+                if (k == B - 1) {
+                    w = s / ws_d;
+                    mn = w;
+                }
+            }
+        }
+    };
+
+    issue_dma(0);
+
+    // ---- prologue: rounds 0 .. H-1 hold pieces 0 .. A (static piece numbers) ------------------------------
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        if (h >= n_rounds) goto done;
+        load_round(4 * h);
+        if (h + 1 < n_rounds) issue_dma(h + 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int Tp = 4 * h + k;  // compile-time after unrolling
+            if (16 * Tp >= Lmax) continue;
+            if (Tp < A) {
+                head_piece(ring[Tp], Tp);
+                if (Tp == A - 1 && B == 0) {  // window_size is a multiple of 16: the first window ends with this piece
+                    w = s / ws_d;
+                    mn = w;
+                }
+            } else if (Tp == A) {
+                boundary_piece(ring[Tp], ring[(Tp + R - A - 1) % R], ring[(Tp + R - A) % R], Tp);
+            } else {
+                steady_piece(ring[Tp], ring[(Tp + R - A - 1) % R], ring[(Tp + R - A) % R], Tp);
+            }
+        }
+    }
+    // ---- main loop: one ring revolution per iteration, starting at ring round H % RR -------------------------
+    for (int rb = H;; rb += RR) {
+#pragma unroll
+        for (int u = 0; u < RR; ++u) {
+            const int r = rb + u;
+            if (r >= n_rounds) goto done;
+            const int sr = (H + u) % RR;  // ring round (compile-time)
+            load_round(4 * sr);
+            if (r + 1 < n_rounds) issue_dma(r + 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = 4 * sr + k;  // ring piece (compile-time)
+                const int Tp = 4 * r + k;  // stream piece
+                if (16 * Tp >= Lmax) break;
+                steady_piece(ring[t], ring[(t + R - A - 1) % R], ring[(t + R - A) % R], Tp);
+            }
+        }
+    }
+done:
+    if (live) {
+        finish_read(a, rid, L, s, mn);
+        if (PRIV && (bad & 0x80808080u)) a.redo_list[atomicAdd(a.redo_count, 1u)] = rid;
+    }
+  }
+}
+
+// reads flagged by the bank-private variant (a byte >= 128): exact re-scoring, one lane per read
+__global__ void __launch_bounds__(256) flx_score_phred_redo(const PhredArgs a) {
+    __shared__ double lq[LUT_PAD];
+    __shared__ double ld[LUT_PAD];
+    for (int i = threadIdx.x; i < 257; i += 256) {
+        lq[i] = a.lut_q[i];
+        ld[i] = a.lut_d[i];
+    }
+    __syncthreads();
+    const unsigned int n = *a.redo_count;
+    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t rid = a.redo_list[i];
+        const int L = a.lengths[rid];
+        const uint8_t *q = a.plane + a.offsets[rid];
+        const int ws = a.ws;
+        double s = 0.0, w = 0.0, mn = 0.0;
+        const int head = L < ws ? L : ws;
+        for (int j = 0; j < head; ++j) s += lq[q[j]];
+        if (L > ws) {
+            w = s / a.ws_d;
+            mn = w;
+            for (int j = ws; j < L; ++j) {
+                const uint32_t cj = q[j], ci = q[j - ws];
+                s += lq[cj];
+                w -= ld[ci];
+                w += ld[cj];
+                if (w < mn) mn = w;
+            }
+        }
+        finish_read(a, rid, L, s, mn);
+    }
+}
+
+template <int A, bool PRIV, int WAVES>
+int launch_one(flx_ctx *ctx, PhredArgs &a) {
+    using T = Tab<PRIV>;
+    auto kern = flx_score_phred_regs<A, PRIV, WAVES>;
+    // one persistent workgroup per CU; asking for more than half of the LDS keeps a second one off the CU
+    const size_t lds = std::max<size_t>((size_t)T::SLOT0 + (size_t)WAVES * 4096, 84 * 1024);
+    FLX_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint64_t per_block = (uint64_t)WAVES;
+    const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)a.n_groups + per_block - 1) / per_block,
+                                                       (uint64_t)ctx->prop.multiProcessorCount);
+    flx_time_begin(ctx, PRIV ? "flx_score_phred_regs_private" : "flx_score_phred_regs");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, ctx->stream, a);
+    flx_time_end(ctx);
+    if (PRIV) {
+        flx_time_begin(ctx, "flx_score_phred_redo");
+        hipLaunchKernelGGL(flx_score_phred_redo, dim3(256), dim3(256), 0, ctx->stream, a);
+        flx_time_end(ctx);
+    }
+    FLX_HIP(ctx, hipGetLastError());
+    return FLX_OK;
+}
+
+#ifndef FLX_REGS_WAVES
+#define FLX_REGS_WAVES 12
+#endif
+
+}  // namespace
+
+int flx_launch_score_phred_regs(flx_ctx *ctx, PhredArgs a, bool *launched) {
+    *launched = false;
+    const int A = a.ws / 16;
+    const char *env = getenv("FLX_PHRED_TABLES");  // "plain" (default) | "private"
+    const bool priv = env && strcmp(env, "private") == 0;
+    // scratch: [0,4) ticket, [4,8) redo count, [64, 64 + 4 n) redo list
+    void *scr;
+    FLX_CHECK(flx_scratch(ctx, 64 + (priv ? a.n_reads * 4 : 0), &scr));
+    a.ticket = (unsigned int *)scr;
+    a.redo_count = (unsigned int *)scr + 1;
+    a.redo_list = (uint32_t *)((char *)scr + 64);
+    a.n_groups = (unsigned int)((a.n_reads + 63) / 64);
+#define FLX_REGS_CASE(AA)                                                                  \
+    case AA:                                                                               \
+        FLX_HIP(ctx, hipMemsetAsync(scr, 0, 8, ctx->stream));                              \
+        if (priv) FLX_CHECK((launch_one<AA, true, FLX_REGS_WAVES>(ctx, a)));               \
+        else FLX_CHECK((launch_one<AA, false, FLX_REGS_WAVES>(ctx, a)));                   \
+        *launched = true;                                                                  \
+        break;
+    switch (A) {
+        FLX_REGS_CASE(15)
+        default: break;
+    }
+#undef FLX_REGS_CASE
+    return FLX_OK;
+}
