@@ -208,6 +208,9 @@ extern "C" int flx_plane_layout(const int32_t *lengths, uint64_t n_reads, uint64
     uint64_t off = 0;
     for (uint64_t i = 0; i < n_reads; ++i) {
         if (lengths[i] < 0) return FLX_ERR_INVALID;
+        // Reads start 16-byte aligned (the kernels' only requirement); reads of at least 1 KiB start on a 128-byte line, so
+        // that the Phred kernel's 128-byte chunks are whole lines (each line crosses the fabric exactly once; < 6 % padding).
+        if (lengths[i] >= 1024) off = (off + 127u) & ~(uint64_t)127u;
         if (offsets) offsets[i] = off;
         off += ((uint64_t)lengths[i] + 15u) & ~(uint64_t)15u;
     }

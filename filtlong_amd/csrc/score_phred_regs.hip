@@ -8,10 +8,10 @@
 //     store of a CU (512 KiB vs 160 KiB of LDS); with the history out of LDS a wave needs 4 KiB of LDS instead of
 //     21 KiB, so 12-16 waves fit a CU instead of 7 — and ds_read_b64 table gathers only reach the LDS's rate
 //     (1.0 ns per wave-gather per CU instead of 1.6) from 3-4 waves per SIMD (profiles/r02_microbench.txt).
-//   * the plane is still read exactly once: per round a wave moves 64 contiguous bytes of each of its 64 reads
-//     HBM -> LDS with four `global_load_lds_dwordx4` (no staging VGPRs, no ds_write), into one 4 KiB slot whose rows are
-//     rotated so that every lane then pulls its own 64 bytes with four conflict-free ds_read_b128.  The next
-//     round's DMA is issued as soon as the slot has been read, a whole round of compute ahead.
+//   * the plane is still read exactly once: per 128 bases a wave moves one 128-byte line of each of its 64 reads
+//     HBM -> LDS with eight `global_load_lds_dwordx4` (no staging VGPRs, no ds_write), into one 8 KiB slot whose rows
+//     are rotated so that every lane then pulls its own bytes with conflict-free ds_read_b128.  The next chunk's DMA
+//     is issued as soon as the slot has been read, a whole round (64 bases per lane) of compute ahead.
 //   * per base: 2 address ops, 3 ds_read_b64 gathers, 3 v_add_f64, 1 v_min_f64 — written as asm statements of
 //     4 bases (12 gathers issued back to back, the FP64 chain follows as data arrives); left to hipcc the unrolled
 //     loop gets its gathers hoisted away from the chain and spills.
@@ -139,6 +139,7 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_regs(const PhredAr
     constexpr int R = ((A + 5 + 3) / 4) * 4;  // ring pieces (16 bytes each): a multiple of the 4 pieces per round, >= A + 5
     constexpr int RR = R / 4;                 // ring rounds = unroll factor of the main loop
     constexpr int H = (A + 1 + 3) / 4;        // prologue rounds: they cover pieces 0..A (everything up to position ws)
+    constexpr int SLOT_BYTES = 8192;          // LDS per wave: one 128-byte chunk of each of its 64 reads
     static_assert(H <= RR, "prologue must fit one ring revolution");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -161,13 +162,17 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_regs(const PhredAr
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    unsigned char *slot = smem + T::SLOT0 + wave * 4096;
-    const uint32_t slot_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(T::SLOT0 + wave * 4096));
-    // Slot layout: row of 64 bytes per read (row = lane that owns the read), the four 16-byte pieces of row r stored
-    // rotated by r >> 2, so that the ds_read_b128 lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... touch 16
-    // distinct bank quads (MI355X_MICROARCH.md §LDS).  The DMA lands lane-linear (lane l -> slot + 1024 m + 16 l), so
-    // the rotation is applied to the SOURCE address: DMA m, lane l carries piece ((l & 3) - (l >> 4)) & 3 of read
-    // 16 m + (l >> 2).
+    unsigned char *slot = smem + T::SLOT0 + wave * SLOT_BYTES;
+    const uint32_t slot_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(T::SLOT0 + wave * SLOT_BYTES));
+    // Slot layout: two halves of 4 KiB, half h holding bytes [64 h, 64 h + 64) of the current 128-byte chunk of every
+    // read as a row of 64 bytes (row = lane that owns the read), the four 16-byte pieces of row r stored rotated by
+    // r >> 2, so that the ds_read_b128 lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... touch 16 distinct bank
+    // quads (MI355X_MICROARCH.md §LDS).  The DMA lands lane-linear (lane l -> slot + 1024 m + 16 l), so the rotation is
+    // applied to the SOURCE address: DMA m (0..7), lane l carries piece ((l & 3) - (l >> 4)) & 3 of half m >> 2 of
+    // read 16 (m & 3) + (l >> 2).  A chunk is one whole 128-byte line when the read starts 128-byte aligned
+    // (flx_plane_layout does that): both halves of a line are requested back to back, so the line crosses the fabric
+    // once.  (With 64-byte chunks the second half of a line was requested a whole round later, when the L2 — 4 MiB per
+    // XCD for 32 CUs x 768 reads — had usually dropped it: FETCH_SIZE 1.8x the bytes, profiles/r02_*.)
     const unsigned char *my_row = slot + lane * 64;
     const int rot = lane >> 2;
     const uint32_t laneoff = (uint32_t)(lane & 31) * 8u;
@@ -201,10 +206,10 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_regs(const PhredAr
     }
     const int n_rounds = (Lmax + 63) >> 6;
 
-    // DMA map of this lane: for m = 0..3 piece `dq` of read 16 m + (lane >> 2)
+    // DMA map of this lane: for m = 0..7 piece `dq` of half m >> 2 of read 16 (m & 3) + (lane >> 2)
     const int dq = ((lane & 3) - (lane >> 4)) & 3;
     const uint8_t *gsrc[4];
-    int lim[4];  // the piece exists in round r iff 64 r < lim
+    int lim[4];  // the piece exists at stream offset o (a multiple of 64) iff o < lim
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int r = m * 16 + (lane >> 2);
@@ -213,12 +218,20 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_regs(const PhredAr
         gsrc[m] = a.plane + ((((uint64_t)hi << 32) | lo) + (uint64_t)(dq * 16));
         lim[m] = ((__shfl(L, r, 64) + 15) & ~15) - dq * 16;
     }
-    auto issue_dma = [&](int r) {  // round r of the current group -> the slot (whose previous content has been read)
+    auto issue_dma = [&](int c) {  // chunk c (stream bytes [128 c, 128 c + 128)) -> the slot, whose previous content has been read
+#ifdef FLX_ABL_NODMA
+        if (c > 0) return;
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int o = r * 64;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m) {  // the two halves of a line back to back
+            const int o = c * 128;
+#ifdef FLX_ABL_HALFDMA
+            if (m & 1) continue;
+#endif
             if (o < lim[m]) dma16(gsrc[m] + o, slot_lds + m * 1024);
+            if (o + 64 < lim[m]) dma16(gsrc[m] + o + 64, slot_lds + 4096 + m * 1024);
+        }
     };
 
     uint32_t ring[R][4];
@@ -227,14 +240,21 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_regs(const PhredAr
     double s = 0.0, w = 0.0, mn = 0.0;
     uint32_t bad = 0;
 
-    auto load_round = [&](int t0) {  // the slot's 4 pieces -> ring[t0 .. t0 + 3]
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // round r (64 bases): the 4 pieces of half r & 1 of the slot -> ring[t0 .. t0 + 3]; after the second half the slot is
+    // free and the next chunk's DMA goes out, a whole round of compute ahead of its first use
+    auto load_round = [&](int t0, int r) {
+        const int half = r & 1;
+#ifndef FLX_ABL_NOWAIT
+        if (half == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        const unsigned char *row = my_row + half * 4096;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(my_row + (((k + rot) & 3) << 4));
+            const uint4 v = *reinterpret_cast<const uint4 *>(row + (((k + rot) & 3) << 4));
             ring[t0 + k][0] = v.x; ring[t0 + k][1] = v.y; ring[t0 + k][2] = v.z; ring[t0 + k][3] = v.w;
             if (PRIV) bad |= v.x | v.y | v.z | v.w;
         }
+        if (half == 1 && r + 1 < n_rounds) issue_dma((r + 1) >> 1);
     };
     // addresses of the 4 bases of dword d; lanes whose read has ended look up the zero entry instead (exact no-op)
     auto addr4 = [&](uint32_t x, bool masked, int rem, int k0, uint32_t (&o)[4]) {
@@ -242,7 +262,7 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_regs(const PhredAr
         o[1] = tab_addr<PRIV, 1>(x, laneoff);
         o[2] = tab_addr<PRIV, 2>(x, laneoff);
         o[3] = tab_addr<PRIV, 3>(x, laneoff);
-        if (masked) {
+        if (__builtin_expect(masked, 0)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = (k0 + i) < rem ? o[i] : zaddr;
         }
@@ -258,7 +278,11 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_regs(const PhredAr
         }
     };
     auto steady_piece = [&](const uint32_t (&lw)[4], const uint32_t (&p0)[4], const uint32_t (&p1)[4], int Tp) {
+#ifdef FLX_ABL_NOMASK
+        const bool masked = false;
+#else
         const bool masked = 16 * (Tp + 1) > Lmin;
+#endif
         const int rem = L - 16 * Tp;
         uint32_t tw[4];
         funnel(p0, p1, fD, fsh, tw);
@@ -299,8 +323,7 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_regs(const PhredAr
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         if (h >= n_rounds) goto done;
-        load_round(4 * h);
-        if (h + 1 < n_rounds) issue_dma(h + 1);
+        load_round(4 * h, h);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             constexpr int dummy = 0;
@@ -327,8 +350,7 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_regs(const PhredAr
             const int r = rb + u;
             if (r >= n_rounds) goto done;
             const int sr = (H + u) % RR;  // ring round (compile-time)
-            load_round(4 * sr);
-            if (r + 1 < n_rounds) issue_dma(r + 1);
+            load_round(4 * sr, r);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int t = 4 * sr + k;  // ring piece (compile-time)
@@ -384,7 +406,7 @@ int launch_one(flx_ctx *ctx, PhredArgs &a) {
     using T = Tab<PRIV>;
     auto kern = flx_score_phred_regs<A, PRIV, WAVES>;
     // one persistent workgroup per CU; asking for more than half of the LDS keeps a second one off the CU
-    const size_t lds = std::max<size_t>((size_t)T::SLOT0 + (size_t)WAVES * 4096, 84 * 1024);
+    const size_t lds = std::max<size_t>((size_t)T::SLOT0 + (size_t)WAVES * 8192, 84 * 1024);
     FLX_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t per_block = (uint64_t)WAVES;
     const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)a.n_groups + per_block - 1) / per_block,
@@ -404,6 +426,7 @@ int launch_one(flx_ctx *ctx, PhredArgs &a) {
 #ifndef FLX_REGS_WAVES
 #define FLX_REGS_WAVES 12
 #endif
+#define FLX_REGS_WAVES_PRIV 11  // 2 x 33 KB of tables + 11 x 8 KiB of slots = 156 KB of the 160 KB
 
 }  // namespace
 
@@ -422,7 +445,7 @@ int flx_launch_score_phred_regs(flx_ctx *ctx, PhredArgs a, bool *launched) {
 #define FLX_REGS_CASE(AA)                                                                  \
     case AA:                                                                               \
         FLX_HIP(ctx, hipMemsetAsync(scr, 0, 8, ctx->stream));                              \
-        if (priv) FLX_CHECK((launch_one<AA, true, FLX_REGS_WAVES>(ctx, a)));               \
+        if (priv) FLX_CHECK((launch_one<AA, true, FLX_REGS_WAVES_PRIV>(ctx, a)));          \
         else FLX_CHECK((launch_one<AA, false, FLX_REGS_WAVES>(ctx, a)));                   \
         *launched = true;                                                                  \
         break;

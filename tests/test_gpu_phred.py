@@ -44,10 +44,18 @@ def score_hip(ctx, reads, pkw, use_order=True):
     return ctx.score_reads(plane, offsets, lengths, api.make_params(**pkw), order=order)
 
 
-@pytest.mark.parametrize("kernel", ["ring", "direct"])
+def select_kernel(monkeypatch, kernel):
+    """default = register-history kernel where the window size has one (else LDS ring); "private" = its bank-private
+    table variant; "ring" / "direct" force the older kernels."""
+    if kernel in ("ring", "direct"):
+        monkeypatch.setenv("FLX_PHRED_KERNEL", kernel)
+    elif kernel == "private":
+        monkeypatch.setenv("FLX_PHRED_TABLES", "private")
+
+
+@pytest.mark.parametrize("kernel", ["default", "private", "ring", "direct"])
 def test_golden_synth_phred(ctx, kernel, monkeypatch):
-    if kernel == "direct":
-        monkeypatch.setenv("FLX_PHRED_KERNEL", "direct")
+    select_kernel(monkeypatch, kernel)
     gold = json.load(open(os.path.join(_cases.GOLDEN, "probe_synth_phred.json")))
     reads = _cases.phred_reads()
     for key, case in gold.items():
@@ -67,6 +75,35 @@ def test_reference_fixture_phred(ctx):
            ("0x1.831476491630dp+6", "0x1.82b0ce9fc8fd7p+6")]
     for i, (m, w) in enumerate(exp):
         assert o["mean_q"][i] == float.fromhex(m) and o["window_q"][i] == float.fromhex(w)
+
+
+@pytest.mark.parametrize("kernel", ["default", "private"])
+def test_regs_kernel_every_window_remainder(ctx, kernel, monkeypatch):
+    """Register-history kernel: every window size of its range (ws % 16 = 0..15 drives the byte funnel and the position of
+    the first full window inside a piece), lengths around ws and every 16/64-byte boundary, arbitrary bytes (bank-private
+    tables: reads with bytes >= 128 take the redo path), batches that are not a multiple of 64, both processing orders."""
+    select_kernel(monkeypatch, kernel)
+    rng = np.random.RandomState(31)
+    lens = list(range(0, 70)) + list(range(230, 330)) + [383, 384, 385, 511, 512, 513, 1023, 1024, 1025, 5000, 5003]
+    lens += [int(x) for x in rng.randint(200, 6000, 150)]
+    reads = []
+    for i, L in enumerate(lens):
+        if i % 9 == 0:
+            q = rng.randint(0, 256, size=L).astype(np.uint8)        # any byte
+        elif i % 9 == 1:
+            q = rng.randint(33, 127, size=L).astype(np.uint8)       # the full FASTQ alphabet
+        else:
+            q = synth.qual_read(5000 + i, int(L), 17)
+        reads.append(("x%d" % i, b"", q.tobytes()))
+    for ws in range(240, 256):
+        pkw = dict(window_size=ws)
+        p = _oracle.make_params(**pkw)
+        want = [_oracle.score_read(None, q, p) for _, _, q in reads]
+        for use_order in (True, False):
+            o = score_hip(ctx, reads, pkw, use_order)
+            assert_same_f64(o["mean_q"], np.array([w["mean_q"] for w in want]), "ws %d mean_q" % ws)
+            assert_same_f64(o["window_q"], np.array([w["window_q"] for w in want]), "ws %d window_q" % ws)
+            assert (o["passed"] == np.array([w["passed"] for w in want], dtype=np.uint8)).all()
 
 
 @pytest.mark.parametrize("ws", [250, 7, 64, 333])
