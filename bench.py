@@ -187,7 +187,8 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
-    k_ms, k_n = ctx.timing_get("flx_score_phred")
+    kernel_name = ctx.last_phred_kernel()
+    k_ms, k_n = ctx.timing_get(kernel_name)
     rank_ms, _ = ctx.timing_get("flx_rank")
     sort_ms, _ = ctx.timing_get("flx_sort")
     ctx.timing_enable(False)
@@ -231,7 +232,7 @@ def main():
                 "device": info["name"],
             },
             "roofline": {
-                "bound": "hbm", "kernel": "flx_score_phred_ring", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_kernel_ms": round(avg_kernel_ms, 3), "launches": int(k_n), "algorithmic_bytes": int(algo_bytes),
             },

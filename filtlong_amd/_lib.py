@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "flx_plane_layout", "flx_length_order", "flx_score_batch", "flx_score_batch_dev", "flx_rank_and_cut",
     "flx_rank_and_cut_dev", "flx_rank_and_cut_sharded_dev", "flx_kmerset_create", "flx_kmerset_destroy", "flx_kmerset_add_assembly",
     "flx_kmerset_add_short_reads", "flx_kmerset_finalize", "flx_kmerset_size", "flx_kmerset_contains",
-    "flx_synth_qual_dev", "flx_synth_seq_dev",
+    "flx_last_phred_kernel", "flx_synth_qual_dev", "flx_synth_qual_profile_dev", "flx_synth_seq_dev",
 ]
 
 
@@ -132,7 +132,10 @@ def load():
     L.flx_kmerset_size.argtypes = [vp]
     L.flx_kmerset_size.restype = u64
     L.flx_kmerset_contains.argtypes = [vp, vp, u64, vp]
+    L.flx_last_phred_kernel.argtypes = [vp]
+    L.flx_last_phred_kernel.restype = C.c_char_p
     L.flx_synth_qual_dev.argtypes = [vp, u64, vp, u64, vp, vp, vp, u64]
+    L.flx_synth_qual_profile_dev.argtypes = [vp, u64, C.c_int, vp, u64, vp, vp, vp, u64]
     L.flx_synth_seq_dev.argtypes = [vp, u64, vp, u64, vp, vp, vp, u64, vp, u64]
     _lib = L
     return L

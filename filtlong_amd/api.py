@@ -225,8 +225,12 @@ class Context:
         self._check(rc)
         return rep, False
 
-    def synth_qual_dev(self, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n):
-        self._check(self.L.flx_synth_qual_dev(self.h, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n))
+    def last_phred_kernel(self):
+        return self.L.flx_last_phred_kernel(self.h).decode()
+
+    def synth_qual_dev(self, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n, profile=0):
+        self._check(self.L.flx_synth_qual_profile_dev(self.h, seed, profile, d_plane, plane_bytes, d_offsets, d_lengths,
+                                                      d_read_ids, n))
 
 
     def synth_seq_dev(self, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n, d_ref, ref_len):

@@ -21,6 +21,8 @@ int flx_fail(flx_ctx *ctx, int code, const char *fmt, ...) {
 extern "C" int flx_abi_version(void) { return FLX_ABI_VERSION; }
 extern "C" const char *flx_version(void) { return "filtlong-amd 0.1 (hot path of Filtlong v0.3.1; gfx950)"; }
 
+extern "C" const char *flx_last_phred_kernel(const flx_ctx *ctx) { return ctx ? ctx->last_phred_kernel : ""; }
+
 extern "C" const char *flx_last_error(const flx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 // Phred byte -> quality, reference src/read.cpp:270-273.  Evaluated on the HOST with the host libm so

@@ -24,6 +24,7 @@ struct flx_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
     std::string err;
+    const char *last_phred_kernel = "";  // which Phred kernel the last scoring call launched (flx_last_phred_kernel)
 
     // Phred LUTs: lut_q[c] = 1 - 10^(-(c-33)/10) for the signed-char value of byte c, built on the
     // host with the host libm (the same one the CPU reference uses); lut_d = lut_q / window_size.

@@ -441,6 +441,7 @@ int flx_launch_score_phred(flx_ctx *ctx, const uint8_t *d_plane, uint64_t plane_
         auto kern = flx_score_phred_ring<W>;                                                                  \
         FLX_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                          (int)lds));                                                          \
+        ctx->last_phred_kernel = "flx_score_phred_ring";                                                      \
         flx_time_begin(ctx, "flx_score_phred_ring");                                                          \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(W * 64), lds, ctx->stream, a);                              \
         flx_time_end(ctx);                                                                                    \
@@ -461,6 +462,7 @@ int flx_launch_score_phred(flx_ctx *ctx, const uint8_t *d_plane, uint64_t plane_
         a.ticket = nullptr;
         a.n_groups = 0;
         const unsigned grid = (unsigned)((n_reads + 255) / 256);
+        ctx->last_phred_kernel = "flx_score_phred_direct";
         flx_time_begin(ctx, "flx_score_phred_direct");
         hipLaunchKernelGGL(flx_score_phred_direct, dim3(grid), dim3(256), 0, ctx->stream, a);
         flx_time_end(ctx);

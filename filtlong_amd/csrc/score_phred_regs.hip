@@ -29,6 +29,10 @@
 
 using namespace flx_phred;
 
+#ifndef FLX_REGS_PART
+#define FLX_REGS_PART 0
+#endif
+
 namespace {
 
 template <bool PRIV>
@@ -368,6 +372,7 @@ done:
   }
 }
 
+#if FLX_REGS_PART == 0
 // reads flagged by the bank-private variant (a byte >= 128): exact re-scoring, one lane per read
 __global__ void __launch_bounds__(256) flx_score_phred_redo(const PhredArgs a) {
     __shared__ double lq[LUT_PAD];
@@ -401,6 +406,8 @@ __global__ void __launch_bounds__(256) flx_score_phred_redo(const PhredArgs a) {
     }
 }
 
+#endif
+
 template <int A, bool PRIV, int WAVES>
 int launch_one(flx_ctx *ctx, PhredArgs &a) {
     using T = Tab<PRIV>;
@@ -411,48 +418,127 @@ int launch_one(flx_ctx *ctx, PhredArgs &a) {
     const uint64_t per_block = (uint64_t)WAVES;
     const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)a.n_groups + per_block - 1) / per_block,
                                                        (uint64_t)ctx->prop.multiProcessorCount);
-    flx_time_begin(ctx, PRIV ? "flx_score_phred_regs_private" : "flx_score_phred_regs");
+    ctx->last_phred_kernel = PRIV ? "flx_score_phred_regs_private" : "flx_score_phred_regs";
+    flx_time_begin(ctx, ctx->last_phred_kernel);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, ctx->stream, a);
     flx_time_end(ctx);
-    if (PRIV) {
-        flx_time_begin(ctx, "flx_score_phred_redo");
-        hipLaunchKernelGGL(flx_score_phred_redo, dim3(256), dim3(256), 0, ctx->stream, a);
-        flx_time_end(ctx);
-    }
     FLX_HIP(ctx, hipGetLastError());
     return FLX_OK;
 }
 
-#ifndef FLX_REGS_WAVES
-#define FLX_REGS_WAVES 12
-#endif
-#define FLX_REGS_WAVES_PRIV 11  // 2 x 33 KB of tables + 11 x 8 KiB of slots = 156 KB of the 160 KB
+// waves per CU: 16 (4 per SIMD, <= 128 VGPRs) for rings of up to 12 pieces, 12 (<= 168 VGPRs) up to 20 pieces, 8 beyond;
+// the bank-private tables (66 KB) leave room for 11 slots of 8 KiB
+template <int A, bool PRIV>
+struct WavesFor {
+    static constexpr int plain = A <= 7 ? 16 : A <= 15 ? 12 : 8;
+    static constexpr int value = PRIV && plain > 11 ? 11 : plain;
+};
 
+template <int A>
+int launch_a(flx_ctx *ctx, PhredArgs &a, bool priv) {
+    return priv ? launch_one<A, true, WavesFor<A, true>::value>(ctx, a) : launch_one<A, false, WavesFor<A, false>::value>(ctx, a);
+}
+
+}  // namespace
+
+// The instantiations (window sizes 48..319, A = ws / 16 = 3..19) are spread over four translation units of this same file
+// (-DFLX_REGS_PART=0..3, see the Makefile) so that they compile in parallel.
+#define FLX_REGS_CASE(AA) \
+    case AA:              \
+        *launched = true; \
+        return launch_a<AA>(ctx, a, priv);
+#if FLX_REGS_PART == 0
+int flx_launch_score_phred_regs_part0(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
+    switch (a.ws / 16) { FLX_REGS_CASE(3) FLX_REGS_CASE(4) FLX_REGS_CASE(5) FLX_REGS_CASE(6) FLX_REGS_CASE(7) default: return FLX_OK; }
+}
+#elif FLX_REGS_PART == 1
+int flx_launch_score_phred_regs_part1(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
+    switch (a.ws / 16) { FLX_REGS_CASE(8) FLX_REGS_CASE(9) FLX_REGS_CASE(10) FLX_REGS_CASE(11) default: return FLX_OK; }
+}
+#elif FLX_REGS_PART == 2
+int flx_launch_score_phred_regs_part2(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
+    switch (a.ws / 16) { FLX_REGS_CASE(12) FLX_REGS_CASE(13) FLX_REGS_CASE(14) FLX_REGS_CASE(15) default: return FLX_OK; }
+}
+#else
+int flx_launch_score_phred_regs_part3(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
+    switch (a.ws / 16) { FLX_REGS_CASE(16) FLX_REGS_CASE(17) FLX_REGS_CASE(18) FLX_REGS_CASE(19) default: return FLX_OK; }
+}
+#endif
+#undef FLX_REGS_CASE
+
+#if FLX_REGS_PART == 0
+int flx_launch_score_phred_regs_part1(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
+int flx_launch_score_phred_regs_part2(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
+int flx_launch_score_phred_regs_part3(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
+
+namespace {
+// Which table layout?  Plain tables are ~6 % faster when a wavefront's quality values stay within ~32 consecutive table
+// entries; bank-private tables cost the same whatever the data is and win (by up to ~11 %) on a wide quality range, where
+// plain entries e and e + 32 collide.  16 K sampled bytes give the byte distribution p; C(32,2) * sum over bank pairs of
+// p_e * p_e' (e != e', e = e' mod 32) is the expected number of conflicting lane pairs per 32-lane gather group.
+__global__ void __launch_bounds__(256) flx_phred_sample(const PhredArgs a, unsigned int *hist) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint64_t z = (t + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    const uint64_t r = z % a.n_reads;
+    const int L = a.lengths[r];
+    if (L <= 0) return;
+    const uint32_t pos = (uint32_t)((z >> 32) % (uint64_t)L);
+    atomicAdd(&hist[a.plane[a.offsets[r] + pos]], 1u);
+}
 }  // namespace
 
 int flx_launch_score_phred_regs(flx_ctx *ctx, PhredArgs a, bool *launched) {
     *launched = false;
     const int A = a.ws / 16;
-    const char *env = getenv("FLX_PHRED_TABLES");  // "plain" (default) | "private"
-    const bool priv = env && strcmp(env, "private") == 0;
-    // scratch: [0,4) ticket, [4,8) redo count, [64, 64 + 4 n) redo list
+    if (A < 3 || A > 19) return FLX_OK;
+    const char *env = getenv("FLX_PHRED_TABLES");  // "plain" | "private" | unset = decide from a sample of the data
+    bool priv = env && strcmp(env, "private") == 0;
+    // scratch: [0,4) ticket, [4,8) redo count, [64, 1088) sample histogram, [2048, 2048 + 4 n) redo list
     void *scr;
-    FLX_CHECK(flx_scratch(ctx, 64 + (priv ? a.n_reads * 4 : 0), &scr));
+    FLX_CHECK(flx_scratch(ctx, 2048 + a.n_reads * 4, &scr));
     a.ticket = (unsigned int *)scr;
     a.redo_count = (unsigned int *)scr + 1;
-    a.redo_list = (uint32_t *)((char *)scr + 64);
+    a.redo_list = (uint32_t *)((char *)scr + 2048);
     a.n_groups = (unsigned int)((a.n_reads + 63) / 64);
-#define FLX_REGS_CASE(AA)                                                                  \
-    case AA:                                                                               \
-        FLX_HIP(ctx, hipMemsetAsync(scr, 0, 8, ctx->stream));                              \
-        if (priv) FLX_CHECK((launch_one<AA, true, FLX_REGS_WAVES_PRIV>(ctx, a)));          \
-        else FLX_CHECK((launch_one<AA, false, FLX_REGS_WAVES>(ctx, a)));                   \
-        *launched = true;                                                                  \
-        break;
-    switch (A) {
-        FLX_REGS_CASE(15)
-        default: break;
+    FLX_HIP(ctx, hipMemsetAsync(scr, 0, 2048, ctx->stream));
+    if (!env || (strcmp(env, "private") != 0 && strcmp(env, "plain") != 0)) {
+        unsigned int h[256];
+        unsigned int *d_hist = (unsigned int *)((char *)scr + 64);
+        hipLaunchKernelGGL(flx_phred_sample, dim3(64), dim3(256), 0, ctx->stream, a, d_hist);
+        FLX_HIP(ctx, hipMemcpyAsync(h, d_hist, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        double tot = 0.0, conflicts = 0.0;
+        for (int i = 0; i < 256; ++i) tot += h[i];
+        bool high = false;
+        for (int i = 128; i < 256; ++i) high = high || h[i] != 0;
+        if (tot > 0) {
+            for (int b = 0; b < 32; ++b) {
+                double pb = 0.0, sq = 0.0;
+                for (int e = b; e < 256; e += 32) {
+                    const double pe = h[e] / tot;
+                    pb += pe;
+                    sq += pe * pe;
+                }
+                conflicts += pb * pb - sq;
+            }
+        }
+        priv = !high && 496.0 * conflicts > 3.0;  // bytes >= 128 would all go through the redo path: stay plain
     }
-#undef FLX_REGS_CASE
+    switch (A / 4) {
+        case 0: case 1: FLX_CHECK(flx_launch_score_phred_regs_part0(ctx, a, priv, launched)); break;
+        case 2: FLX_CHECK(flx_launch_score_phred_regs_part1(ctx, a, priv, launched)); break;
+        case 3: FLX_CHECK(flx_launch_score_phred_regs_part2(ctx, a, priv, launched)); break;
+        default: FLX_CHECK(flx_launch_score_phred_regs_part3(ctx, a, priv, launched)); break;
+    }
+    if (*launched && priv) {
+        flx_time_begin(ctx, "flx_score_phred_redo");
+        hipLaunchKernelGGL(flx_score_phred_redo, dim3(256), dim3(256), 0, ctx->stream, a);
+        flx_time_end(ctx);
+        FLX_HIP(ctx, hipGetLastError());
+    }
     return FLX_OK;
 }
+#endif

@@ -13,12 +13,16 @@ __device__ __forceinline__ uint64_t mix(uint64_t seed, uint64_t stream, uint64_t
 }
 
 // one block per read-chunk: grid.x walks reads, each thread writes 16 bytes (4 hashes) per step
+// quality profile: per-read centre mu = mu_lo + hash % mu_span, per base q = clamp(mu + a % j1 - j1 / 2 + b % 9 - 4, 1, q_max).
+// profile 0: centre 8..25, jitter +-4 +-4, q <= 60; profile 1 ("wide", a realistic ONT spread): centre 3..44,
+// jitter +-6 +-4, q <= 50 — a wave's 64 reads then touch ~50 distinct table entries instead of ~34.
 __global__ void __launch_bounds__(256) k_synth_qual(uint64_t seed, uint8_t *plane, const uint64_t *offsets,
-                                                    const int32_t *lengths, const uint64_t *read_ids, uint64_t n) {
+                                                    const int32_t *lengths, const uint64_t *read_ids, uint64_t n,
+                                                    int mu_lo, int mu_span, int j1, int q_max) {
     for (uint64_t r = blockIdx.x; r < n; r += gridDim.x) {
         const uint64_t gid = read_ids ? read_ids[r] : r;
         const int L = lengths[r];
-        const int mu = 8 + (int)(mix(seed, 2, gid, 0) % 18);
+        const int mu = mu_lo + (int)(mix(seed, 2, gid, 0) % (uint64_t)mu_span);
         uint8_t *dst = plane + offsets[r];
         const int L16 = (L + 15) & ~15;
         for (int p0 = threadIdx.x * 16; p0 < L16; p0 += 256 * 16) {
@@ -30,8 +34,8 @@ __global__ void __launch_bounds__(256) k_synth_qual(uint64_t seed, uint8_t *plan
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const uint32_t f = (uint32_t)(h >> (16 * b)) & 0xffffu;
-                    int q = mu + (int)((f & 0xff) % 9) - 4 + (int)((f >> 8) % 9) - 4;
-                    q = q < 1 ? 1 : (q > 60 ? 60 : q);
+                    int q = mu + (int)((f & 0xff) % (uint32_t)j1) - j1 / 2 + (int)((f >> 8) % 9) - 4;
+                    q = q < 1 ? 1 : (q > q_max ? q_max : q);
                     const int pos = p0 + g * 4 + b;
                     const uint32_t byte = pos < L ? (uint32_t)(q + 33) : 0u;  // padding bytes are zero
                     packed |= byte << (8 * b);
@@ -95,17 +99,26 @@ extern "C" int flx_synth_seq_dev(flx_ctx *ctx, uint64_t seed, void *d_plane, uin
     return FLX_OK;
 }
 
-extern "C" int flx_synth_qual_dev(flx_ctx *ctx, uint64_t seed, void *d_plane, uint64_t plane_bytes,
-                                  const void *d_offsets, const void *d_lengths, const void *d_read_ids,
-                                  uint64_t n_reads) {
+extern "C" int flx_synth_qual_profile_dev(flx_ctx *ctx, uint64_t seed, int profile, void *d_plane, uint64_t plane_bytes,
+                                          const void *d_offsets, const void *d_lengths, const void *d_read_ids,
+                                          uint64_t n_reads) {
     if (!ctx) return FLX_ERR_INVALID;
+    if (profile != 0 && profile != 1) return flx_fail(ctx, FLX_ERR_INVALID, "unknown quality profile %d", profile);
+    const int mu_lo = profile ? 3 : 8, mu_span = profile ? 42 : 18, j1 = profile ? 13 : 9, q_max = profile ? 50 : 60;
     (void)plane_bytes;
     if (n_reads == 0) return FLX_OK;
     FLX_HIP(ctx, hipSetDevice(ctx->device));
     const unsigned grid = (unsigned)std::min<uint64_t>(n_reads, 65535ull * 16);
     hipLaunchKernelGGL(k_synth_qual, dim3(grid), dim3(256), 0, ctx->stream, seed, (uint8_t *)d_plane,
-                       (const uint64_t *)d_offsets, (const int32_t *)d_lengths, (const uint64_t *)d_read_ids, n_reads);
+                       (const uint64_t *)d_offsets, (const int32_t *)d_lengths, (const uint64_t *)d_read_ids, n_reads, mu_lo, mu_span,
+                       j1, q_max);
     FLX_HIP(ctx, hipGetLastError());
     FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FLX_OK;
+}
+
+extern "C" int flx_synth_qual_dev(flx_ctx *ctx, uint64_t seed, void *d_plane, uint64_t plane_bytes,
+                                  const void *d_offsets, const void *d_lengths, const void *d_read_ids,
+                                  uint64_t n_reads) {
+    return flx_synth_qual_profile_dev(ctx, seed, 0, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n_reads);
 }

@@ -44,18 +44,24 @@ def lengths(n, first=0, seed=SEED, fixed=None):
     return np.clip(np.rint(2500.0 * g), 200, 200000).astype(np.int32)
 
 
-def mu(read, seed=SEED):
-    return (8 + (mix(seed, STREAM_MU, read, 0) % _M(18))).astype(np.int64)
+# quality profiles (mu_lo, mu_span, jitter1, q_max): 0 = SURVEY §8(d); 1 = "wide" (centre Q3..Q44, q <= 50); csrc/synth.hip
+PROFILES = {0: (8, 18, 9, 60), 1: (3, 42, 13, 50)}
 
 
-def qual_read(read, length, seed=SEED):
+def mu(read, seed=SEED, profile=0):
+    lo, span, _, _ = PROFILES[profile]
+    return (lo + (mix(seed, STREAM_MU, read, 0) % _M(span))).astype(np.int64)
+
+
+def qual_read(read, length, seed=SEED, profile=0):
     """Phred+33 bytes of one read (uint8[length])."""
+    _, _, j1, q_max = PROFILES[profile]
     pos = np.arange(length, dtype=np.uint64)
     h = mix(seed, STREAM_QUAL, read, pos >> _M(2))
     f = (h >> (_M(16) * (pos & _M(3)))) & _M(0xFFFF)
-    m = int(mu(np.uint64(read), seed))
-    q = m + (f & _M(0xFF)).astype(np.int64) % 9 - 4 + (f >> _M(8)).astype(np.int64) % 9 - 4
-    return (np.clip(q, 1, 60) + 33).astype(np.uint8)
+    m = int(mu(np.uint64(read), seed, profile))
+    q = m + (f & _M(0xFF)).astype(np.int64) % j1 - j1 // 2 + (f >> _M(8)).astype(np.int64) % 9 - 4
+    return (np.clip(q, 1, q_max) + 33).astype(np.uint8)
 
 
 def bases_read(stream, read, start, length, seed=SEED):

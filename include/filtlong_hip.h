@@ -86,6 +86,9 @@ int flx_ctx_device_info(const flx_ctx *ctx, char *name, size_t name_cap, int *n_
  * While enabled, every launch of a hot kernel is bracketed by events; flx_timing_get drains them
  * (synchronising) and returns total milliseconds and launch count for kernels whose name starts
  * with `prefix` ("" = all). */
+/* Name of the Phred scoring kernel the last Phred-mode scoring call launched (the library picks by window size and data:
+ * "flx_score_phred_regs", "flx_score_phred_regs_private", "flx_score_phred_ring" or "flx_score_phred_direct"). */
+const char *flx_last_phred_kernel(const flx_ctx *ctx);
 int flx_timing_enable(flx_ctx *ctx, int on);
 int flx_timing_reset(flx_ctx *ctx);
 int flx_timing_get(flx_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches);
@@ -225,6 +228,10 @@ int flx_kmerset_contains(const flx_kmerset *set, const uint32_t *kmers, uint64_t
  * ---------------------------------------------------------------------------------------- */
 int flx_synth_qual_dev(flx_ctx *ctx, uint64_t seed, void *d_plane, uint64_t plane_bytes, const void *d_offsets,
                        const void *d_lengths, const void *d_read_ids, uint64_t n_reads);
+/* the same with a quality profile: 0 = the SURVEY §8(d) definition (what flx_synth_qual_dev writes), 1 = "wide": per-read
+ * centre Q3..Q44, per-base jitter +-10, q <= 50 (a realistic spread; bench.py's second Phred line) */
+int flx_synth_qual_profile_dev(flx_ctx *ctx, uint64_t seed, int profile, void *d_plane, uint64_t plane_bytes,
+                               const void *d_offsets, const void *d_lengths, const void *d_read_ids, uint64_t n_reads);
 
 /* k-mer configurations: reads drawn from a device-resident reference genome (d_ref, ASCII ACGT) with per-read
  * substitution rates and junk blocks. */

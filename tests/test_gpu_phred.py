@@ -45,15 +45,15 @@ def score_hip(ctx, reads, pkw, use_order=True):
 
 
 def select_kernel(monkeypatch, kernel):
-    """default = register-history kernel where the window size has one (else LDS ring); "private" = its bank-private
-    table variant; "ring" / "direct" force the older kernels."""
+    """default = register-history kernel where the window size has one (48..319, else LDS ring), table layout chosen from a
+    sample of the data; "plain" / "private" force its table layout; "ring" / "direct" force the older kernels."""
     if kernel in ("ring", "direct"):
         monkeypatch.setenv("FLX_PHRED_KERNEL", kernel)
-    elif kernel == "private":
-        monkeypatch.setenv("FLX_PHRED_TABLES", "private")
+    elif kernel in ("private", "plain"):
+        monkeypatch.setenv("FLX_PHRED_TABLES", kernel)
 
 
-@pytest.mark.parametrize("kernel", ["default", "private", "ring", "direct"])
+@pytest.mark.parametrize("kernel", ["default", "plain", "private", "ring", "direct"])
 def test_golden_synth_phred(ctx, kernel, monkeypatch):
     select_kernel(monkeypatch, kernel)
     gold = json.load(open(os.path.join(_cases.GOLDEN, "probe_synth_phred.json")))
@@ -77,9 +77,9 @@ def test_reference_fixture_phred(ctx):
         assert o["mean_q"][i] == float.fromhex(m) and o["window_q"][i] == float.fromhex(w)
 
 
-@pytest.mark.parametrize("kernel", ["default", "private"])
+@pytest.mark.parametrize("kernel", ["plain", "private"])
 def test_regs_kernel_every_window_remainder(ctx, kernel, monkeypatch):
-    """Register-history kernel: every window size of its range (ws % 16 = 0..15 drives the byte funnel and the position of
+    """Register-history kernel: window sizes across its range 48..319 and just outside, every remainder (ws % 16 = 0..15 drives the byte funnel and the position of
     the first full window inside a piece), lengths around ws and every 16/64-byte boundary, arbitrary bytes (bank-private
     tables: reads with bytes >= 128 take the redo path), batches that are not a multiple of 64, both processing orders."""
     select_kernel(monkeypatch, kernel)
@@ -95,7 +95,7 @@ def test_regs_kernel_every_window_remainder(ctx, kernel, monkeypatch):
         else:
             q = synth.qual_read(5000 + i, int(L), 17)
         reads.append(("x%d" % i, b"", q.tobytes()))
-    for ws in range(240, 256):
+    for ws in list(range(240, 256)) + [47, 48, 49, 63, 64, 65, 100, 127, 128, 129, 191, 192, 200, 256, 257, 300, 319, 320]:
         pkw = dict(window_size=ws)
         p = _oracle.make_params(**pkw)
         want = [_oracle.score_read(None, q, p) for _, _, q in reads]
@@ -129,8 +129,9 @@ def test_empty_batch_and_all_empty_reads(ctx):
     assert np.isnan(o["mean_q"]).all() and np.isnan(o["window_q"]).all() and list(o["passed"]) == [0, 0]
 
 
-def test_device_generator_matches_numpy(ctx):
-    """flx_synth_qual_dev (HBM) == filtlong_amd/synth.py (host), so full-size runs score known bytes."""
+@pytest.mark.parametrize("profile", [0, 1])
+def test_device_generator_matches_numpy(ctx, profile):
+    """flx_synth_qual_profile_dev (HBM) == filtlong_amd/synth.py (host), so full-size runs score known bytes."""
     import torch
     lens = np.array([1, 15, 16, 17, 250, 1000, 4097, 33], dtype=np.int32)
     ids = np.array([0, 5, 9, 123456789, 2, 77, 1 << 33, 3], dtype=np.uint64)
@@ -141,11 +142,11 @@ def test_device_generator_matches_numpy(ctx):
     d_ids = torch.from_numpy(ids.astype(np.int64)).cuda()
     torch.cuda.synchronize()
     ctx.synth_qual_dev(synth.SEED, d_plane.data_ptr(), plane.nbytes, d_off.data_ptr(), d_len.data_ptr(),
-                       d_ids.data_ptr(), len(lens))
+                       d_ids.data_ptr(), len(lens), profile=profile)
     got = d_plane.cpu().numpy()
     for i, L in enumerate(lens):
         o = int(offsets[i])
-        assert (got[o:o + L] == synth.qual_read(int(ids[i]), int(L))).all(), i
+        assert (got[o:o + L] == synth.qual_read(int(ids[i]), int(L), profile=profile)).all(), i
         assert (got[o + L:o + ((L + 15) & ~15)] == 0).all()
 
 

@@ -1,5 +1,5 @@
 """Times the Phred scoring kernel alone (HIP events on the library's stream) on synthetic reads generated in HBM.
-usage: python tools/bench_phred_kernel.py [n_reads] [window_size]   (FLX_LIB_PATH selects an experimental build)"""
+usage: python tools/bench_phred_kernel.py [n_reads] [window_size] [quality profile 0|1]   (FLX_LIB_PATH selects an experimental build)"""
 import ctypes as C
 import os
 import sys
@@ -12,6 +12,7 @@ from filtlong_amd import api, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3_000_000
 ws = int(sys.argv[2]) if len(sys.argv) > 2 else 250
+profile = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ctx = api.Context(0)
 dev = torch.device("cuda", 0)
 lengths = synth.lengths(n)
@@ -28,7 +29,7 @@ d_mean = torch.empty(n, dtype=torch.float64, device=dev)
 d_win = torch.empty(n, dtype=torch.float64, device=dev)
 d_pass = torch.empty(n, dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
-ctx.synth_qual_dev(synth.SEED, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ids.data_ptr(), n)
+ctx.synth_qual_dev(synth.SEED, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ids.data_ptr(), n, profile=profile)
 params = api.make_params(window_size=ws)
 for rep in range(6):
     if rep == 1:
@@ -39,6 +40,6 @@ for rep in range(6):
 ms, k = ctx.timing_get("flx_score_phred")
 bases = int(lengths.astype(np.int64).sum())
 chk = float(d_mean.sum().item()), float(d_win.sum().item())
-print("reads %d bases %d ws %d: kernel %.3f ms avg over %d launches = %.1f Gbases/s   checksum %.6f %.6f" % (
-    n, bases, ws, ms / k, k, bases / (ms / k) / 1e6, chk[0], chk[1]))
+print("profile %d reads %d bases %d ws %d: kernel %.3f ms avg over %d launches = %.1f Gbases/s   checksum %.6f %.6f" % (
+    profile, n, bases, ws, ms / k, k, bases / (ms / k) / 1e6, chk[0], chk[1]))
 ctx.close()
