@@ -225,6 +225,34 @@ class Context:
         self._check(rc)
         return rep, False
 
+    # ---- multi-GPU with the library's own RCCL communicator (include/filtlong_hip.h, flx_comm_*) -------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        self._check(self.L.flx_comm_unique_id(self.h, buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        self._check(self.L.flx_comm_init(self.h, C.c_char_p(bytes(unique_id)), rank, world))
+
+    def comm_destroy(self):
+        self._check(self.L.flx_comm_destroy(self.h))
+
+    def comm_sum_u64(self, values):
+        a = np.ascontiguousarray(values, dtype=np.uint64).copy()
+        self._check(self.L.flx_comm_sum_u64(self.h, a.ctypes.data, a.size))
+        return a
+
+    def rank_and_cut_comm_dev(self, n_local, d_mean_q, d_window_q, d_length, d_passed, length_weight=1.0, mean_q_weight=1.0,
+                              window_q_weight=1.0, target_bases=None, keep_percent=None, total_bases=0, d_final_score=None):
+        """flx_rank_and_cut_comm_dev: the global stage over all ranks of the context's RCCL communicator (one all-gather of
+        the mean qualities + device-side all-reduces, no host round trips per pass); `total_bases` is the global sum."""
+        rep = CutReport()
+        self._check(self.L.flx_rank_and_cut_comm_dev(self.h, n_local, d_mean_q, d_window_q, d_length, d_passed, length_weight,
+                                                     mean_q_weight, window_q_weight, 1 if target_bases is not None else 0,
+                                                     int(target_bases or 0), 1 if keep_percent is not None else 0,
+                                                     float(keep_percent or 0.0), int(total_bases), d_final_score, C.byref(rep)))
+        return rep
+
     def last_phred_kernel(self):
         return self.L.flx_last_phred_kernel(self.h).decode()
 

@@ -1,0 +1,255 @@
+// comm.hip — multi-GPU exchange of the global stage over RCCL (xGMI), owned by the library.
+//
+// One process per GPU; every process holds one flx_ctx with one RCCL communicator.  The reference has no counterpart (it
+// is a single process, src/main.cpp:37-321); what is exchanged is what main.cpp:169-261 needs from ALL reads2 entries:
+//   * ONE all-gather of the mean qualities (the statistics of main.cpp:170-196 are order-dependent folds over all of
+//     them; 8 bytes per entry, ncclBroadcast per root inside one group = all-gather with unequal counts);
+//   * the 8 selection histograms (257 x u64) are ncclAllReduce'd on the device, on the context's stream, between the
+//     histogram kernel and the kernel that picks the next key byte — no host synchronisation per pass;
+//   * three small host-side sums (passed bases, band sizes, boundary-audit candidates);
+//   * only when the reference's own std::sort order over all reads has to decide (NaN scores, equal scores straddling
+//     the cut): all-gather of window / length / passed as well and the single-GPU stage replicated on every rank.
+//
+// RCCL is loaded with dlopen on first use (FLX_RCCL_LIB, else librccl.so.1 — the copy a host process such as PyTorch may
+// already have loaded — else /opt/rocm/lib/librccl.so.1), so single-GPU users never touch it and the library does not
+// force a second RCCL into a process that brings its own.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "flx_internal.h"
+#include "rank_internal.h"
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+RcclApi g_rccl;
+
+int load_rccl(flx_ctx *ctx) {
+    if (g_rccl.handle) return FLX_OK;
+    const char *cands[] = {getenv("FLX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *c : cands) {
+        if (!c || !*c) continue;
+        h = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) return flx_fail(ctx, FLX_ERR_STATE, "cannot load RCCL (librccl.so.1): %s", dlerror());
+#define FLX_SYM(field, name)                                                                  \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));                  \
+    if (!g_rccl.field) return flx_fail(ctx, FLX_ERR_STATE, "RCCL symbol %s not found", name);
+    FLX_SYM(GetUniqueId, "ncclGetUniqueId")
+    FLX_SYM(CommInitRank, "ncclCommInitRank")
+    FLX_SYM(CommDestroy, "ncclCommDestroy")
+    FLX_SYM(AllReduce, "ncclAllReduce")
+    FLX_SYM(Broadcast, "ncclBroadcast")
+    FLX_SYM(GroupStart, "ncclGroupStart")
+    FLX_SYM(GroupEnd, "ncclGroupEnd")
+    FLX_SYM(GetErrorString, "ncclGetErrorString")
+#undef FLX_SYM
+    g_rccl.handle = h;
+    return FLX_OK;
+}
+
+#define FLX_NCCL(ctx, call)                                                                                     \
+    do {                                                                                                        \
+        ncclResult_t r__ = (call);                                                                              \
+        if (r__ != ncclSuccess)                                                                                 \
+            return flx_fail((ctx), FLX_ERR_STATE, "%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString(r__), __FILE__, \
+                            __LINE__);                                                                          \
+    } while (0)
+
+}  // namespace
+
+struct flx_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    void *stage = nullptr;  // small device staging buffer for host-side sums
+    size_t stage_bytes = 0;
+    void *gather = nullptr;  // all-gathered arrays (grow-only)
+    size_t gather_bytes = 0;
+};
+
+extern "C" int flx_comm_unique_id(flx_ctx *ctx, void *id_out) {
+    if (!ctx || !id_out) return FLX_ERR_INVALID;
+    FLX_CHECK(load_rccl(ctx));
+    ncclUniqueId id;
+    FLX_NCCL(ctx, g_rccl.GetUniqueId(&id));
+    static_assert(sizeof id == FLX_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id_out, &id, sizeof id);
+    return FLX_OK;
+}
+
+extern "C" int flx_comm_init(flx_ctx *ctx, const void *id_in, int rank, int world) {
+    if (!ctx || !id_in) return FLX_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return flx_fail(ctx, FLX_ERR_INVALID, "bad rank %d / world %d", rank, world);
+    if (ctx->comm) return flx_fail(ctx, FLX_ERR_STATE, "communicator already initialised");
+    FLX_CHECK(load_rccl(ctx));
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof id);
+    flx_comm *c = new flx_comm();
+    c->rank = rank;
+    c->world = world;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return flx_fail(ctx, FLX_ERR_STATE, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+    }
+    ctx->comm = c;
+    return FLX_OK;
+}
+
+extern "C" int flx_comm_destroy(flx_ctx *ctx) {
+    if (!ctx) return FLX_ERR_INVALID;
+    flx_comm *c = ctx->comm;
+    if (!c) return FLX_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    if (c->stage) (void)hipFree(c->stage);
+    if (c->gather) (void)hipFree(c->gather);
+    delete c;
+    ctx->comm = nullptr;
+    return FLX_OK;
+}
+
+extern "C" int flx_comm_rank(const flx_ctx *ctx) { return ctx && ctx->comm ? ctx->comm->rank : 0; }
+extern "C" int flx_comm_world(const flx_ctx *ctx) { return ctx && ctx->comm ? ctx->comm->world : 1; }
+
+int flx_comm_allreduce_u64_dev(flx_ctx *ctx, uint64_t *d_buf, uint64_t count) {
+    flx_comm *c = ctx->comm;
+    if (!c) return flx_fail(ctx, FLX_ERR_STATE, "no communicator");
+    FLX_NCCL(ctx, g_rccl.AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, c->comm, ctx->stream));
+    return FLX_OK;
+}
+
+int flx_comm_allreduce_u64_host(flx_ctx *ctx, uint64_t *buf, uint64_t count) {
+    flx_comm *c = ctx->comm;
+    if (!c) return flx_fail(ctx, FLX_ERR_STATE, "no communicator");
+    const size_t bytes = count * 8;
+    if (bytes > c->stage_bytes) {
+        if (c->stage) (void)hipFree(c->stage);
+        c->stage = nullptr;
+        c->stage_bytes = 0;
+        const size_t want = std::max<size_t>(bytes * 2, 1 << 16);
+        FLX_HIP(ctx, hipMalloc(&c->stage, want));
+        c->stage_bytes = want;
+    }
+    FLX_HIP(ctx, hipMemcpyAsync(c->stage, buf, bytes, hipMemcpyHostToDevice, ctx->stream));
+    FLX_NCCL(ctx, g_rccl.AllReduce(c->stage, c->stage, count, ncclUint64, ncclSum, c->comm, ctx->stream));
+    FLX_HIP(ctx, hipMemcpyAsync(buf, c->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FLX_OK;
+}
+
+extern "C" int flx_comm_sum_u64(flx_ctx *ctx, uint64_t *buf, uint64_t count) {
+    if (!ctx || (!buf && count)) return FLX_ERR_INVALID;
+    if (!ctx->comm || count == 0) return FLX_OK;  // single rank: the sum is the value itself
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    return flx_comm_allreduce_u64_host(ctx, buf, count);
+}
+
+// all-gather with per-rank counts: rank r's `elems[r]` elements of `esize` bytes land at offset sum(elems[0..r)) of recv.
+// One ncclBroadcast per root inside a group: the transfers of all roots run concurrently over xGMI.
+static int allgather_v(flx_ctx *ctx, const void *d_send, void *d_recv, const std::vector<uint64_t> &elems, size_t esize) {
+    flx_comm *c = ctx->comm;
+    FLX_NCCL(ctx, g_rccl.GroupStart());
+    uint64_t at = 0;
+    for (int r = 0; r < c->world; ++r) {
+        const size_t bytes = (size_t)elems[r] * esize;
+        if (bytes) {
+            char *dst = (char *)d_recv + at * esize;
+            const void *src = r == c->rank ? d_send : (const void *)dst;
+            ncclResult_t rr = g_rccl.Broadcast(src, dst, bytes, ncclUint8, r, c->comm, ctx->stream);
+            if (rr != ncclSuccess) {
+                (void)g_rccl.GroupEnd();
+                return flx_fail(ctx, FLX_ERR_STATE, "ncclBroadcast failed: %s", g_rccl.GetErrorString(rr));
+            }
+        }
+        at += elems[r];
+    }
+    FLX_NCCL(ctx, g_rccl.GroupEnd());
+    return FLX_OK;
+}
+
+extern "C" int flx_rank_and_cut_comm_dev(flx_ctx *ctx, uint64_t n_local, const void *d_mean_q, const void *d_window_q,
+                                         const void *d_length, void *d_passed, double lw, double mw, double ww,
+                                         int target_bases_set, int64_t target_bases, int keep_percent_set,
+                                         double keep_percent, int64_t total_bases, void *d_final_score,
+                                         flx_cut_report *rep) {
+    if (!ctx) return FLX_ERR_INVALID;
+    if (!rep) return flx_fail(ctx, FLX_ERR_INVALID, "report must not be NULL");
+    flx_comm *c = ctx->comm;
+    if (!c)  // no communicator: the plain single-GPU stage
+        return flx_rank_and_cut_dev(ctx, n_local, d_mean_q, d_window_q, d_length, d_passed, lw, mw, ww, target_bases_set,
+                                    target_bases, keep_percent_set, keep_percent, total_bases, d_final_score, rep);
+    if (n_local && (!d_mean_q || !d_window_q || !d_length || !d_passed)) return flx_fail(ctx, FLX_ERR_INVALID, "NULL local array");
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
+    // shard sizes (reads2 entries per rank: children make them unequal)
+    std::vector<uint64_t> counts((size_t)c->world, 0);
+    counts[c->rank] = n_local;
+    FLX_CHECK(flx_comm_allreduce_u64_host(ctx, counts.data(), counts.size()));
+    uint64_t n_total = 0, first = 0;
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) first = n_total;
+        n_total += counts[r];
+    }
+    if (n_total > 0xffffffffull) return flx_fail(ctx, FLX_ERR_INVALID, "at most 2^32-1 reads");
+
+    // gather buffer: [mean f64 | window f64 | length i32 | passed u8] x n_total (only the first part is filled unless the
+    // replicated fallback is needed)
+    const size_t need = n_total * 21 + 64;
+    if (need > c->gather_bytes) {
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+        if (c->gather) (void)hipFree(c->gather);
+        c->gather = nullptr;
+        c->gather_bytes = 0;
+        FLX_HIP(ctx, hipMalloc(&c->gather, need + need / 8));
+        c->gather_bytes = need + need / 8;
+    }
+    double *g_mean = (double *)c->gather;
+    double *g_win = g_mean + n_total;
+    int32_t *g_len = (int32_t *)(g_win + n_total);
+    uint8_t *g_pass = (uint8_t *)(g_len + n_total);
+
+    flx_time_begin(ctx, "flx_comm_allgather_means");
+    int rc = allgather_v(ctx, d_mean_q, g_mean, counts, 8);
+    flx_time_end(ctx);
+    FLX_CHECK(rc);
+
+    rc = flx_rank_and_cut_sharded_comm(ctx, n_total, g_mean, first, n_local, (const double *)d_window_q, (const int32_t *)d_length,
+                                       (uint8_t *)d_passed, lw, mw, ww, target_bases_set, target_bases, keep_percent_set,
+                                       keep_percent, total_bases, d_final_score, c->rank, c->world, rep);
+    if (rc != FLX_NEED_REPLICATED) return rc;
+
+    // the reference's own std::sort order over ALL reads decides: every record to every rank, single-GPU stage replicated
+    flx_time_begin(ctx, "flx_comm_allgather_records");
+    rc = allgather_v(ctx, d_window_q, g_win, counts, 8);
+    if (rc == FLX_OK) rc = allgather_v(ctx, d_length, g_len, counts, 4);
+    if (rc == FLX_OK) rc = allgather_v(ctx, d_passed, g_pass, counts, 1);
+    flx_time_end(ctx);
+    FLX_CHECK(rc);
+    flx_dbuf d_fs;
+    if (d_final_score) FLX_CHECK(flx_dalloc(ctx, d_fs, n_total * 8));
+    FLX_CHECK(flx_rank_and_cut_dev(ctx, n_total, g_mean, g_win, g_len, g_pass, lw, mw, ww, target_bases_set, target_bases,
+                                   keep_percent_set, keep_percent, total_bases, d_final_score ? d_fs.p : nullptr, rep));
+    if (n_local) {
+        FLX_HIP(ctx, hipMemcpyAsync(d_passed, g_pass + first, n_local, hipMemcpyDeviceToDevice, st));
+        if (d_final_score)
+            FLX_HIP(ctx, hipMemcpyAsync(d_final_score, (const double *)d_fs.p + first, n_local * 8, hipMemcpyDeviceToDevice, st));
+    }
+    FLX_HIP(ctx, hipStreamSynchronize(st));
+    return FLX_OK;
+}

@@ -72,6 +72,7 @@ extern "C" void flx_ctx_destroy(flx_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)flx_comm_destroy(ctx);
     for (auto &t : ctx->timed) {
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);

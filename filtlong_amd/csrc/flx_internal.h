@@ -13,6 +13,8 @@
 
 #include "../../include/filtlong_hip.h"
 
+struct flx_comm;  // comm.hip: the RCCL communicator of this rank
+
 struct flx_timed_launch {
     const char *name;
     hipEvent_t start, stop;
@@ -33,6 +35,8 @@ struct flx_ctx {
     double *d_lut_q = nullptr;  // [257]
     double *d_lut_d = nullptr;  // [257], rebuilt when window_size changes
     int lut_d_ws = -1;
+
+    flx_comm *comm = nullptr;  // multi-GPU: set by flx_comm_init
 
     // timing
     bool timing = false;
@@ -77,6 +81,10 @@ struct flx_dbuf {
     T *as() { return (T *)p; }
 };
 int flx_dalloc(flx_ctx *ctx, flx_dbuf &b, size_t bytes);
+
+// comm.hip: element-wise sums over all ranks of the context's communicator
+int flx_comm_allreduce_u64_dev(flx_ctx *ctx, uint64_t *d_buf, uint64_t count);   // device buffer, in stream order
+int flx_comm_allreduce_u64_host(flx_ctx *ctx, uint64_t *buf, uint64_t count);    // host buffer, synchronous
 
 // internal launchers -------------------------------------------------------------------------
 struct flx_score_out_dev {  // device pointers

@@ -155,14 +155,23 @@ __global__ void k_cut_mark(uint64_t n, const uint64_t *keys_orig, uint64_t key_s
 
 
 // ---- SELECT path ---------------------------------------------------------------------------------
-// weight histogram of one key byte: bins[b] += length of every PASSED read whose key agrees with `prefix` in its top
-// `prefix_bytes` bytes and whose next byte is b
+// state of the radix selection, kept on the device so that the 8 passes need no host round trip
+struct SelState {
+    unsigned long long prefix;  // key bytes decided so far (most significant first)
+    long long remaining;        // bases still to be collected inside the current prefix
+    unsigned int nan;           // some final score is NaN
+    unsigned int fail;          // ran out of weight (cannot happen when 0 < target < passed_bases)
+};
+
+// weight histogram of one key byte: bins[b] += length of every PASSED read whose key agrees with the state's prefix in its
+// top `prefix_bytes` bytes and whose next byte is b
 __global__ void __launch_bounds__(256) k_select_hist(uint64_t n, const uint64_t *keys, const int32_t *length,
-                                                     const uint8_t *passed, uint64_t prefix, int prefix_bytes,
+                                                     const uint8_t *passed, const SelState *st, int prefix_bytes,
                                                      unsigned long long *bins) {
     __shared__ unsigned long long h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
+    const uint64_t prefix = st->prefix;
     const int shift = 56 - 8 * prefix_bytes;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t k = keys[i];
@@ -174,6 +183,77 @@ __global__ void __launch_bounds__(256) k_select_hist(uint64_t n, const uint64_t 
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
+}
+
+// one byte of the crossing key from the (globally summed) histogram of this pass; bins[256] of pass 0 carries the NaN flag
+__global__ void __launch_bounds__(256) k_select_decide(const unsigned long long *bins, SelState *st, int pass) {
+    __shared__ unsigned long long h[256];
+    h[threadIdx.x] = bins[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (pass == 0 && bins[256]) st->nan = 1;
+    long long cum = 0;
+    const long long remaining = st->remaining;
+    int d = 0;
+    for (; d < 256; ++d) {
+        if (cum + (long long)h[d] >= remaining) break;
+        cum += (long long)h[d];
+    }
+    if (d == 256) {
+        st->fail = 1;
+        d = 255;
+    }
+    st->remaining = remaining - cum;
+    st->prefix = (st->prefix << 8) | (unsigned long long)d;
+}
+
+// boundary-audit record of one read: everything the host needs to re-score it with the host libm
+struct BandRec {
+    uint64_t key;
+    double mean, window;
+    uint32_t idx;  // local reads2 index
+    int32_t len;
+    uint32_t was_passed;
+    uint32_t pad;
+};
+__global__ void __launch_bounds__(256) k_band_gather(unsigned int m, const uint32_t *band_idx, const uint64_t *keys,
+                                                     const double *mean, const double *window, const int32_t *length,
+                                                     const uint8_t *passed, BandRec *out) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t r = band_idx[i];
+    BandRec b;
+    b.key = keys[r];
+    b.mean = mean[r];
+    b.window = window[r];
+    b.idx = r;
+    b.len = length[r];
+    b.was_passed = passed[r];
+    b.pad = 0;
+    out[i] = b;
+}
+// the same for a run of SORTED positions [pos0, pos0 + m): read index from the sorted values, pre-cut flag in sorted order
+__global__ void __launch_bounds__(256) k_band_gather_sorted(unsigned int m, uint64_t pos0, const uint32_t *sorted_idx,
+                                                            const uint64_t *sorted_keys, const double *mean,
+                                                            const double *window, const int32_t *length,
+                                                            const uint8_t *pre_sorted, BandRec *out) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t r = sorted_idx[pos0 + i];
+    BandRec b;
+    b.key = sorted_keys[pos0 + i];
+    b.mean = mean[r];
+    b.window = window[r];
+    b.idx = r;
+    b.len = length[r];
+    b.was_passed = pre_sorted[pos0 + i];
+    b.pad = 0;
+    out[i] = b;
+}
+// passed[idx[i]] = val[i]
+__global__ void __launch_bounds__(256) k_scatter_flags(unsigned int m, const uint32_t *idx, const uint8_t *val, uint8_t *passed) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m) passed[idx[i]] = val[i];
 }
 
 // every read whose key lies in [k_lo, k_hi] is appended to the band list; the lengths of passed reads with a
@@ -275,18 +355,36 @@ static int exact_host_cut(flx_ctx *ctx, uint64_t n, const double *d_mean, const 
 // =================================================================================================
 static const int FLX_SELECT_BAND_TOO_LARGE = -1000;
 
-// One rank's view when the global stage is sharded (flx_rank_and_cut_sharded_dev): the statistics are global, the
-// final scores / keys / pass flags are those of the local reads2 entries [first, first + n), and every quantity the
-// selection needs from the other ranks is a SUM of 64-bit integers, obtained through the caller's all-reduce.
+// One rank's view when the global stage is sharded (flx_rank_and_cut_sharded_dev / flx_rank_and_cut_comm_dev): the
+// statistics are global, the final scores / keys / pass flags are those of the local reads2 entries [first, first + n),
+// and every quantity the selection needs from the other ranks is a SUM of 64-bit integers.  Two transports:
+//   * the context's RCCL communicator (comm.hip): ncclAllReduce on the device buffer, on the context's stream, no host
+//     synchronisation — the 8 selection passes then run back to back;
+//   * the caller's host callback (tests, torch.distributed/gloo): the buffer goes through the host.
 struct Shard {
-    flx_allreduce_u64_fn reduce = nullptr;  // NULL: single rank, nothing to exchange
+    flx_allreduce_u64_fn reduce = nullptr;
     void *user = nullptr;
+    bool use_comm = false;
     uint64_t first = 0;
     int rank = 0, world = 1;
-    bool sharded() const { return reduce != nullptr; }
+    bool sharded() const { return reduce != nullptr || use_comm; }
+    // sum of a HOST buffer over all ranks
     int sum(flx_ctx *ctx, uint64_t *buf, uint64_t count) const {
-        if (!reduce || count == 0) return FLX_OK;  // (an empty exchange is empty on every rank)
+        if (!sharded() || count == 0) return FLX_OK;  // (an empty exchange is empty on every rank)
+        if (use_comm) return flx_comm_allreduce_u64_host(ctx, buf, count);
         if (reduce(user, buf, count) != 0) return flx_fail(ctx, FLX_ERR_STATE, "all-reduce callback failed");
+        return FLX_OK;
+    }
+    // sum of a DEVICE buffer over all ranks, in stream order
+    int sum_dev(flx_ctx *ctx, uint64_t *d_buf, uint64_t count) const {
+        if (!sharded() || count == 0) return FLX_OK;
+        if (use_comm) return flx_comm_allreduce_u64_dev(ctx, d_buf, count);
+        std::vector<uint64_t> h(count);
+        FLX_HIP(ctx, hipMemcpyAsync(h.data(), d_buf, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+        FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (reduce(user, h.data(), count) != 0) return flx_fail(ctx, FLX_ERR_STATE, "all-reduce callback failed");
+        FLX_HIP(ctx, hipMemcpyAsync(d_buf, h.data(), count * 8, hipMemcpyHostToDevice, ctx->stream));
+        FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return FLX_OK;
     }
 };
@@ -299,64 +397,123 @@ static double key_to_score(uint64_t k) {
     return v;
 }
 
+// flx_time_begin / flx_time_end as a scope: an early return cannot leave a bracket open
+struct TimeScope {
+    flx_ctx *ctx;
+    bool open;
+    TimeScope(flx_ctx *c, const char *name) : ctx(c), open(true) { flx_time_begin(c, name); }
+    void end() {
+        if (open) flx_time_end(ctx);
+        open = false;
+    }
+    ~TimeScope() { end(); }
+};
+
+// ---- the boundary audit, shared by both cut implementations ---------------------------------------------------------
+// Candidates = every read whose DEVICE score lies within the band around the crossing score, with its EXACT score (host
+// libm).  The walk of main.cpp:251-257 is replayed over them in exact order (descending exact score; equal scores in
+// device order).  Returns true when the outcome depends on the order inside a group of EQUAL exact scores — which only the
+// reference's own std::sort (unstable, libstdc++ introsort) can settle: the target is reached inside a group with more
+// than one passed member and not every order keeps all of them.  (Walking the group in one order and comparing the
+// members' decisions is not enough: lengths {10, 20} entering at target - 15 keep both in that order and only the
+// second in the other.)
+struct Cand { uint64_t idx; uint64_t key; double score; int32_t len; uint8_t was_passed; };
+static bool audit_walk(const std::vector<Cand> &cand, long long weight_before, long long target, std::vector<uint8_t> &keep,
+                       long long *so_far_out) {
+    const size_t m = cand.size();
+    std::vector<size_t> ord(m);
+    std::iota(ord.begin(), ord.end(), (size_t)0);
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
+        if (cand[x].score != cand[y].score) return cand[x].score > cand[y].score;
+        if (cand[x].key != cand[y].key) return cand[x].key < cand[y].key;
+        return cand[x].idx < cand[y].idx;
+    });
+    keep.assign(m, 0);
+    long long so_far = weight_before;
+    bool order_dependent = false;
+    for (size_t k = 0; k < m;) {
+        size_t e = k;
+        long long sum = 0, min_len = std::numeric_limits<long long>::max();
+        int passed_n = 0;
+        while (e < m && cand[ord[e]].score == cand[ord[k]].score) {
+            const Cand &c = cand[ord[e]];
+            if (c.was_passed) {
+                ++passed_n;
+                sum += c.len;
+                min_len = std::min<long long>(min_len, c.len);
+            }
+            ++e;
+        }
+        // before >= target: no member is kept in any order; before + sum - min_len < target: every member is kept in any
+        // order (even the shortest one, walked last, still starts below the target); anything in between depends on it
+        if (passed_n > 1 && so_far < target && so_far + sum - min_len >= target) order_dependent = true;
+        for (size_t i = k; i < e; ++i) {
+            const Cand &c = cand[ord[i]];
+            if (c.was_passed && so_far < target) {
+                so_far += c.len;
+                keep[ord[i]] = 1;
+            }
+        }
+        k = e;
+    }
+    *so_far_out = so_far;
+    return order_dependent;
+}
+
 static int cut_by_select(flx_ctx *ctx, uint64_t n, const double *mean, const double *window, const int32_t *length,
                          uint8_t *passed, const NormArgs &s, int64_t target, void *d_final_score, flx_cut_report *rep,
                          const Shard &sh = Shard()) {
     hipStream_t st = ctx->stream;
     const unsigned nb = (unsigned)((n + 255) / 256);
     const unsigned cap = 1u << 16;
-    const size_t bytes = n * 8 + 256 * 8 * 8 + (size_t)cap * 4 + 1024;
+    const size_t bins_bytes = 8 * 264 * 8;  // 8 passes x (256 bins + flag slot + padding)
+    const size_t bytes = n * 8 + bins_bytes + 256 + (size_t)cap * (4 + sizeof(BandRec) + 4 + 1) + 1024;
     void *scr;
-    FLX_CHECK(flx_scratch(ctx, bytes ? bytes : 1024, &scr));
+    FLX_CHECK(flx_scratch(ctx, bytes, &scr));
     char *p = (char *)scr;
     uint64_t *keys = (uint64_t *)p; p += n * 8;
-    unsigned long long *bins = (unsigned long long *)p; p += 256 * 8 * 8;  // one 256-bin table per pass
-    unsigned long long *d_acc = (unsigned long long *)p; p += 256;
-    uint32_t *band_idx = (uint32_t *)p;
+    unsigned long long *bins = (unsigned long long *)p; p += bins_bytes;  // pass q at bins + 264 q
+    SelState *d_state = (SelState *)p; p += 64;
+    unsigned long long *d_acc = (unsigned long long *)p; p += 192;       // [0] band count, [1] weight before the band
+    BandRec *d_recs = (BandRec *)p; p += (size_t)cap * sizeof(BandRec);
+    uint32_t *band_idx = (uint32_t *)p; p += (size_t)cap * 4;
+    uint32_t *d_set_idx = (uint32_t *)p; p += (size_t)cap * 4;
+    uint8_t *d_set_val = (uint8_t *)p;
 
-    FLX_HIP(ctx, hipMemsetAsync(bins, 0, 256 * 8 * 8 + 256, st));
-    flx_time_begin(ctx, "flx_rank_final_score");
-    if (n)
-        hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s, (double *)d_final_score, keys,
-                           (uint32_t *)nullptr, (unsigned int *)(d_acc + 2));
-    flx_time_end(ctx);
-
-    // ---- 8 weighted histogram passes, most significant byte first ------------------------------------------
-    flx_time_begin(ctx, "flx_rank_select");
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, 2048));
-    uint64_t prefix = 0;
-    long long remaining = target;  // bases still to be collected inside the current prefix
-    unsigned long long h_nan = 0;
-    for (int pass = 0; pass < 8; ++pass) {
-        unsigned long long *b = bins + 256 * pass;
-        hipLaunchKernelGGL(k_select_hist, dim3(grid), dim3(256), 0, st, n, keys, length, passed, prefix, pass, b);
-        unsigned long long h[257];
-        FLX_HIP(ctx, hipMemcpyAsync(h, b, 256 * 8, hipMemcpyDeviceToHost, st));
-        if (pass == 0) FLX_HIP(ctx, hipMemcpyAsync(&h_nan, d_acc + 2, 8, hipMemcpyDeviceToHost, st));
-        FLX_HIP(ctx, hipStreamSynchronize(st));
-        h[256] = pass == 0 ? (h_nan & 1ull) : 0;  // the NaN flag rides along with the first histogram
-        FLX_CHECK(sh.sum(ctx, (uint64_t *)h, 257));
-        if (pass == 0 && h[256]) {
-            // NaN scores (stdev == 0 -> 0/0, main.cpp:192-206, or 0/0 window ratios): the reference's comparator is
-            // inconsistent and its outcome is whatever libstdc++'s introsort does on reads2 order -> host path.
-            flx_time_end(ctx);
-            if (sh.sharded()) return FLX_NEED_REPLICATED;
-            return exact_host_cut(ctx, n, mean, window, length, passed, nullptr, nullptr, s, target, rep);
-        }
-        int d = 0;
-        long long cum = 0;
-        for (; d < 256; ++d) {
-            if (cum + (long long)h[d] >= remaining) break;
-            cum += (long long)h[d];
-        }
-        if (d == 256) {  // cannot happen when 0 < target < passed_bases
-            flx_time_end(ctx);
-            return flx_fail(ctx, FLX_ERR_STATE, "radix select ran out of weight (target %lld)", (long long)target);
-        }
-        remaining -= cum;
-        prefix = (prefix << 8) | (uint64_t)d;
+    FLX_HIP(ctx, hipMemsetAsync(bins, 0, bins_bytes + 256, st));
+    {
+        SelState init = {0ull, (long long)target, 0u, 0u};
+        FLX_HIP(ctx, hipMemcpyAsync(d_state, &init, sizeof init, hipMemcpyHostToDevice, st));
     }
-    const uint64_t key_star = prefix;  // key of the read at which the walk reaches the target
+    {
+        TimeScope t(ctx, "flx_rank_final_score");
+        if (n)  // the NaN flag is OR-ed into the flag slot of the first histogram and summed over the ranks with it
+            hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s, (double *)d_final_score, keys,
+                               (uint32_t *)nullptr, (unsigned int *)(bins + 256));
+    }
+
+    // ---- 8 weighted histogram passes, most significant byte first; the crossing byte is picked on the device ----------
+    TimeScope tsel(ctx, "flx_rank_select");
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, 2048));
+    for (int pass = 0; pass < 8; ++pass) {
+        unsigned long long *b = bins + 264 * pass;
+        hipLaunchKernelGGL(k_select_hist, dim3(grid), dim3(256), 0, st, n, keys, length, passed, d_state, pass, b);
+        FLX_CHECK(sh.sum_dev(ctx, (uint64_t *)b, 257));
+        hipLaunchKernelGGL(k_select_decide, dim3(1), dim3(256), 0, st, b, d_state, pass);
+    }
+    SelState h_state;
+    FLX_HIP(ctx, hipMemcpyAsync(&h_state, d_state, sizeof h_state, hipMemcpyDeviceToHost, st));
+    FLX_HIP(ctx, hipStreamSynchronize(st));
+    if (h_state.nan) {
+        // NaN scores (stdev == 0 -> 0/0, main.cpp:192-206, or 0/0 window ratios): the reference's comparator is
+        // inconsistent and its outcome is whatever libstdc++'s introsort does on reads2 order -> host path.
+        tsel.end();
+        if (sh.sharded()) return FLX_NEED_REPLICATED;
+        return exact_host_cut(ctx, n, mean, window, length, passed, nullptr, nullptr, s, target, rep);
+    }
+    if (h_state.fail)  // cannot happen when 0 < target < passed_bases
+        return flx_fail(ctx, FLX_ERR_STATE, "radix select ran out of weight (target %lld)", (long long)target);
+    const uint64_t key_star = h_state.prefix;  // key of the read at which the walk reaches the target
     const double sp = key_to_score(key_star);
 
     // ---- band around the crossing score: everything the reference might order differently -------------------
@@ -364,10 +521,9 @@ static int cut_by_select(flx_ctx *ctx, uint64_t n, const double *mean, const dou
     const double band = std::fabs(sp) * kBand + 1e-300;
     const uint64_t k_lo = ~key_ascending(sp + band), k_hi = ~key_ascending(sp - band);  // descending keys: lo = best score
     hipLaunchKernelGGL(k_select_band, dim3(grid), dim3(256), 0, st, n, keys, length, passed, k_lo, k_hi, band_idx,
-                       (unsigned int *)(d_acc + 3), cap, d_acc + 4);
+                       (unsigned int *)d_acc, cap, d_acc + 1);
     unsigned long long h_acc[2] = {0, 0};
-    FLX_HIP(ctx, hipMemcpyAsync(&h_acc[0], d_acc + 3, 8, hipMemcpyDeviceToHost, st));
-    FLX_HIP(ctx, hipMemcpyAsync(&h_acc[1], d_acc + 4, 8, hipMemcpyDeviceToHost, st));
+    FLX_HIP(ctx, hipMemcpyAsync(h_acc, d_acc, 16, hipMemcpyDeviceToHost, st));
     FLX_HIP(ctx, hipStreamSynchronize(st));
     const unsigned local_n = (unsigned)(h_acc[0] & 0xffffffffull);
     // band sizes of every rank (own slot filled, the rest zero) + the weight in front of the band, in one sum
@@ -382,34 +538,30 @@ static int cut_by_select(flx_ctx *ctx, uint64_t n, const double *mean, const dou
     }
     const long long weight_before = (long long)counts[sh.world];
     if (band_total > cap) {  // huge tie group (e.g. millions of duplicate reads): let the sort path handle it
-        flx_time_end(ctx);
+        tsel.end();
         return sh.sharded() ? FLX_NEED_REPLICATED : FLX_SELECT_BAND_TOO_LARGE;
     }
     const unsigned band_n = (unsigned)band_total;
-    std::vector<uint32_t> idx(local_n);
-    if (local_n) FLX_HIP(ctx, hipMemcpy(idx.data(), band_idx, (size_t)local_n * 4, hipMemcpyDeviceToHost));
-    std::sort(idx.begin(), idx.end());
-    struct Cand { uint64_t idx; uint64_t key; double score; int32_t len; uint8_t was_passed; };
+    // the band's records in ONE gather kernel + ONE copy; exact scores with the host libm (what the reference computes)
+    std::vector<BandRec> recs(local_n);
+    if (local_n) {
+        hipLaunchKernelGGL(k_band_gather, dim3((local_n + 255) / 256), dim3(256), 0, st, local_n, band_idx, keys, mean, window,
+                           length, passed, d_recs);
+        FLX_HIP(ctx, hipMemcpyAsync(recs.data(), d_recs, (size_t)local_n * sizeof(BandRec), hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+        std::sort(recs.begin(), recs.end(), [](const BandRec &x, const BandRec &y) { return x.idx < y.idx; });
+    }
     // five words per candidate: global reads2 index, key, exact score bits, length, pre-cut flag
     std::vector<uint64_t> wire((size_t)band_n * 5, 0);
     for (unsigned i = 0; i < local_n; ++i) {
-        const uint32_t li = idx[i];
-        double mq, wq;
-        int32_t len;
-        uint8_t was;
-        uint64_t key;
-        FLX_HIP(ctx, hipMemcpy(&mq, mean + li, 8, hipMemcpyDeviceToHost));
-        FLX_HIP(ctx, hipMemcpy(&wq, window + li, 8, hipMemcpyDeviceToHost));
-        FLX_HIP(ctx, hipMemcpy(&len, length + li, 4, hipMemcpyDeviceToHost));
-        FLX_HIP(ctx, hipMemcpy(&was, passed + li, 1, hipMemcpyDeviceToHost));
-        FLX_HIP(ctx, hipMemcpy(&key, keys + li, 8, hipMemcpyDeviceToHost));
-        const double sc = host_final_score(len, mq, wq, s);  // host libm: what the reference computes
+        const BandRec &b = recs[i];
+        const double sc = host_final_score(b.len, b.mean, b.window, s);
         uint64_t *w = &wire[(my_at + i) * 5];
-        w[0] = sh.first + li;
-        w[1] = key;
+        w[0] = sh.first + b.idx;
+        w[1] = b.key;
         memcpy(&w[2], &sc, 8);
-        w[3] = (uint64_t)(uint32_t)len;
-        w[4] = was;
+        w[3] = (uint64_t)(uint32_t)b.len;
+        w[4] = b.was_passed;
     }
     FLX_CHECK(sh.sum(ctx, wire.data(), wire.size()));
     std::vector<Cand> cand(band_n);
@@ -422,47 +574,31 @@ static int cut_by_select(flx_ctx *ctx, uint64_t n, const double *mean, const dou
         c.len = (int32_t)(uint32_t)w[3];
         c.was_passed = (uint8_t)w[4];
     }
-    // exact order inside the band: descending exact score; the device order (key, then reads2 index) breaks the rest
-    std::vector<unsigned> ord(band_n);
-    std::iota(ord.begin(), ord.end(), 0u);
-    std::stable_sort(ord.begin(), ord.end(), [&](unsigned x, unsigned y) {
-        if (cand[x].score != cand[y].score) return cand[x].score > cand[y].score;
-        if (cand[x].key != cand[y].key) return cand[x].key < cand[y].key;
-        return cand[x].idx < cand[y].idx;
-    });
-    long long so_far = weight_before;
-    std::vector<uint8_t> keep(band_n, 0);
-    for (unsigned k = 0; k < band_n; ++k) {
-        Cand &c = cand[ord[k]];
-        if (c.was_passed && so_far < target) { so_far += c.len; keep[ord[k]] = 1; }
-    }
-    // a group of equal exact scores whose passed members got different decisions: only the reference's own std::sort
-    // tie order can say which of them crossed the target
-    bool tie_straddle = false;
-    for (unsigned k = 0; k < band_n;) {
-        unsigned e = k;
-        int kept_n = 0, passed_n = 0;
-        while (e < band_n && cand[ord[e]].score == cand[ord[k]].score) {
-            if (cand[ord[e]].was_passed) { ++passed_n; kept_n += keep[ord[e]]; }
-            ++e;
-        }
-        if (kept_n != 0 && kept_n != passed_n) tie_straddle = true;
-        k = e;
-    }
-    flx_time_end(ctx);
-    if (tie_straddle) {
+    std::vector<uint8_t> keep;
+    long long so_far = 0;
+    const bool order_dependent = audit_walk(cand, weight_before, target, keep, &so_far);
+    tsel.end();
+    if (order_dependent) {
         if (sh.sharded()) return FLX_NEED_REPLICATED;
         return exact_host_cut(ctx, n, mean, window, length, passed, nullptr, nullptr, s, target, rep);
     }
 
     // ---- mark: better than the band -> unchanged; band and worse -> fail; kept band members -> back on ----------
     if (n) hipLaunchKernelGGL(k_select_mark, dim3(nb), dim3(256), 0, st, n, keys, k_lo, passed);
-    FLX_HIP(ctx, hipStreamSynchronize(st));
-    for (unsigned i = 0; i < local_n; ++i)  // this rank's members sit at [my_at, my_at + local_n) of the global band
-        if (keep[my_at + i]) {
-            const uint8_t one = 1;
-            FLX_HIP(ctx, hipMemcpy(passed + (cand[my_at + i].idx - sh.first), &one, 1, hipMemcpyHostToDevice));
+    {   // this rank's members sit at [my_at, my_at + local_n) of the global band: one upload, one scatter kernel
+        std::vector<uint32_t> set_idx;
+        for (unsigned i = 0; i < local_n; ++i)
+            if (keep[my_at + i]) set_idx.push_back((uint32_t)(cand[my_at + i].idx - sh.first));
+        if (!set_idx.empty()) {
+            const unsigned m = (unsigned)set_idx.size();
+            std::vector<uint8_t> ones(m, 1);
+            FLX_HIP(ctx, hipMemcpyAsync(d_set_idx, set_idx.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+            FLX_HIP(ctx, hipMemcpyAsync(d_set_val, ones.data(), m, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_scatter_flags, dim3((m + 255) / 256), dim3(256), 0, st, m, d_set_idx, d_set_val, passed);
+            FLX_HIP(ctx, hipStreamSynchronize(st));  // the host vectors go out of scope
         }
+    }
+    FLX_HIP(ctx, hipStreamSynchronize(st));
     rep->kept_bases = so_far;  // "keeping N bp", main.cpp:258
     rep->audited = band_n;
     FLX_HIP(ctx, hipGetLastError());
@@ -494,10 +630,11 @@ static int cut_by_sort(flx_ctx *ctx, uint64_t n, const double *mean, const doubl
     void *sort_tmp = p;
 
     FLX_HIP(ctx, hipMemsetAsync(d_acc, 0, 32, st));
-    flx_time_begin(ctx, "flx_rank_final_score");
-    hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s,
-                       (double *)d_final_score, keys0, vals0, (unsigned int *)(d_acc + 2));
-    flx_time_end(ctx);
+    {
+        TimeScope t(ctx, "flx_rank_final_score");
+        hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s,
+                           (double *)d_final_score, keys0, vals0, (unsigned int *)(d_acc + 2));
+    }
 
     FLX_HIP(ctx, hipMemcpyAsync(keys_orig, keys0, n * 8, hipMemcpyDeviceToDevice, st));
 
@@ -507,7 +644,7 @@ static int cut_by_sort(flx_ctx *ctx, uint64_t n, const double *mean, const doubl
     FLX_CHECK(flx_radix_sort_pairs(ctx, n, keys0, keys1, vals0, vals1, sort_tmp, sort_ws, &skeys, &svals));
 
     // ---- a25: cut walk as an exclusive scan ------------------------------------------------------
-    flx_time_begin(ctx, "flx_rank_cut");
+    TimeScope tcut(ctx, "flx_rank_cut");
     hipLaunchKernelGGL(k_cut_weights, dim3(nb), dim3(256), 0, st, n, svals, length, passed, wts, pre_sorted);
     FLX_CHECK(flx_exclusive_scan_i64(ctx, n, wts, excl, sort_tmp, sort_ws));
 
@@ -517,7 +654,7 @@ static int cut_by_sort(flx_ctx *ctx, uint64_t n, const double *mean, const doubl
     FLX_HIP(ctx, hipStreamSynchronize(st));
     if (h_acc[1] == 0) {  // nothing can be kept (not reachable when 0 < target < passed_bases); fail everything
         FLX_HIP(ctx, hipMemsetAsync(passed, 0, n, st));
-        flx_time_end(ctx);
+        tcut.end();
         FLX_HIP(ctx, hipStreamSynchronize(st));
         rep->kept_bases = 0;
         return FLX_OK;
@@ -533,7 +670,7 @@ static int cut_by_sort(flx_ctx *ctx, uint64_t n, const double *mean, const doubl
         FLX_HIP(ctx, hipMemcpyAsync(&ex_w[1], wts + ps, 8, hipMemcpyDeviceToHost, st));
         FLX_HIP(ctx, hipStreamSynchronize(st));
         hipLaunchKernelGGL(k_cut_mark, dim3(nb), dim3(256), 0, st, n, keys_orig, kstar, istar, passed);
-        flx_time_end(ctx);
+        tcut.end();
         FLX_HIP(ctx, hipStreamSynchronize(st));
         rep->kept_bases = ex_w[0] + ex_w[1];  // "keeping N bp", main.cpp:258
     }
@@ -588,52 +725,39 @@ static int cut_by_sort(flx_ctx *ctx, uint64_t n, const double *mean, const doubl
         rep->audited = nb_band;
         if (nb_band == 1) return FLX_OK;  // only the crossing read itself: nothing can reorder
 
-        // gather the band's inputs, re-score with the host libm
-        struct Cand { uint32_t idx; double score; int32_t len; uint8_t was_passed; uint64_t pos; };
-        std::vector<Cand> cand(nb_band);
-        for (uint64_t i = 0; i < nb_band; ++i) {
-            Cand &c = cand[i];
-            c.idx = hv[a + i];
-            c.pos = lo + a + i;
-            double mq, wq;
-            FLX_HIP(ctx, hipMemcpy(&mq, mean + c.idx, 8, hipMemcpyDeviceToHost));
-            FLX_HIP(ctx, hipMemcpy(&wq, window + c.idx, 8, hipMemcpyDeviceToHost));
-            FLX_HIP(ctx, hipMemcpy(&c.len, length + c.idx, 4, hipMemcpyDeviceToHost));
-            FLX_HIP(ctx, hipMemcpy(&c.was_passed, pre_sorted + c.pos, 1, hipMemcpyDeviceToHost));
-            c.score = host_final_score(c.len, mq, wq, s);
+        // the band's records in ONE gather kernel + ONE copy, re-scored with the host libm
+        if (nb_band > 0xffffffffull) return exact_host_cut(ctx, n, mean, window, length, passed, svals, pre_sorted, s, target, rep);
+        const unsigned mb = (unsigned)nb_band;
+        flx_dbuf d_recs, d_idx, d_val;
+        FLX_CHECK(flx_dalloc(ctx, d_recs, (size_t)mb * sizeof(BandRec)));
+        hipLaunchKernelGGL(k_band_gather_sorted, dim3((mb + 255) / 256), dim3(256), 0, st, mb, lo + a, svals, skeys, mean, window,
+                           length, pre_sorted, d_recs.as<BandRec>());
+        std::vector<BandRec> recs(mb);
+        FLX_HIP(ctx, hipMemcpyAsync(recs.data(), d_recs.p, (size_t)mb * sizeof(BandRec), hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+        std::vector<Cand> cand(mb);
+        for (unsigned i = 0; i < mb; ++i) {
+            const BandRec &r = recs[i];
+            cand[i].idx = r.idx;
+            cand[i].key = r.key;
+            cand[i].len = r.len;
+            cand[i].was_passed = (uint8_t)r.was_passed;
+            cand[i].score = host_final_score(r.len, r.mean, r.window, s);
         }
-        // exact order inside the band: descending exact score; equal exact scores keep... the reference's
-        // std::sort tie order, which only the full host path can reproduce.
-        std::vector<uint64_t> ord(nb_band);
-        std::iota(ord.begin(), ord.end(), 0ull);
-        std::stable_sort(ord.begin(), ord.end(), [&](uint64_t x, uint64_t y) { return cand[x].score > cand[y].score; });
-        // walk
-        long long so_far = hex[a];
-        std::vector<uint8_t> keep(nb_band, 0);
-        for (uint64_t k = 0; k < nb_band; ++k) {
-            Cand &c = cand[ord[k]];
-            if (c.was_passed && so_far < target) { so_far += c.len; keep[ord[k]] = 1; }
-        }
-        // tie check: a group of equal exact scores whose passed members got different decisions -> only the
-        // reference's own std::sort tie order can say which of them crossed the target
-        bool tie_straddle = false;
-        for (uint64_t k = 0; k < nb_band;) {
-            uint64_t e = k;
-            int kept_n = 0, passed_n = 0;
-            while (e < nb_band && cand[ord[e]].score == cand[ord[k]].score) {
-                if (cand[ord[e]].was_passed) { ++passed_n; kept_n += keep[ord[e]]; }
-                ++e;
-            }
-            if (kept_n != 0 && kept_n != passed_n) tie_straddle = true;
-            k = e;
-        }
-        if (tie_straddle)
+        // exact order inside the band, walk, and the test whether only the reference's std::sort can decide (audit_walk)
+        std::vector<uint8_t> keep;
+        long long so_far = 0;
+        if (audit_walk(cand, hex[a], target, keep, &so_far))
             return exact_host_cut(ctx, n, mean, window, length, passed, svals, pre_sorted, s, target, rep);
-        // patch flags of the band; reads after the band all fail, reads before it are unchanged
-        for (uint64_t i = 0; i < nb_band; ++i) {
-            const uint8_t v = keep[i];
-            FLX_HIP(ctx, hipMemcpy(passed + cand[i].idx, &v, 1, hipMemcpyHostToDevice));
-        }
+        // patch the flags of the band (one upload, one scatter); reads after it all fail, reads before it are unchanged
+        std::vector<uint32_t> idx(mb);
+        for (unsigned i = 0; i < mb; ++i) idx[i] = (uint32_t)cand[i].idx;
+        FLX_CHECK(flx_dalloc(ctx, d_idx, (size_t)mb * 4));
+        FLX_CHECK(flx_dalloc(ctx, d_val, mb));
+        FLX_HIP(ctx, hipMemcpyAsync(d_idx.p, idx.data(), (size_t)mb * 4, hipMemcpyHostToDevice, st));
+        FLX_HIP(ctx, hipMemcpyAsync(d_val.p, keep.data(), mb, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_scatter_flags, dim3((mb + 255) / 256), dim3(256), 0, st, mb, d_idx.as<uint32_t>(), d_val.as<uint8_t>(), passed);
+        FLX_HIP(ctx, hipStreamSynchronize(st));
         rep->kept_bases = so_far;
         return FLX_OK;
     }
@@ -679,9 +803,10 @@ static int rank_and_cut_impl(flx_ctx *ctx, uint64_t n_total, const double *mean_
         FLX_CHECK(flx_scratch(ctx, 64, &scr));
         unsigned long long *d_acc = (unsigned long long *)scr;
         FLX_HIP(ctx, hipMemsetAsync(d_acc, 0, 8, st));
-        flx_time_begin(ctx, "flx_rank_passed_bases");
-        hipLaunchKernelGGL(k_passed_bases, dim3(1024), dim3(256), 0, st, n, length, passed, d_acc);
-        flx_time_end(ctx);
+        {
+            TimeScope t(ctx, "flx_rank_passed_bases");
+            hipLaunchKernelGGL(k_passed_bases, dim3(1024), dim3(256), 0, st, n, length, passed, d_acc);
+        }
         unsigned long long passed_bases = 0;
         FLX_HIP(ctx, hipMemcpyAsync(&passed_bases, d_acc, 8, hipMemcpyDeviceToHost, st));
         FLX_HIP(ctx, hipStreamSynchronize(st));
@@ -704,11 +829,11 @@ static int rank_and_cut_impl(flx_ctx *ctx, uint64_t n_total, const double *mean_
     const unsigned nb = (unsigned)((n + 255) / 256);
     if (!need_sort) {
         if (d_final_score && n) {
-            flx_time_begin(ctx, "flx_rank_final_score");
+            TimeScope t(ctx, "flx_rank_final_score");
             hipLaunchKernelGGL(k_final_score, dim3(nb), dim3(256), 0, st, n, mean, window, length, s,
                                (double *)d_final_score, (uint64_t *)nullptr, (uint32_t *)nullptr,
                                (unsigned int *)nullptr);
-            flx_time_end(ctx);
+            t.end();
             FLX_HIP(ctx, hipStreamSynchronize(st));
         }
         return FLX_OK;
@@ -762,6 +887,18 @@ extern "C" int flx_rank_and_cut_sharded_dev(flx_ctx *ctx, uint64_t n_total, cons
     return rank_and_cut_impl(ctx, n_total, (const double *)d_mean_q_all, n_local, (const double *)d_window_q,
                              (const int32_t *)d_length, (uint8_t *)d_passed, lw, mw, ww, target_bases_set, target_bases,
                              keep_percent_set, keep_percent, total_bases, d_final_score, rep, sh);
+}
+
+int flx_rank_and_cut_sharded_comm(flx_ctx *ctx, uint64_t n_total, const double *d_mean_all, uint64_t first, uint64_t n_local,
+                                  const double *d_window, const int32_t *d_length, uint8_t *d_passed, double lw, double mw,
+                                  double ww, int target_bases_set, int64_t target_bases, int keep_percent_set,
+                                  double keep_percent, int64_t total_bases, void *d_final_score, int rank, int world,
+                                  flx_cut_report *rep) {
+    memset(rep, 0, sizeof *rep);
+    Shard sh;
+    sh.use_comm = true; sh.first = first; sh.rank = rank; sh.world = world;
+    return rank_and_cut_impl(ctx, n_total, d_mean_all, n_local, d_window, d_length, d_passed, lw, mw, ww, target_bases_set,
+                             target_bases, keep_percent_set, keep_percent, total_bases, d_final_score, rep, sh);
 }
 
 extern "C" int flx_rank_and_cut(flx_ctx *ctx, uint64_t n, const double *mean_q, const double *window_q,

@@ -24,3 +24,11 @@ int flx_exclusive_scan_i64(flx_ctx *ctx, uint64_t n, const int64_t *in, int64_t 
 int flx_exclusive_scan_f64_approx(flx_ctx *ctx, uint64_t n, double *data, void *workspace);
 int flx_exclusive_scan_u32(flx_ctx *ctx, uint64_t n, const uint32_t *in, uint32_t *out, void *workspace,
                            size_t workspace_bytes);
+
+// rank.hip: the sharded global stage with the context's RCCL communicator as transport (called by comm.hip once the mean
+// qualities of all ranks are gathered in d_mean_all)
+int flx_rank_and_cut_sharded_comm(flx_ctx *ctx, uint64_t n_total, const double *d_mean_all, uint64_t first, uint64_t n_local,
+                                  const double *d_window, const int32_t *d_length, uint8_t *d_passed, double lw, double mw,
+                                  double ww, int target_bases_set, int64_t target_bases, int keep_percent_set,
+                                  double keep_percent, int64_t total_bases, void *d_final_score, int rank, int world,
+                                  flx_cut_report *rep);

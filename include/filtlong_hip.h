@@ -201,6 +201,29 @@ int flx_rank_and_cut_sharded_dev(flx_ctx *ctx, uint64_t n_total, const void *d_m
                                  int64_t total_bases, void *d_final_score, int rank, int world,
                                  flx_allreduce_u64_fn reduce, void *user, flx_cut_report *report);
 
+/* Multi-GPU without a host framework: one process per GPU, each with one context; the library owns the RCCL communicator
+ * (loaded with dlopen on first use) and does the exchange of the global stage itself, on device buffers on the context's
+ * stream (no host synchronisation inside the 8 selection passes):
+ *     rank 0: flx_comm_unique_id(ctx, id) -> hand the 128 bytes to every rank (file, socket, launcher, ...)
+ *     all:    flx_comm_init(ctx, id, rank, world)
+ *     all:    flx_score_batch_dev(...) on the rank's own reads (contiguous block of file order, sharded by count)
+ *     all:    flx_rank_and_cut_comm_dev(...)  = ONE all-gather of the mean qualities over xGMI + the sharded stage above;
+ *             the rare NaN / tie cases that need the reference's std::sort over all reads gather the remaining fields and
+ *             run the replicated stage internally.  `total_bases` is the GLOBAL sum (flx_comm_sum_u64 helps).
+ * Without a communicator flx_rank_and_cut_comm_dev is flx_rank_and_cut_dev.  The reference has no counterpart (single
+ * process, src/main.cpp:37-321). */
+#define FLX_COMM_ID_BYTES 128
+int flx_comm_unique_id(flx_ctx *ctx, void *id_out /* FLX_COMM_ID_BYTES */);
+int flx_comm_init(flx_ctx *ctx, const void *id, int rank, int world);
+int flx_comm_destroy(flx_ctx *ctx);
+int flx_comm_rank(const flx_ctx *ctx);
+int flx_comm_world(const flx_ctx *ctx);
+int flx_comm_sum_u64(flx_ctx *ctx, uint64_t *host_buf, uint64_t count); /* element-wise sum over all ranks, in place */
+int flx_rank_and_cut_comm_dev(flx_ctx *ctx, uint64_t n_local, const void *d_mean_q, const void *d_window_q,
+                              const void *d_length, void *d_passed, double length_weight, double mean_q_weight,
+                              double window_q_weight, int target_bases_set, int64_t target_bases, int keep_percent_set,
+                              double keep_percent, int64_t total_bases, void *d_final_score, flx_cut_report *report);
+
 /* ------------------------------------------------------------------------------------------
  * seam 1 — reference 16-mer set   (replaces Kmers, src/kmers.cpp:28-172 + src/bloom_filter.h)
  *

@@ -94,6 +94,51 @@ def test_ties_straddling_the_cut(ctx):
     assert fallbacks > 0
 
 
+def test_equal_scores_with_different_lengths_at_the_cut(ctx):
+    """length_weight 0 makes the score independent of the length, so reads with equal qualities but DIFFERENT lengths tie
+    exactly.  When the target falls inside such a group the kept set depends on the order inside it (lengths {10, 20}
+    entering at target - 15: one order keeps both, the other only the second), i.e. on libstdc++'s unstable std::sort:
+    the library must notice that and take the reference's own order (n > 16, so introsort really permutes)."""
+    rng = np.random.RandomState(5)
+    n = 400
+    mean = rng.uniform(60, 99, n)
+    window = mean * rng.uniform(0.5, 1.0, n)
+    length = rng.randint(500, 3000, n).astype(np.int32)
+    for g in range(60):  # tie groups of 2..5 members with different lengths
+        members = rng.choice(n, rng.randint(2, 6), replace=False)
+        mean[members] = mean[members[0]]
+        window[members] = window[members[0]]
+    passed = (rng.random_sample(n) > 0.05).astype(np.uint8)
+    tot = int(length.astype(np.int64).sum())
+    fallbacks = 0
+    for t in range(tot // 20, tot - tot // 20, tot // 300):
+        fallbacks += compare(ctx, mean, window, length, passed, target_bases=int(t), lw=0.0).exact_fallback
+    assert fallbacks > 0
+
+
+def test_comm_single_rank_matches_plain_stage(ctx):
+    """flx_rank_and_cut_comm_dev over a one-rank RCCL communicator (ncclCommInitRank, all-gather of the mean qualities,
+    device-side all-reduces inside the selection) gives the result of flx_rank_and_cut_dev."""
+    import torch
+    mean, window, length, passed = random_reads2(50_000, 17, dup=300)
+    tot = int(length.astype(np.int64).sum())
+    c2 = api.Context(0)
+    try:
+        c2.comm_init(c2.comm_unique_id(), 0, 1)
+        assert int(c2.comm_sum_u64([5, 7])[1]) == 7
+        for target in (tot // 3, tot // 2, int(tot * 0.9)):
+            want = ctx.rank_and_cut(mean, window, length, passed, target_bases=target, total_bases=tot)
+            d_mean, d_win = torch.from_numpy(mean).cuda(), torch.from_numpy(window).cuda()
+            d_len, d_pass = torch.from_numpy(length).cuda(), torch.from_numpy(passed.copy()).cuda()
+            torch.cuda.synchronize()
+            rep = c2.rank_and_cut_comm_dev(len(mean), d_mean.data_ptr(), d_win.data_ptr(), d_len.data_ptr(), d_pass.data_ptr(),
+                                           target_bases=target, total_bases=tot)
+            assert (d_pass.cpu().numpy() == want["passed"]).all()
+            assert rep.kept_bases == want["report"].kept_bases and rep.mean_quality == want["report"].mean_quality
+    finally:
+        c2.close()
+
+
 def test_all_equal_quality_gives_nan_scores(ctx):
     """stdev == 0 -> 0/0 (main.cpp:192-195,206): all scores NaN; must follow the reference's order, not crash."""
     n = 500
