@@ -2,19 +2,26 @@
 """bench.py — throughput of the Filtlong scoring hot path on MI355X.
 
 One "step" = one pass of the hot path over the whole synthetic batch resident in HBM:
-    flx_score_batch_dev   (per-read mean / sliding-window quality, hard cut-offs)
-  + [N > 1: one RCCL all-gather of the per-read (mean_q, window_q, length, passed) records]
-  + flx_rank_and_cut_dev  (exact statistics, normalise, final score, radix sort, --target_bases cut)
+    flx_score_batch_dev        per-read scoring (Phred: mean / sliding-window quality; k-mer: coverage, first/last,
+                               trim/split children), hard cut-offs
+  + the global stage           exact statistics, normalise, final score, --target_bases cut
+                               (N = 1: flx_rank_and_cut_dev;  N > 1: flx_rank_and_cut_comm_dev = ONE RCCL all-gather of
+                               the mean qualities over xGMI + the selection's histograms all-reduced on the device)
 
-Workload (BASELINE.json configs[1], C2): 10 M synthetic reads per GPU, gamma(k=4) lengths with mean
-10 kbp (1e11 bases per GPU), Phred-only, --target_bases 50g per GPU.  Weak scaling: rank r owns reads
-[r*10M, (r+1)*10M) (configs[4], C5, at 8 GPUs); the global stage is replicated on every rank after the
-all-gather so the threshold is exact.
+Workloads (BASELINE.json `configs`), `--config`:
+    c2      10 M reads per GPU x gamma(k=4) mean 10 kbp (1e11 bases), Phred-only, --target_bases 50 %   (default: the
+            configuration BASELINE.json's metric is quoted on; weak scaling, C5 at 8 GPUs)
+    c2wide  the same with the wide quality profile (per-read centre Q3..Q44, q <= 50 instead of Q8..Q25 +-8)
+    c3      10 M reads drawn from a 5 Mbp reference, -a assembly (k-mer mode), --target_bases 50 %
+    c4      the same reads, -1/-2 short-read reference (1e6 error-free 100 bp pairs), --trim --split 500
+The default run times c2 and then — outside the timed region, N = 1 only, `--no-extras` skips it — measures c2wide, c3
+and c4 (one or two steps each) and both implementations of the cut (radix select / radix sort), reported under
+`extras` on the same JSON line.
 
-Prints ONE JSON line (rank 0).  `value` = total bases over all ranks / max-over-ranks wall time of the
-timed steps.  The `roofline` object is for the dominant kernel (flx_score_phred_ring), timed with HIP
-events on the stream it runs on; `cpu_baseline` is the reference's own compiled code (oracle/_ref/ref_bench,
-kind "reference") on a bounded sample on this box's host cores (1 thread: the reference is single-threaded).
+Prints ONE JSON line (rank 0).  `value` = total bases over all ranks / max-over-ranks wall time of the timed steps.
+`roofline` is for the dominant kernel, timed with HIP events on the stream it runs on; `cpu_baseline` is the reference's
+own compiled code (oracle/_ref/ref_bench, kind "reference") on a bounded sample on this box's host cores (1 thread: the
+reference is single-threaded).
 """
 import argparse
 import ctypes as C
@@ -22,6 +29,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,20 +37,25 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+RANDOM_REQ_PEAK_G = 55.0     # tools/randbench: random 4-byte reads from a table beyond the L2, G requests/s (64 B each)
+REF_LEN = 5_000_000
 
 
-def cpu_baseline(sample_reads):
-    """Time the CPU reference on a bounded sample of the same workload (rank 0, N == 1 only)."""
+def _run_ref_bench(argv):
     ref_bench = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
     env = dict(os.environ, LANG="C", LC_ALL="C")
-    cores = 1
-    if os.path.exists(ref_bench):
+    out = subprocess.run([ref_bench] + [str(a) for a in argv], env=env, check=True, stdout=subprocess.PIPE,
+                         stderr=subprocess.DEVNULL).stdout.decode()
+    return json.loads(out.strip().splitlines()[-1])
+
+
+def cpu_baseline_phred(sample_reads):
+    """Time the CPU reference on a bounded sample of the same workload (rank 0, N == 1 only)."""
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_bench")):
         # ~half of the sample's bases as target, like --target_bases 50g on 1e11 bases
-        out = subprocess.run([ref_bench, str(sample_reads), "0", str(sample_reads * 5000)], env=env, check=True,
-                             stdout=subprocess.PIPE).stdout.decode()
-        r = json.loads(out)
-        return {"value": round(r["mbases_per_s"], 3), "unit": "Mbases/s", "cores": cores, "kind": "reference",
+        r = _run_ref_bench([sample_reads, 0, sample_reads * 5000])
+        return {"value": round(r["mbases_per_s"], 3), "unit": "Mbases/s", "cores": 1, "kind": "reference",
                 "sample": "%d reads / %d bases of the same synthetic Phred-only workload, reference objects "
                           "(Read::Read + set_final_score + std::sort) in memory, %.1f s score + %.2f s rank"
                           % (r["reads"], r["bases"], r["score_s"], r["rank_s"]),
@@ -53,9 +66,191 @@ def cpu_baseline(sample_reads):
                                     C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     ss, rs, tb, kb = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
     lib.flo_bench_phred(sample_reads, 20250919, 0, sample_reads * 5000, ss, rs, tb, kb)
-    return {"value": round(tb.value / (ss.value + rs.value) / 1e6, 3), "unit": "Mbases/s", "cores": cores,
+    return {"value": round(tb.value / (ss.value + rs.value) / 1e6, 3), "unit": "Mbases/s", "cores": 1,
             "kind": "port", "sample": "%d reads / %d bases, oracle restatement in memory" % (sample_reads, tb.value),
             "host_cores_available": os.cpu_count()}
+
+
+def cpu_baseline_kmer(cfg, sample_reads, full_set):
+    """K-mer mode on the CPU reference: sample reads + the 5 Mbp reference written to a temp dir, scored by the reference's
+    own objects in memory (oracle/_ref/ref_bench kmer).  C4's short-read set takes the reference ~80 s to hash
+    (profiles/r02_cpu_kmer.txt); unless `full_set`, the C4 sample is scored against the set built from the assembly,
+    which holds the same 16-mers (9,988,379 vs 9,988,279) — set-build time is reported separately either way."""
+    from filtlong_amd import synth
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_bench")):
+        return None
+    ref = synth.bases_read(synth.STREAM_REF, 0, 0, REF_LEN)
+    lens = synth.lengths(sample_reads)
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "ref.fasta"), "wb") as f:
+            f.write(b">ref\n" + ref.tobytes() + b"\n")
+        with open(os.path.join(d, "reads.fastq"), "wb") as f:
+            for i, L in enumerate(lens):
+                f.write(b"@r%d\n" % i + synth.seq_read(i, int(L), ref).tobytes() + b"\n+\n" + b"I" * int(L) + b"\n")
+        opts = ["-a", os.path.join(d, "ref.fasta")]
+        note = "set from the assembly"
+        if cfg == "c4":
+            if full_set:
+                r1, r2 = short_read_pairs(ref)
+                for name, arr in (("r1.fq", r1), ("r2.fq", r2)):
+                    with open(os.path.join(d, name), "wb") as f:
+                        q = b"I" * 100
+                        for i in range(arr.shape[0]):
+                            f.write(b"@p%d\n" % i + arr[i].tobytes() + b"\n+\n" + q + b"\n")
+                opts = ["-1", os.path.join(d, "r1.fq"), "-2", os.path.join(d, "r2.fq")]
+                note = "set from the 1e6 short-read pairs"
+            else:
+                note = "set from the assembly (same 16-mers as the short-read set, which takes the reference ~80 s to hash)"
+            opts += ["--trim", "--split", "500"]
+        r = _run_ref_bench(["kmer", os.path.join(d, "reads.fastq"), int(lens.astype(np.int64).sum()) // 2] + opts)
+    return {"value": round(r["mbases_per_s"], 3), "unit": "Mbases/s", "cores": 1, "kind": "reference",
+            "sample": "%d reads / %d bases of the same synthetic k-mer workload, reference objects in memory, %s: "
+                      "%.1f s score + %.3f s rank (set build %.1f s, not counted)"
+                      % (r["reads"], r["bases"], note, r["score_s"], r["rank_s"], r["set_build_s"]),
+            "host_cores_available": os.cpu_count()}
+
+
+def short_read_pairs(ref):
+    """C4 reference: 1e6 error-free pairs of 100 bp per 5 Mbp (40x): -1 forward substring, -2 reverse complement of the
+    substring 350 bp downstream."""
+    from filtlong_amd import synth
+    npairs = len(ref) // 5
+    starts = (synth.mix(synth.SEED, synth.STREAM_START, np.arange(npairs, dtype=np.uint64) + np.uint64(1 << 40), 0)
+              % np.uint64(len(ref) - 450)).astype(np.int64)
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    idx = starts[:, None] + np.arange(100)[None, :]
+    return ref[idx], comp[ref[idx + 350]][:, ::-1]
+
+
+class Batch:
+    """The packed batch of one rank in HBM (layout, processing order, id range)."""
+
+    def __init__(self, ctx, torch, dev, n, first, fixed_len):
+        from filtlong_amd import api, synth
+        self.n = n
+        self.lengths = synth.lengths(n, first=first, fixed=fixed_len or None)
+        offsets = np.zeros(n, dtype=np.uint64)
+        pb = C.c_uint64()
+        ctx.L.flx_plane_layout(self.lengths.ctypes.data, n, offsets.ctypes.data, C.byref(pb))
+        self.plane_bytes = pb.value
+        order = api.length_order(self.lengths)
+        self.bases = int(self.lengths.astype(np.int64).sum())
+        self.d_plane = torch.empty(self.plane_bytes, dtype=torch.uint8, device=dev)
+        self.d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+        self.d_len = torch.from_numpy(self.lengths).to(dev)
+        self.d_ord = torch.from_numpy(order.view(np.int32)).to(dev)
+        self.d_ids = torch.arange(first, first + n, dtype=torch.int64, device=dev)
+
+
+def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac):
+    """C3 / C4 on one GPU: k-mer scoring + reads2 gather + global stage; returns the result dictionary."""
+    from filtlong_amd import api, synth, _lib
+    ref = synth.bases_read(synth.STREAM_REF, 0, 0, REF_LEN)
+    t0 = time.time()
+    ks = api.Kmers(ctx)
+    if cfg == "c4":
+        r1, r2 = short_read_pairs(ref)
+        ks.add_read_fastqs([[r.tobytes() for r in r1], [r.tobytes() for r in r2]])
+    else:
+        ks.add_assembly_fasta([ref.tobytes()])
+    ks.finalize()
+    build_s = time.time() - t0
+    b = Batch(ctx, torch, dev, n, 0, 0)
+    d_ref = torch.from_numpy(ref).to(dev)
+    torch.cuda.synchronize()
+    ctx.synth_seq_dev(synth.SEED, b.d_plane.data_ptr(), b.plane_bytes, b.d_off.data_ptr(), b.d_len.data_ptr(),
+                      b.d_ids.data_ptr(), n, d_ref.data_ptr(), REF_LEN)
+    trim_split = cfg == "c4"
+    cap = 4 * n if trim_split else 16
+    t = {k: torch.zeros(sz, dtype=dt, device=dev) for k, sz, dt in (
+        ("mean", n, torch.float64), ("win", n, torch.float64), ("pass", n, torch.uint8), ("first", n, torch.int32),
+        ("last", n, torch.int32), ("coff", n + 1, torch.int64), ("crng", 2 * cap, torch.int32), ("cmean", cap, torch.float64),
+        ("cwin", cap, torch.float64), ("cpass", cap, torch.uint8))}
+    params = api.make_params(trim=trim_split, split=500 if trim_split else None)
+    s = _lib.Scores()
+    s.mean_q, s.window_q, s.passed, s.first, s.last = (t["mean"].data_ptr(), t["win"].data_ptr(), t["pass"].data_ptr(),
+                                                      t["first"].data_ptr(), t["last"].data_ptr())
+    s.child_offsets, s.child_ranges, s.child_mean_q, s.child_window_q, s.child_passed = (
+        t["coff"].data_ptr(), t["crng"].data_ptr(), t["cmean"].data_ptr(), t["cwin"].data_ptr(), t["cpass"].data_ptr())
+    s.child_capacity = cap
+    target = int(b.bases * target_frac)
+    idx_n = torch.arange(n, dtype=torch.int64, device=dev)
+
+    def step():
+        ctx.score_kmer_dev(ks, b.d_plane.data_ptr(), b.plane_bytes, b.d_off.data_ptr(), b.d_len.data_ptr(),
+                           b.d_ord.data_ptr(), n, params, s)
+        nc = int(s.n_children)
+        if nc == 0:
+            m2, w2, l2, p2 = t["mean"], t["win"], b.d_len, t["pass"].clone()
+        else:
+            # reads2 (src/main.cpp:138-147): file order, every parent with children replaced in place by its children
+            cnt = t["coff"][1:] - t["coff"][:-1]
+            size = torch.where(cnt > 0, cnt, torch.ones_like(cnt))
+            parent = torch.repeat_interleave(idx_n, size)
+            start2 = torch.cumsum(size, 0) - size
+            is_child = cnt[parent] > 0
+            ci = torch.where(is_child, t["coff"][:-1][parent] + (torch.arange(parent.numel(), device=dev) - start2[parent]),
+                             torch.zeros_like(parent))
+            crng = t["crng"].view(-1, 2)
+            m2 = torch.where(is_child, t["cmean"][ci], t["mean"][parent])
+            w2 = torch.where(is_child, t["cwin"][ci], t["win"][parent])
+            l2 = torch.where(is_child, crng[ci, 1] - crng[ci, 0], b.d_len[parent]).to(torch.int32)
+            p2 = torch.where(is_child, t["cpass"][ci], t["pass"][parent])
+        torch.cuda.synchronize()
+        rep = ctx.rank_and_cut_dev(m2.numel(), m2.data_ptr(), w2.data_ptr(), l2.data_ptr(), p2.data_ptr(),
+                                   target_bases=target, total_bases=b.bases)
+        return rep, nc, m2.numel()
+
+    for _ in range(warmup):
+        step()
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rep, nc, n2 = step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    cover_ms, cn = ctx.timing_get("flx_score_kmer_cover")
+    fold_ms, _ = ctx.timing_get("flx_score_kmer_fold")
+    rank_ms, _ = ctx.timing_get("flx_rank")
+    ctx.timing_enable(False)
+    cover = cover_ms / max(cn, 1)
+    lookups = b.bases - 15 * n
+    # far (beyond-L2) 64-byte requests of one k_kmer_cover launch: PMC pass of this same command (profiles/), when recorded
+    far = None
+    fpath = os.path.join(ROOT, "profiles", "r02_kmer_far_requests.json")
+    if os.path.exists(fpath):
+        rec = json.load(open(fpath)).get(cfg)
+        if rec and rec.get("reads") == n:
+            far = rec
+    algo_bytes = b.bases + 33 * n + 25 * nc  # SURVEY §8d: L + 8 + 25 per read, 8 + 17 per child
+    out = {
+        "workload": "%s: %s reads x gamma(k=4) mean 10 kbp from a 5 Mbp reference, %s, --target_bases %d" % (
+            cfg.upper(), "{:,}".format(n),
+            "-1/-2 short-read reference, --trim --split 500" if trim_split else "-a assembly", target),
+        "value": round(b.bases / el / 1e6, 1), "unit": "Mbases/s", "ms_per_step": round(el * 1e3, 2),
+        "bases": b.bases, "set_size": len(ks), "set_build_s_device": round(build_s, 2), "children": nc, "reads2": n2,
+        "stage_ms_per_step": {"cover_kernel": round(cover, 2), "fold_kernels": round(fold_ms / steps, 2),
+                              "rank_kernels": round(rank_ms / steps, 2)},
+        "lookups_per_s_G": round(lookups / (cover * 1e-3) / 1e9, 2),
+        "roofline": {
+            "bound": "hbm", "kernel": "k_kmer_cover",
+            "note": "bound by random 64-byte fabric requests into the 512 MiB exact 16-mer bitmap, not by streaming: `achieved` = "
+                    "far requests x 64 B / kernel time (requests from the PMC pass recorded in profiles/, not from this run), "
+                    "`peak` = the measured random-request ceiling (tools/randbench: 55 G requests/s x 64 B); the streamed "
+                    "bytes (SURVEY §8d, `algorithmic_bytes`) are %.1f %% of the 8 TB/s HBM peak over the whole step" % (
+                        100.0 * algo_bytes / el / 1e9 / HBM_PEAK_GBS),
+            "achieved": round(far["far_requests"] * 64 / (cover * 1e-3) / 1e9, 1) if far else None,
+            "peak": RANDOM_REQ_PEAK_G * 64, "unit": "GB/s",
+            "frac": round(far["far_requests"] / (cover * 1e-3) / 1e9 / RANDOM_REQ_PEAK_G, 4) if far else None,
+            "traffic": int(far["traffic_bytes"]) if far else None, "avg_kernel_ms": round(cover, 3),
+            "algorithmic_bytes": int(algo_bytes)},
+        "cut": {"target_bases": int(rep.target_bases), "kept_bases": int(rep.kept_bases), "outcome": int(rep.outcome)},
+    }
+    ks.close()
+    return out
 
 
 def main():
@@ -63,15 +258,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=("c2", "c2wide", "c3", "c4"), default="c2")
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (default: the C2 workload)")
     ap.add_argument("--fixed-len", type=int, default=0, help="fixed read length (C1 uses 5000); 0 = gamma lengths")
     ap.add_argument("--target-frac", type=float, default=0.5, help="--target_bases as a fraction of all bases")
     ap.add_argument("--cpu-sample-reads", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-reads-kmer", type=int, default=2000)
+    ap.add_argument("--full-cpu-baseline", action="store_true", help="c4: let the CPU reference hash the short reads itself (~80 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="default config only: skip the c2wide / c3 / c4 / cut-path extras")
     ap.add_argument("--window-size", type=int, default=250)
-    ap.add_argument("--global-stage", choices=("sharded", "replicated"), default="sharded",
-                    help="N > 1: all-gather the mean qualities and select with all-reduced histograms (default), or "
-                         "all-gather the full per-read records and replicate the single-GPU stage")
+    ap.add_argument("--global-stage", choices=("rccl", "sharded", "replicated"), default="rccl",
+                    help="N > 1: rccl = the library's own communicator (flx_rank_and_cut_comm_dev: one all-gather of the mean "
+                         "qualities, histograms all-reduced on the device, no host round trips); sharded / replicated = the same "
+                         "exchange driven from torch.distributed (host callback / full records)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                                                        "one-GPU functional test of the N > 1 path)")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, collectives) even "
@@ -93,6 +293,8 @@ def main():
     device_index = local_rank % max(torch.cuda.device_count(), 1)  # == local_rank except in the one-GPU gloo test
     torch.cuda.set_device(device_index)
     multi = world > 1 or args.force_dist
+    if args.backend != "nccl" and args.global_stage == "rccl":
+        args.global_stage = "sharded"  # the library's communicator is RCCL only
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -108,21 +310,29 @@ def main():
     n = args.reads
     first = rank * n
 
+    if args.config in ("c3", "c4"):
+        if multi:
+            sys.exit("bench.py --config %s is a single-GPU configuration" % args.config)
+        r = run_kmer(ctx, torch, dev, args.config, n, args.steps, args.warmup, args.target_frac)
+        info = ctx.device_info()
+        out = {"metric": "Mbases/s scored+sorted", "value": r["value"], "unit": "Mbases/s", "n_gpus": 1, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "u32 k-mers / f64 scores", "data": "synthetic",
+               "config": {"workload": r["workload"], "reads_total": n, "bases_total": r["bases"], "parallelism": "1 GPU",
+                          "device": info["name"]},
+               "roofline": r["roofline"], "stage_ms_per_step": r["stage_ms_per_step"], "lookups_per_s_G": r["lookups_per_s_G"],
+               "children": r["children"], "set_size": r["set_size"], "cut": r["cut"]}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_kmer(args.config, args.cpu_sample_reads_kmer, args.full_cpu_baseline)
+        print(json.dumps(out), flush=True)
+        ctx.close()
+        return
+
+    profile = 1 if args.config == "c2wide" else 0
     # ---- build the packed batch in HBM (not timed) -----------------------------------------------
     t_setup = time.time()
-    lengths = synth.lengths(n, first=first, fixed=args.fixed_len or None)
-    offsets = np.zeros(n, dtype=np.uint64)
-    pb = C.c_uint64()
-    ctx.L.flx_plane_layout(lengths.ctypes.data, n, offsets.ctypes.data, C.byref(pb))
-    plane_bytes = pb.value
-    order = api.length_order(lengths)
-    local_bases = int(lengths.astype(np.int64).sum())
-
-    d_plane = torch.empty(plane_bytes, dtype=torch.uint8, device=dev)
-    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
-    d_len = torch.from_numpy(lengths).to(dev)
-    d_ord = torch.from_numpy(order.view(np.int32)).to(dev)
-    d_ids = torch.arange(first, first + n, dtype=torch.int64, device=dev)
+    b = Batch(ctx, torch, dev, n, first, args.fixed_len)
+    plane_bytes, local_bases = b.plane_bytes, b.bases
     # packed per-read record buffer [mean f64 | window f64 | length i32 | passed u8] -> one all-gather
     d_rec = fdist.alloc_records(n, dev)
     p_mean = d_rec.data_ptr()
@@ -130,34 +340,44 @@ def main():
     p_len = p_mean + 16 * n
     p_pass = p_mean + 20 * n
     t_mean, t_win, t_len, t_pass = fdist.record_views(d_rec, n)
-    t_len.copy_(d_len)
+    t_len.copy_(b.d_len)
     torch.cuda.synchronize()
-    ctx.synth_qual_dev(synth.SEED, d_plane.data_ptr(), plane_bytes, d_off.data_ptr(), d_len.data_ptr(),
-                       d_ids.data_ptr(), n)
-    del d_ids
+    ctx.synth_qual_dev(synth.SEED, b.d_plane.data_ptr(), plane_bytes, b.d_off.data_ptr(), b.d_len.data_ptr(),
+                       b.d_ids.data_ptr(), n, profile=profile)
 
     total_n = n * world
     if multi:
         tb = torch.tensor([local_bases], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tb)
         total_bases = int(tb.item())
+        if args.global_stage == "rccl":
+            # the library's own RCCL communicator: rank 0 draws the id, torch.distributed only carries its 128 bytes
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
     else:
         total_bases = local_bases
     target = int(total_bases * args.target_frac)
     params = api.make_params(window_size=args.window_size)
     setup_s = time.time() - t_setup
 
-    def step():
-        ctx.score_reads_dev(d_plane.data_ptr(), plane_bytes, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n,
+    def score():
+        ctx.score_reads_dev(b.d_plane.data_ptr(), plane_bytes, b.d_off.data_ptr(), b.d_len.data_ptr(), b.d_ord.data_ptr(), n,
                             params, p_mean, p_win, p_pass)
+
+    def step():
+        score()
+        if multi and args.global_stage == "rccl":
+            return ctx.rank_and_cut_comm_dev(n, p_mean, p_win, p_len, p_pass, target_bases=target, total_bases=total_bases)
         if multi and args.global_stage == "sharded":
-            # ONE RCCL all-gather of the mean qualities (the statistics fold over all of them in file order); final
-            # scores and the cut are computed on the local reads, the selection's histograms all-reduced
-            # (filtlong_amd/dist.py, flx_rank_and_cut_sharded_dev).
+            # ONE all-gather of the mean qualities through torch.distributed; the selection's histograms go through the
+            # host callback (filtlong_amd/dist.py, flx_rank_and_cut_sharded_dev).
             return fdist.sharded_rank_and_cut(ctx, t_mean, t_win, t_len, t_pass, target_bases=target,
                                               total_bases=total_bases)
         if multi:
-            # ONE RCCL all-gather of the full per-read records; every rank then runs the identical single-GPU stage.
+            # ONE all-gather of the full per-read records; every rank then runs the identical single-GPU stage.
             g_mean, g_win, g_len, g_pass, _counts = fdist.gather_records(d_rec, n)
             torch.cuda.synchronize()
             rep = ctx.rank_and_cut_dev(total_n, g_mean.data_ptr(), g_win.data_ptr(), g_len.data_ptr(),
@@ -191,7 +411,11 @@ def main():
     k_ms, k_n = ctx.timing_get(kernel_name)
     rank_ms, _ = ctx.timing_get("flx_rank")
     sort_ms, _ = ctx.timing_get("flx_sort")
+    comm_ms, _ = ctx.timing_get("flx_comm")
     ctx.timing_enable(False)
+    if args.dump_flags:
+        torch.cuda.synchronize()
+        np.save("%s.rank%d.npy" % (args.dump_flags, rank), t_pass.cpu().numpy())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -200,12 +424,15 @@ def main():
         algo_bytes = local_bases + 25 * n
         avg_kernel_ms = k_ms / max(k_n, 1)
         achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 if k_n else 0.0
-        # HBM traffic of one launch from the PMC passes of tools/prof_phred.sh (separate rocprofv3 --pmc runs of this same
-        # C2 command; FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md prescribes), only when the workload is the same.
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_c2.json")
-        if os.path.exists(tpath) and n == 10_000_000 and not args.fixed_len and args.window_size == 250:
-            traffic = int(json.load(open(tpath))["traffic_bytes"])
+        # HBM traffic of one launch: PMC passes of this same command (tools/prof_phred.sh: separate rocprofv3 --pmc runs;
+        # FETCH_SIZE x2 on gfx950 — calibrated for this kernel's 64-byte-per-read pattern on a known byte count,
+        # profiles/r02_microbench.txt), recorded in profiles/ — NOT measured in this run; only quoted for the same workload.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic_c2.json")
+        if os.path.exists(tpath) and n == 10_000_000 and not args.fixed_len and args.window_size == 250 and profile == 0:
+            rec = json.load(open(tpath))
+            if rec.get("kernel") == kernel_name:
+                traffic, traffic_src = int(rec["traffic_bytes"]), "profiles/r02_traffic_c2.json (PMC pass of this command, not this run)"
         info = ctx.device_info()
         out = {
             "metric": "Mbases/s scored+sorted",
@@ -221,33 +448,92 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s synthetic reads per GPU x %s, Phred-only, --target_bases %d (%.0f%% of bases)%s" % (
+                "workload": "%s synthetic reads per GPU x %s, Phred-only%s, --target_bases %d (%.0f%% of bases)%s" % (
                     "{:,}".format(n), ("fixed %d bp" % args.fixed_len) if args.fixed_len else "gamma(k=4) mean 10 kbp",
-                    target, args.target_frac * 100, "; C2" if (n == 10_000_000 and not args.fixed_len) else ""),
+                    " (wide quality profile)" if profile else "", target, args.target_frac * 100,
+                    "; C2" if (n == 10_000_000 and not args.fixed_len and not profile) else ""),
                 "reads_total": total_n, "bases_total": total_bases, "window_size": args.window_size,
                 "parallelism": ("1 GPU" if not multi else
-                                "reads sharded by count; 1 RCCL all-gather of mean qualities + all-reduced selection histograms"
-                                if args.global_stage == "sharded" else
-                                "reads sharded by count; 1 RCCL all-gather of per-read records, global stage replicated"),
+                                "reads sharded by count; library-owned RCCL communicator: 1 all-gather of mean qualities + "
+                                "selection histograms all-reduced on the device" if args.global_stage == "rccl" else
+                                "reads sharded by count; 1 all-gather of mean qualities + all-reduced selection histograms "
+                                "(torch.distributed, host callback)" if args.global_stage == "sharded" else
+                                "reads sharded by count; 1 all-gather of per-read records, global stage replicated"),
                 "device": info["name"],
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_kernel_ms": round(avg_kernel_ms, 3), "launches": int(k_n), "algorithmic_bytes": int(algo_bytes),
             },
             "stage_ms_per_step": {"score_kernel": round(k_ms / args.steps, 3), "sort": round(sort_ms / args.steps, 3),
-                                  "rank_other_kernels": round(rank_ms / args.steps, 3)},
+                                  "rank_other_kernels": round(rank_ms / args.steps, 3),
+                                  "comm": round(comm_ms / args.steps, 3)},
             "cut": {"target_bases": int(rep.target_bases), "kept_bases": int(rep.kept_bases),
                     "outcome": int(rep.outcome), "audited": int(rep.audited), "exact_fallback": int(rep.exact_fallback)},
             "setup_s": round(setup_s, 1),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_reads)
+            out["cpu_baseline"] = cpu_baseline_phred(args.cpu_sample_reads)
+
+        if world == 1 and not multi and args.config == "c2" and not args.no_extras:
+            extras = {}
+            # (1) both implementations of the cut on this batch's records: weighted radix SELECT (what the steps above ran)
+            #     and radix SORT + scan (north_star's "device radix sort over final_score"); wall time of the whole stage
+            score()  # pre-cut flags (hard cut-offs only) for both variants
+            torch.cuda.synchronize()
+            flags0 = t_pass.clone()
+            for name, env in (("select", None), ("sort", "1")):
+                if env:
+                    os.environ["FLX_RANK_SORT"] = env
+                else:
+                    os.environ.pop("FLX_RANK_SORT", None)
+                ts = []
+                for _ in range(3):
+                    score_flags = flags0.clone()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    ctx.rank_and_cut_dev(n, p_mean, p_win, p_len, score_flags.data_ptr(), target_bases=target,
+                                         total_bases=total_bases)
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                extras.setdefault("global_stage_ms", {})[name] = round(min(ts), 3)
+            os.environ.pop("FLX_RANK_SORT", None)
+            # (2) the same Phred workload with a wide quality spread
+            ctx.synth_qual_dev(synth.SEED, b.d_plane.data_ptr(), plane_bytes, b.d_off.data_ptr(), b.d_len.data_ptr(),
+                               b.d_ids.data_ptr(), n, profile=1)
+            score()
+            ctx.timing_enable(True)
+            ctx.timing_reset()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                score()
+                ctx.rank_and_cut_dev(n, p_mean, p_win, p_len, p_pass, target_bases=target, total_bases=total_bases)
+            torch.cuda.synchronize()
+            elw = (time.perf_counter() - t1) / 2
+            kname = ctx.last_phred_kernel()
+            kw_ms, kw_n = ctx.timing_get(kname)
+            ctx.timing_enable(False)
+            extras["c2_wide_quality"] = {
+                "workload": "C2 with per-read centre Q3..Q44 and q <= 50 (synth profile 1)", "value": round(local_bases / elw / 1e6, 1),
+                "unit": "Mbases/s", "ms_per_step": round(elw * 1e3, 3), "kernel": kname,
+                "avg_kernel_ms": round(kw_ms / max(kw_n, 1), 3),
+                "roofline_frac": round(algo_bytes / (kw_ms / max(kw_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            # (3) the k-mer configurations at BASELINE size (free the Phred batch first: 100 GB per plane)
+            del b, d_rec, t_mean, t_win, t_len, t_pass, flags0, score_flags
+            torch.cuda.empty_cache()
+            for cfg in ("c3", "c4"):
+                try:
+                    r = run_kmer(ctx, torch, dev, cfg, n, 2, 1, args.target_frac)
+                    if not args.no_cpu_baseline:
+                        r["cpu_baseline"] = cpu_baseline_kmer(cfg, args.cpu_sample_reads_kmer, False)
+                    extras[cfg] = r
+                except Exception as e:  # an extra must not cost the headline line
+                    extras[cfg] = {"error": repr(e)}
+                torch.cuda.empty_cache()
+            out["extras"] = extras
         print(json.dumps(out), flush=True)
-    if args.dump_flags:
-        torch.cuda.synchronize()
-        np.save("%s.rank%d.npy" % (args.dump_flags, rank), t_pass.cpu().numpy())
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -12,6 +12,10 @@
 // The reference is single-threaded, so this is a 1-core number.
 //
 // usage: ref_bench <n_reads> <fixed_len|0> <target_bases> [seed] [first_read_index]
+//        ref_bench kmer <reads.fastq> <target_bases> [filtlong options: -a ref.fasta | -1 r1.fq -2 r2.fq, --trim, --split N]
+//            k-mer mode (BASELINE configs[2]/[3]): the reads are loaded into memory first (not timed); timed separately:
+//            the reference's set build (Kmers::add_assembly_fasta / add_read_fastqs), one Read::Read per read (incl. its
+//            children), and the rank stage over reads2 (children in place of their parents, src/main.cpp:138-147).
 // prints one JSON line on stdout.
 
 #include <algorithm>
@@ -33,7 +37,102 @@ static double now_s() {
     return duration_cast<duration<double>>(steady_clock::now().time_since_epoch()).count();
 }
 
+static int kmer_mode(int argc, char **argv) {
+    std::string reads_path = argv[2];
+    long long target_arg = atoll(argv[3]);
+    std::string t = std::to_string(target_arg);
+    std::vector<const char *> fargv = {"filtlong"};
+    for (int i = 4; i < argc; ++i) fargv.push_back(argv[i]);
+    fargv.push_back("--target_bases");
+    fargv.push_back(t.c_str());
+    fargv.push_back(reads_path.c_str());
+    Arguments args((int)fargv.size(), (char **)fargv.data());
+    if (args.parsing_result != GOOD) return 2;
+
+    // load the reads (4-line FASTQ written by bench.py); not timed
+    std::vector<std::string> names, seqs, quals;
+    {
+        FILE *f = fopen(reads_path.c_str(), "r");
+        if (!f) return 2;
+        char *line = nullptr;
+        size_t cap = 0;
+        ssize_t m;
+        int k = 0;
+        while ((m = getline(&line, &cap, f)) > 0) {
+            while (m > 0 && (line[m - 1] == '\n' || line[m - 1] == '\r')) --m;
+            std::string v(line, (size_t)m);
+            if (k == 0) names.push_back(v.substr(1));
+            else if (k == 1) seqs.push_back(v);
+            else if (k == 3) quals.push_back(v);
+            k = (k + 1) & 3;
+        }
+        free(line);
+        fclose(f);
+    }
+    const long long n = (long long)seqs.size();
+    long long total_bases = 0;
+    for (auto &q : seqs) total_bases += (long long)q.size();
+
+    double t0 = now_s();
+    Kmers kmers;
+    if (args.assembly_set) kmers.add_assembly_fasta(args.assembly);
+    if (args.short_reads.size() > 0) kmers.add_read_fastqs(args.short_reads);
+    double t1 = now_s();
+
+    std::vector<Read *> reads;
+    reads.reserve(n);
+    for (long long i = 0; i < n; ++i)
+        reads.push_back(new Read(names[i], &seqs[i][0], &quals[i][0], (int)seqs[i].size(), &kmers, &args));
+    double t2 = now_s();
+
+    std::vector<Read *> reads2;  // src/main.cpp:138-147
+    long long children = 0;
+    for (auto r : reads) {
+        if (r->m_child_reads.size() > 0) {
+            for (auto c : r->m_child_reads) reads2.push_back(c);
+            children += (long long)r->m_child_reads.size();
+        } else reads2.push_back(r);
+    }
+    double qmin = 100.0, qmax = 0.0, qsum = 0.0;
+    for (auto r : reads2) {
+        qsum += r->m_mean_quality;
+        qmax = std::max(qmax, r->m_mean_quality);
+        qmin = std::min(qmin, r->m_mean_quality);
+    }
+    double qmean = qsum / reads2.size(), ssum = 0.0;
+    for (auto r : reads2) {
+        double d = r->m_mean_quality - qmean;
+        ssum += d * d;
+    }
+    double qstd = sqrt(ssum / reads2.size());
+    double zmin = qstd > 0 ? (qmin - qmean) / qstd : 1.0, zmax = qstd > 0 ? (qmax - qmean) / qstd : 1.0;
+    for (auto r : reads2) {
+        double ratio = r->m_window_quality / r->m_mean_quality;
+        if (ratio > 1.0) ratio = 1.0;
+        double z = (r->m_mean_quality - qmean) / qstd;
+        r->m_mean_quality = 100.0 * (z - zmin) / (zmax - zmin);
+        r->m_window_quality = r->m_mean_quality * ratio;
+        r->set_final_score(args.length_weight, args.mean_q_weight, args.window_q_weight);
+    }
+    long long kept = 0, kept_reads = 0;
+    if (target_arg < total_bases) {
+        std::sort(reads2.begin(), reads2.end(),
+                  [](const Read *a, const Read *b) { return a->m_final_score > b->m_final_score; });
+        for (auto r : reads2) {
+            if (r->m_passed && kept < target_arg) { kept += r->m_length; ++kept_reads; }
+            else r->m_passed = false;
+        }
+    }
+    double t3 = now_s();
+    printf("{\"reads\": %lld, \"bases\": %lld, \"set_build_s\": %.6f, \"score_s\": %.6f, \"rank_s\": %.6f, "
+           "\"mbases_per_s\": %.3f, \"children\": %lld, \"kept_bases\": %lld, \"kept_reads\": %lld}\n",
+           n, total_bases, t1 - t0, t2 - t1, t3 - t2, total_bases / ((t2 - t1) + (t3 - t2)) / 1e6, children, kept, kept_reads);
+    for (auto r : reads) delete r;
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 4 && std::string(argv[1]) == "kmer") return kmer_mode(argc, argv);
     if (argc < 4) {
         fprintf(stderr, "usage: ref_bench n_reads fixed_len|0 target_bases [seed] [first_read]\n");
         return 2;

@@ -167,7 +167,7 @@ def test_bench_two_processes_one_gpu(tmp_path, stage):
     one = str(tmp_path / "one")
     two = str(tmp_path / "two")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--reads", "40000",
-                        "--no-cpu-baseline", "--dump-flags", one], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                        "--no-cpu-baseline", "--no-extras", "--dump-flags", one], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
@@ -182,3 +182,19 @@ def test_bench_two_processes_one_gpu(tmp_path, stage):
     got = np.concatenate([np.load(two + ".rank%d.npy" % k) for k in range(2)])
     assert want.shape == got.shape and (want == got).all()
     assert 0 < int(want.sum()) < len(want)
+
+
+def test_bench_rccl_stage_single_rank(tmp_path):
+    """bench.py's default N > 1 path (the library's own RCCL communicator: ncclCommInitRank, all-gather of the mean
+    qualities, device-side all-reduces) taken with ONE rank (--force-dist): same flags as the plain single-GPU run."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741")
+    env.pop("FLX_RANK_SORT", None)
+    outs = []
+    for extra, tag in (([], "plain"), (["--force-dist", "--global-stage", "rccl"], "rccl")):
+        path = str(tmp_path / tag)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--reads", "50000",
+                            "--no-cpu-baseline", "--no-extras", "--dump-flags", path] + extra, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-3000:]
+        outs.append(np.load(path + ".rank0.npy"))
+    assert (outs[0] == outs[1]).all() and 0 < int(outs[0].sum()) < len(outs[0])
