@@ -223,8 +223,8 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac):
     fpath = os.path.join(ROOT, "profiles", "r02_kmer_far_requests.json")
     if os.path.exists(fpath):
         rec = json.load(open(fpath)).get(cfg)
-        if rec and rec.get("reads") == n:
-            far = rec
+        if rec:  # per-base figures measured at 1e6 reads, scaled to this batch (the mix of reads is the same)
+            far = {"far_requests": rec["far_requests_per_base"] * b.bases, "traffic_bytes": rec["traffic_bytes_per_base"] * b.bases}
     algo_bytes = b.bases + 33 * n + 25 * nc  # L + 8 + 25 per read, 8 + 17 per child
     out = {
         "workload": "%s: %s reads x gamma(k=4) mean 10 kbp from a 5 Mbp reference, %s, --target_bases %d" % (

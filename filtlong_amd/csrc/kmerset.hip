@@ -108,15 +108,19 @@ __global__ void __launch_bounds__(256) k_add_reference(const uint8_t *bases, con
     }
 }
 
-// every set bit of the exact bitmap sets its hashed bit of the prefilter
+// every member of the exact bitmap marks its five 12-mers in the prefilter
 __global__ void __launch_bounds__(256) k_build_prefilter(const uint32_t *bm, uint64_t n_words, uint32_t *pre) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t w = bm[i];
         while (w) {
             const int b = __ffs(w) - 1;
             w &= w - 1;
-            const uint32_t h = flx_prefilter_hash((uint32_t)(i << 5) | (uint32_t)b);
-            atomicOr(&pre[h >> 5], 1u << (h & 31));
+            const uint32_t k = (uint32_t)(i << 5) | (uint32_t)b;
+#pragma unroll
+            for (int d = 0; d < 5; ++d) {
+                const uint32_t h = flx_sub12(k, d);
+                atomicOr(&pre[h >> 5], 1u << (h & 31));
+            }
         }
     }
 }
@@ -541,7 +545,7 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
     FLX_HIP(ctx, hipMemcpyAsync(&sz, scr, 8, hipMemcpyDeviceToHost, st));
     FLX_HIP(ctx, hipStreamSynchronize(st));
     s->size = sz;
-    // prefilter: worth its L2 footprint while it stays sparse (expected density 1 - exp(-size / 2^24) < ~0.8)
+    // prefilter: worth its L2 footprint while the 12-mer table stays sparse (a genome beyond ~20 Mbp saturates it)
     const char *pf_env = getenv("FLX_KMER_PREFILTER");  // "0" disables (A/B measurements)
     const bool pf_off = pf_env && pf_env[0] == '0';
     if (!pf_off && sz > 0 && sz < (3ull << (kPrefilterBits - 1))) {

@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
                                                               const uint32_t *prefilter, uint32_t *cov, const uint64_t *cov_off, int32_t *count,
                                                               int32_t *first, int32_t *last) {
     __shared__ uint32_t sh_hits[COVER_THREADS];
+    __shared__ uint16_t sh_p12[COVER_THREADS];
     __shared__ uint8_t sh_anchor[COVER_THREADS];
     __shared__ uint32_t sh_carry;
     __shared__ int sh_cnt[COVER_THREADS / 64], sh_first[COVER_THREADS / 64], sh_last[COVER_THREADS / 64];
@@ -61,10 +62,14 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
         const int n_spans = (L + COVER_SPAN - 1) / COVER_SPAN;
         for (int sp = n_spans - 1; sp >= 0; --sp) {  // descending: the right neighbour's hits are already known
             const int p0 = sp * COVER_SPAN + t * 16;
+            const bool active = p0 < L && L >= 16;
             uint32_t hits = 0;
             uint32_t kmers[16];
+            uint32_t kleft[4] = {0, 0, 0, 0};  // the 16-mers ending at p0-4 .. p0-1 (their low 24 bits are the 12-mers there)
+            uint32_t p12 = 0;                  // bit j: the 12-mer ending at p0 + j occurs in the set
+            uint32_t p12_left = 0;             // the same for p0-4 .. p0-1 (only the first thread of a span looks them up itself)
             bool anchor_hit = false;
-            if (p0 < L && L >= 16) {
+            if (active) {
                 // bases [p0-16, p0+16): both loads are 16-byte aligned (read starts are)
                 uint4 a = make_uint4(0, 0, 0, 0);
                 if (p0 > 0) a = *reinterpret_cast<const uint4 *>(seq + p0 - 16);
@@ -72,12 +77,42 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
                 const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
                 uint32_t k = 0;
 #pragma unroll
-                for (int j = 1; j < 16; ++j) k = (k << 2) | code_fwd((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                for (int j = 1; j < 16; ++j) {
+                    k = (k << 2) | code_fwd((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+                    if (j >= 12) kleft[j - 12] = k;
+                }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     k = (k << 2) | code_fwd((w[4 + (j >> 2)] >> (8 * (j & 3))) & 0xffu);
                     kmers[j] = k;  // 16-mer ending at position p0 + j
                 }
+                // 12-mer prefilter (kmerset.h): one L2 lookup per position, all 16 in flight
+                if (prefilter) {
+                    uint32_t pw[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) pw[j] = prefilter[flx_sub12(kmers[j], 0) >> 5];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int i = p0 + j;
+                        if (i >= 11 && i < L) p12 |= ((pw[j] >> (kmers[j] & 31)) & 1u) << j;
+                    }
+                    if (t == 0 && p0 > 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (p0 - 4 + j >= 11) p12_left |= ((prefilter[flx_sub12(kleft[j], 0) >> 5] >> (kleft[j] & 31)) & 1u) << j;
+                    }
+                } else {
+                    p12 = 0xffffu;
+                    p12_left = 0xfu;
+                }
+            }
+            sh_p12[t] = (uint16_t)p12;
+            __syncthreads();
+            uint32_t cand = 0;  // bit j: the 16-mer ending at p0 + j may be present (all five of its 12-mers are)
+            if (active) {
+                if (t > 0) p12_left = prefilter ? (uint32_t)(sh_p12[t - 1] >> 12) : 0xfu;
+                const uint32_t m = p12_left | (p12 << 4);  // bit i: the 12-mer ending at p0 - 4 + i
+                cand = m & (m >> 1) & (m >> 2) & (m >> 3) & (m >> 4) & 0xffffu;
                 // Anchor first: the 16-mer ending at p0+15 spans exactly this thread's 16 bases, so if it is present they
                 // are all covered and the other 15 lookups of the block cannot change them.  Those 15 are needed only
                 // when this anchor misses (own bases) or the LEFT neighbour's anchor misses (its bases reach up to
@@ -85,33 +120,18 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
                 // bit is still evaluated, so the result is identical; on clean reads it is 1 lookup per 16 bases
                 // instead of 16 — the bitmap lookups are bound by the fabric's random-request rate.
                 const int ia = p0 + 15;
-                const bool a_valid = ia < L;
-                bool a_maybe = a_valid;
-                if (a_valid && prefilter) {  // L2-resident superset filter: a clear bit answers "absent" without the far lookup
-                    const uint32_t h = flx_prefilter_hash(kmers[15]);
-                    a_maybe = (prefilter[h >> 5] >> (h & 31)) & 1u;
-                }
-                const bool a_hit = a_maybe && ((bitmap[kmers[15] >> 5] >> (kmers[15] & 31)) & 1u);
+                const bool a_hit = ia < L && ((cand >> 15) & 1u) && ((bitmap[kmers[15] >> 5] >> (kmers[15] & 31)) & 1u);
                 anchor_hit = a_hit;
                 if (a_hit) hits = 1u << 15;
             }
             sh_anchor[t] = anchor_hit ? 1 : 0;
             __syncthreads();
-            if (p0 < L && L >= 16) {
+            if (active) {
                 const bool left_hit = (t > 0) ? (sh_anchor[t - 1] != 0) : false;  // first thread of a span: assume a miss
                 if (!anchor_hit || !left_hit) {
-                    uint32_t maybe = 0x7fffu;  // bit j: the 16-mer ending at p0 + j may be present
-                    if (prefilter) {
-                        uint32_t pw[15];
-#pragma unroll
-                        for (int j = 0; j < 15; ++j) pw[j] = prefilter[flx_prefilter_hash(kmers[j]) >> 5];  // L2 hits, all in flight
-                        maybe = 0;
-#pragma unroll
-                        for (int j = 0; j < 15; ++j) maybe |= ((pw[j] >> (flx_prefilter_hash(kmers[j]) & 31)) & 1u) << j;
-                    }
                     uint32_t words[15];
 #pragma unroll
-                    for (int j = 0; j < 15; ++j) words[j] = ((maybe >> j) & 1u) ? bitmap[kmers[j] >> 5] : 0u;  // independent, in flight
+                    for (int j = 0; j < 15; ++j) words[j] = ((cand >> j) & 1u) ? bitmap[kmers[j] >> 5] : 0u;  // independent, in flight
 #pragma unroll
                     for (int j = 0; j < 15; ++j) {
                         const int i = p0 + j;

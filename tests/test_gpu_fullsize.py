@@ -89,16 +89,19 @@ def test_c2_full_size_properties():
     ctx.close()
 
 
+@pytest.mark.parametrize("size", ["mid", "full"])
 @pytest.mark.parametrize("short_reads", [False, True], ids=["C3-assembly", "C4-short-reads"])
-def test_kmer_mode_mid_size_properties(short_reads):
-    """BASELINE.json configs[2]/[3] (k-mer mode, `--trim --split 500` for C4) at 2x10^5 reads / 2x10^9 bases against a
-    1 Mbp reference: the oracle builds the same 16-mer set and re-scores a sample of reads bit for bit (mean, window,
-    first/last, every child); the rest is checked structurally (children ordered, disjoint, inside the read, CSR sums)."""
+def test_kmer_mode_properties(short_reads, size):
+    """BASELINE.json configs[2]/[3] (k-mer mode, `--trim --split 500` for C4): "mid" = 2x10^5 reads / 2x10^9 bases against a
+    1 Mbp reference, "full" = the BASELINE size, 10^7 reads / 10^11 bases against the 5 Mbp reference (denser set, ~10^7
+    children).  The oracle builds the same 16-mer set (equal sizes) and re-scores a sample of reads bit for bit (mean,
+    window, first/last, every child); the rest is checked structurally (children ordered, disjoint, inside the read, CSR
+    sums), and for C4 the word-level and bit-level child passes must agree on every read."""
     import torch
     from filtlong_amd import _lib
     ctx = api.Context(0)
     dev = torch.device("cuda", 0)
-    n, ref_len = 200_000, 1_000_000
+    n, ref_len = (200_000, 1_000_000) if size == "mid" else (10_000_000, 5_000_000)
     ref = synth.bases_read(synth.STREAM_REF, 0, 0, ref_len)
     ks = api.Kmers(ctx)
     oset = _oracle.KmerSet()
@@ -108,8 +111,9 @@ def test_kmer_mode_mid_size_properties(short_reads):
                   % np.uint64(ref_len - 450)).astype(np.int64)
         comp = np.zeros(256, dtype=np.uint8)
         comp[list(b"ACGT")] = list(b"TGCA")
-        r1 = [ref[s:s + 100].tobytes() for s in starts]
-        r2 = [comp[ref[s + 350:s + 450]][::-1].tobytes() for s in starts]
+        idx = starts[:, None] + np.arange(100)[None, :]
+        r1 = [r.tobytes() for r in ref[idx]]
+        r2 = [r.tobytes() for r in comp[ref[idx + 350]][:, ::-1]]
         ks.add_read_fastqs([r1, r2])
         oset.add_short_reads(r1)
         oset.add_short_reads(r2)
