@@ -20,7 +20,8 @@ ABI_SYMBOLS = [
     "flx_abi_version", "flx_version", "flx_ctx_create", "flx_ctx_destroy", "flx_last_error", "flx_ctx_set_stream",
     "flx_ctx_synchronize", "flx_ctx_device_info", "flx_timing_enable", "flx_timing_reset", "flx_timing_get",
     "flx_plane_layout", "flx_length_order", "flx_score_batch", "flx_score_batch_dev", "flx_rank_and_cut",
-    "flx_rank_and_cut_dev", "flx_rank_and_cut_sharded_dev", "flx_rank_and_cut_comm_dev", "flx_comm_unique_id",
+    "flx_rank_and_cut_dev", "flx_rank_and_cut_sharded_dev", "flx_rank_and_cut_comm_dev", "flx_rank_and_cut_comm", "flx_comm_unique_id",
+    "flx_pipeline_create", "flx_pipeline_next_buffer", "flx_pipeline_submit", "flx_pipeline_finish", "flx_pipeline_destroy",
     "flx_comm_init", "flx_comm_destroy", "flx_comm_rank", "flx_comm_world", "flx_comm_sum_u64", "flx_kmerset_create", "flx_kmerset_destroy", "flx_kmerset_add_assembly",
     "flx_kmerset_add_short_reads", "flx_kmerset_finalize", "flx_kmerset_size", "flx_kmerset_contains",
     "flx_last_phred_kernel", "flx_synth_qual_dev", "flx_synth_qual_profile_dev", "flx_synth_seq_dev",
@@ -125,6 +126,13 @@ def load():
     L.flx_rank_and_cut_sharded_dev.argtypes = [vp, u64, vp, u64, u64, vp, vp, vp, dbl, dbl, dbl, i32, C.c_int64, i32, dbl,
                                                C.c_int64, vp, i32, i32, ALLREDUCE_FN, vp, C.POINTER(CutReport)]
     L.flx_rank_and_cut_comm_dev.argtypes = rank_args
+    L.flx_rank_and_cut_comm.argtypes = rank_args
+    L.flx_pipeline_create.argtypes = [vp, vp, C.POINTER(Params), u64, u64, C.POINTER(vp)]
+    L.flx_pipeline_next_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+    L.flx_pipeline_submit.argtypes = [vp, u64, vp, vp, u64]
+    L.flx_pipeline_finish.argtypes = [vp, C.POINTER(Scores), C.POINTER(u64)]
+    L.flx_pipeline_destroy.argtypes = [vp]
+    L.flx_pipeline_destroy.restype = None
     L.flx_comm_unique_id.argtypes = [vp, vp]
     L.flx_comm_init.argtypes = [vp, vp, i32, i32]
     L.flx_comm_destroy.argtypes = [vp]

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <deque>
 #include <string_view>
 #include <cstdint>
@@ -34,6 +35,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include "../../include/filtlong_hip.h"
@@ -74,6 +76,7 @@ struct Args {
     bool split_set = false; int split = 0;
     long long window_size = 250;
     bool verbose = false;
+    int gpus = 1;  // not a reference flag: --gpus N scores on N GPUs of this node (one process per GPU)
 };
 enum ParsingResult { GOOD, BAD, HELP, VERSION };
 
@@ -88,22 +91,33 @@ static double read_double(const std::string &name, const std::string &value) {  
     }
 }
 
-static long long parse_int_with_suffix(const std::string &value) {  // arguments.cpp:53-93
-    if (value.empty()) throw std::invalid_argument("Empty value");
-    std::string lower = value;
-    std::transform(lower.begin(), lower.end(), lower.begin(), ::tolower);
-    const size_t start = value[0] == '-' ? 1 : 0;
-    const size_t suffix_pos = lower.find_first_not_of("0123456789.", start);
-    if (suffix_pos == std::string::npos) return static_cast<long long>(std::stod(value));
-    const std::string numeric = value.substr(0, suffix_pos), suffix = lower.substr(suffix_pos);
-    if (numeric.empty() || (numeric.size() == 1 && numeric[0] == '-')) throw std::invalid_argument("No numeric value before suffix");
-    const double v = std::stod(numeric);
-    long long mult;
-    if (suffix == "k" || suffix == "kb") mult = 1000;
-    else if (suffix == "m" || suffix == "mb") mult = 1000000;
-    else if (suffix == "g" || suffix == "gb") mult = 1000000000;
-    else throw std::invalid_argument("Unknown suffix: " + suffix);
-    return static_cast<long long>(v * mult);
+// "<number>[k|kb|m|mb|g|gb]", case-insensitive, fractional numbers allowed ("1.5k" = 1500), result truncated towards zero.
+// Behaviour pinned by the reference's unit-suffix tests (test/test_unit_suffixes.py; arguments.cpp:53-93): anything but digits
+// and dots after the optional sign starts the suffix, so "1e3" is an unknown suffix there and here.
+static long long parse_int_with_suffix(const std::string &value) {
+    const char *text = value.c_str();
+    if (*text == '\0') throw std::invalid_argument("empty");
+    // the numeric part: an optional sign, then digits and dots only (no exponent once a suffix follows)
+    size_t i = (text[0] == '-') ? 1 : 0;
+    const size_t digits_from = i;
+    while (isdigit((unsigned char)text[i]) || text[i] == '.') ++i;
+    if (text[i] == '\0') {  // no suffix: the whole token is the number (std::stod semantics, like the reference)
+        size_t used = 0;
+        const double v = std::stod(value, &used);
+        return static_cast<long long>(v);
+    }
+    if (i == digits_from) throw std::invalid_argument("no number");
+    double scale = 0.0;
+    switch (tolower((unsigned char)text[i])) {
+        case 'k': scale = 1e3; break;
+        case 'm': scale = 1e6; break;
+        case 'g': scale = 1e9; break;
+        default: throw std::invalid_argument("suffix");
+    }
+    const char *rest = text + i + 1;
+    if (!(rest[0] == '\0' || (tolower((unsigned char)rest[0]) == 'b' && rest[1] == '\0'))) throw std::invalid_argument("suffix");
+    const double v = std::stod(value.substr(0, i));
+    return static_cast<long long>(v * scale);
 }
 
 static long long read_ll_suffix(const std::string &name, const std::string &value) {  // arguments.cpp:42-51
@@ -155,6 +169,7 @@ static void print_help(const char *prog) {
         "  other:\n"
         "    --window_size [int]                 size of sliding window used when measuring window quality (default: 250)\n"
         "    --verbose                           verbose output to stderr with info for each read\n"
+        "    --gpus [int]                        score on this many GPUs of the node (one process per GPU, RCCL; default: 1)\n"
         "    --version                           display the program version and quit\n"
         "    -h, --help                          display this help menu\n\n"
         "For more information, go to: https://github.com/rrwick/Filtlong\n";
@@ -206,6 +221,7 @@ static ParsingResult parse_args(int argc, char **argv, Args &a) {
             else if (flag == "window_q_weight") a.window_q_weight = read_double("float", need("window_q_weight"));
             else if (flag == "split") { a.split = read_int_suffix("split", need("split")); a.split_set = true; }
             else if (flag == "window_size") a.window_size = read_ll("int", need("window_size"));
+            else if (flag == "gpus") a.gpus = (int)read_ll("int", need("gpus"));
             else throw ParseError("Flag could not be matched: " + flag);
         }
         if (positional.size() > 1) throw ParseError("Passed in argument, but no positional arguments were ready to receive it: " + positional[1]);
@@ -246,6 +262,7 @@ static ParsingResult parse_args(int argc, char **argv, Args &a) {
     if (a.length_weight < 0.0 || a.mean_q_weight < 0.0 || a.window_q_weight < 0.0) { std::cerr << "Error: weight values cannot be negative\n"; return BAD; }
     if (a.split_set && a.split <= 0) { std::cerr << "Error: the value for --split must be a positive integer\n"; return BAD; }
     if (a.window_size <= 0) { std::cerr << "Error: the value for --window_size must be a positive integer\n"; return BAD; }
+    if (a.gpus < 1 || a.gpus > 64) { std::cerr << "Error: the value for --gpus must be between 1 and 64\n"; return BAD; }
     return GOOD;
 }
 
@@ -551,6 +568,8 @@ static int parse_only(const std::string &path, const char *mode) {
 
 // ------------------------------------------------------------------------------------------------ helpers
 #include <chrono>
+static int g_rank = 0, g_world = 1;          // multi-GPU: one process per GPU (RANK / WORLD_SIZE, or forked by --gpus N)
+static std::string g_part_prefix;             // where the ranks leave their parts of the output
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static bool g_timing = false;
 static double g_t0 = 0;
@@ -616,16 +635,75 @@ int main(int argc, char **argv) {
     if (pr == VERSION) { std::cout << "Filtlong v" << PROGRAM_VERSION << "\n"; return 0; }
     if (const char *po = getenv("FLX_CLI_PARSE_ONLY")) return parse_only(args.input_reads, po);
 
+    // ---- ranks: one process per GPU (north_star / SURVEY §8e) ---------------------------------------------------
+    // Either a launcher set RANK / WORLD_SIZE (/ LOCAL_RANK), or --gpus N forks N-1 copies of this process here, before
+    // any GPU state exists.  Reads are sharded by count in contiguous blocks of file order; every rank parses the (mapped)
+    // input's record index, scores its own block and takes part in the global stage through the library's RCCL
+    // communicator; rank 0 owns stderr and stdout.
+    std::vector<pid_t> children;
+    std::string id_file;
+    if (const char *ws = getenv("WORLD_SIZE")) {
+        g_world = std::max(1, atoi(ws));
+        g_rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
+    } else if (args.gpus > 1) {
+        g_world = args.gpus;
+        id_file = "/tmp/flx_comm_" + std::to_string((long long)getpid()) + ".id";
+        setenv("FLX_COMM_ID_FILE", id_file.c_str(), 1);
+        for (int r = 1; r < g_world; ++r) {
+            const pid_t pid = fork();
+            if (pid < 0) { std::cerr << "Error: fork failed\n"; return 1; }
+            if (pid == 0) { g_rank = r; children.clear(); break; }
+            children.push_back(pid);
+        }
+    }
+    if (g_rank < 0 || g_rank >= g_world) { std::cerr << "Error: RANK " << g_rank << " outside WORLD_SIZE " << g_world << "\n"; return 1; }
+    if (g_world > 1 && args.verbose) { std::cerr << "Error: --verbose is not available with more than one GPU\n"; return 1; }
+    if (g_rank > 0) {  // rank 0 speaks for the job
+        if (!freopen("/dev/null", "w", stderr)) return 1;
+        if (!freopen("/dev/null", "w", stdout)) return 1;
+    }
+    if (g_world > 1) {
+        const char *f = getenv("FLX_COMM_ID_FILE");
+        id_file = f ? f : std::string("/tmp/flx_comm_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + ".id";
+        g_part_prefix = id_file + ".out";
+    }
+
     std::cerr << "\n";
     g_timing = getenv("FLX_CLI_TIMING") != nullptr;
     g_t0 = now_s();
     flx_ctx *ctx = nullptr;
     {
         const char *dev = getenv("FLX_DEVICE");
-        if (flx_ctx_create(dev ? atoi(dev) : 0, &ctx) != FLX_OK) {
+        int ordinal = dev ? atoi(dev) : 0;
+        if (!dev && g_world > 1) ordinal = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : g_rank;
+        if (flx_ctx_create(ordinal, &ctx) != FLX_OK) {
             std::cerr << "Error: " << flx_last_error(nullptr) << "\n";
             return 1;
         }
+    }
+    if (g_world > 1) {
+        // the communicator's 128-byte id travels through a file: rank 0 writes it (temp name + rename), the others wait for it
+        unsigned char id[FLX_COMM_ID_BYTES];
+        if (g_rank == 0) {
+            if (flx_comm_unique_id(ctx, id) != FLX_OK) return fail_flx(ctx, "communicator");
+            const std::string tmp = id_file + ".tmp";
+            FILE *f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { std::cerr << "Error: cannot write " << tmp << "\n"; return 1; }
+            fclose(f);
+            if (rename(tmp.c_str(), id_file.c_str()) != 0) { std::cerr << "Error: cannot create " << id_file << "\n"; return 1; }
+        } else {
+            bool ok = false;
+            for (int tries = 0; tries < 6000 && !ok; ++tries) {  // up to 60 s
+                FILE *f = fopen(id_file.c_str(), "rb");
+                if (f) { ok = fread(id, 1, sizeof id, f) == sizeof id; fclose(f); }
+                if (!ok) usleep(10000);
+            }
+            if (!ok) return 1;
+        }
+        if (flx_comm_init(ctx, id, g_rank, g_world) != FLX_OK) return fail_flx(ctx, "communicator");
+        uint64_t ready = 1;  // everybody has read the id
+        if (flx_comm_sum_u64(ctx, &ready, 1) != FLX_OK) return fail_flx(ctx, "communicator");
+        if (g_rank == 0) unlink(id_file.c_str());
     }
 
     stage("context");
@@ -710,42 +788,20 @@ int main(int argc, char **argv) {
         if (parsed.status == -2) { std::cerr << "Error: incorrect FASTQ format for read " << parsed.bad.name << "\n"; return 1; }
     }
     if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)recs.size()) << " reads (" << int_to_string(total_bases) << " bp)";
-    std::cerr << "\n";
+    if (!args.verbose) std::cerr << "\n";  // verbose: after the per-read blocks, as in main.cpp:110-129
     const bool fasta_output = any_fasta, fastq_output = any_fastq;
 
     stage("record checks");
     // ---- pack and score (replaces one Read::Read per record, src/main.cpp:108) ---------------------------
-    const uint64_t n = recs.size();
+    // Streaming: the records of this rank are packed chunk by chunk into the pipeline's pinned staging buffers (two slots:
+    // the GPU copies and scores chunk k while the host threads pack chunk k+1); only per-read scalars survive a chunk.
+    // The input stays mapped, so the record views — and the output pass below — need no second parse.
+    const uint64_t n_all = recs.size();
+    const int world = g_world, rank = g_rank;
+    const uint64_t lo_rec = n_all / (uint64_t)world * (uint64_t)rank + std::min<uint64_t>((uint64_t)rank, n_all % (uint64_t)world);
+    const uint64_t n = n_all / (uint64_t)world + ((uint64_t)rank < n_all % (uint64_t)world ? 1 : 0);  // this rank's contiguous block of file order
     std::vector<int32_t> lengths(n);
-    for (uint64_t i = 0; i < n; ++i) lengths[i] = (int32_t)recs[i].seq.size();
-    std::vector<uint64_t> offsets(n ? n : 1);
-    uint64_t plane_bytes = 0;
-    flx_plane_layout(lengths.data(), n, offsets.data(), &plane_bytes);
-    // anonymous mapping: zero pages (the alignment padding stays 0), first touched by the packing threads themselves
-    // (2 MiB-aligned and advised as huge pages: 500x fewer faults while packing and pages to return afterwards)
-    const size_t kHuge = 2u << 20;
-    const size_t plane_len = ((std::max<uint64_t>(plane_bytes, 16) + kHuge - 1) & ~(uint64_t)(kHuge - 1)) + kHuge;
-    void *plane_raw = mmap(nullptr, plane_len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-    if (plane_raw == MAP_FAILED) { std::cerr << "Error: out of memory packing " << plane_bytes << " bytes\n"; return 1; }
-    void *plane_map = (void *)(((uintptr_t)plane_raw + kHuge - 1) & ~(uintptr_t)(kHuge - 1));
-    madvise(plane_map, plane_len - kHuge, MADV_HUGEPAGE);
-    uint8_t *plane = (uint8_t *)plane_map;
-    {
-        const size_t parts = n ? std::min<uint64_t>(n, (uint64_t)host_threads() * 8) : 0;
-        parallel_for(parts, [&](size_t k) {  // byte-balanced slices of the read range
-            const uint64_t lo_b = plane_bytes / parts * k, hi_b = k + 1 == parts ? plane_bytes : plane_bytes / parts * (k + 1);
-            const uint64_t lo = std::lower_bound(offsets.begin(), offsets.begin() + n, lo_b) - offsets.begin();
-            const uint64_t hi = k + 1 == parts ? n : std::lower_bound(offsets.begin(), offsets.begin() + n, hi_b) - offsets.begin();
-            for (uint64_t i = lo; i < hi; ++i) {
-                const View &src = kmers_empty ? recs[i].qual : recs[i].seq;  // Phred mode reads qual, k-mer mode reads seq
-                if (!src.empty()) memcpy(plane + offsets[i], src.p, src.size());
-            }
-        });
-    }
-    std::vector<uint32_t> order(n ? n : 1);
-    flx_length_order(lengths.data(), n, order.data());
-
-    stage("pack + order");
+    for (uint64_t i = 0; i < n; ++i) lengths[i] = (int32_t)recs[lo_rec + i].seq.size();
     flx_params prm;
     memset(&prm, 0, sizeof prm);
     prm.window_size = (int32_t)args.window_size;
@@ -755,31 +811,65 @@ int main(int argc, char **argv) {
     prm.min_window_q_set = args.min_window_q_set; prm.min_window_q = args.min_window_q;
     prm.trim = args.trim; prm.split_set = args.split_set; prm.split = args.split;
 
-    std::vector<double> mean_q(n), window_q(n), c_mean, c_window;
-    std::vector<uint8_t> passed(n), c_passed;
-    std::vector<int32_t> first(n), last(n), c_ranges;
-    std::vector<uint64_t> child_off(n + 1, 0);
-    uint64_t cap = std::max<uint64_t>(16, 2 * n);
-    uint64_t n_children = 0;
-    for (;;) {
-        c_ranges.assign(2 * cap, 0); c_mean.assign(cap, 0); c_window.assign(cap, 0); c_passed.assign(cap, 0);
-        flx_scores sc;
-        memset(&sc, 0, sizeof sc);
-        sc.mean_q = mean_q.data(); sc.window_q = window_q.data(); sc.passed = passed.data();
-        sc.first = first.data(); sc.last = last.data(); sc.child_offsets = child_off.data();
-        sc.child_ranges = c_ranges.data(); sc.child_mean_q = c_mean.data(); sc.child_window_q = c_window.data();
-        sc.child_passed = c_passed.data(); sc.child_capacity = cap;
-        const int rc = flx_score_batch(ctx, kmers_empty ? nullptr : kmers, plane, plane_bytes, offsets.data(), lengths.data(),
-                                       order.data(), n, &prm, &sc);
-        if (rc == FLX_ERR_CAPACITY && sc.n_children > cap) { cap = sc.n_children; continue; }
-        if (rc != FLX_OK) return fail_flx(ctx, "scoring");
-        n_children = sc.n_children;
-        break;
+    uint64_t chunk_bytes = 1ull << 30, chunk_reads = 4u << 20;
+    if (const char *e = getenv("FLX_CLI_CHUNK_MB")) chunk_bytes = std::max<uint64_t>(1, (uint64_t)atoll(e)) << 20;
+    if (const char *e = getenv("FLX_CLI_CHUNK_BYTES")) chunk_bytes = std::max<uint64_t>(4096, (uint64_t)atoll(e));  // tests force many chunks
+    {
+        int32_t longest = 0;
+        for (uint64_t i = 0; i < n; ++i) longest = std::max(longest, lengths[i]);
+        chunk_bytes = std::max<uint64_t>(chunk_bytes, (((uint64_t)longest + 15) & ~15ull) + 256);  // a read is never split over chunks
     }
-    (void)n_children;
-    munmap(plane_raw, plane_len);
+    flx_pipeline *pipe = nullptr;
+    if (flx_pipeline_create(ctx, kmers_empty ? nullptr : kmers, &prm, chunk_bytes, chunk_reads, &pipe) != FLX_OK) return fail_flx(ctx, "pipeline");
+    uint64_t n_chunks = 0;
+    {
+        std::vector<uint64_t> offsets;
+        for (uint64_t at = 0; at < n;) {
+            // the next chunk: as many records as fit the slot (flx_plane_layout's rule: 16-byte slots, 128-byte starts for long reads)
+            uint64_t end = at, bytes = 0;
+            while (end < n && end - at < chunk_reads) {
+                uint64_t off = bytes;
+                if (lengths[end] >= 1024) off = (off + 127u) & ~(uint64_t)127u;
+                const uint64_t nb = off + (((uint64_t)lengths[end] + 15u) & ~(uint64_t)15u);
+                if (nb > chunk_bytes && end > at) break;
+                bytes = nb;
+                ++end;
+            }
+            const uint64_t m = end - at;
+            offsets.assign(m, 0);
+            uint64_t plane_bytes = 0;
+            flx_plane_layout(lengths.data() + at, m, offsets.data(), &plane_bytes);
+            uint8_t *plane = nullptr;
+            if (flx_pipeline_next_buffer(pipe, &plane, nullptr, nullptr) != FLX_OK) return fail_flx(ctx, "scoring");
+            const size_t parts = std::min<uint64_t>(m, (uint64_t)host_threads() * 8);
+            parallel_for(parts, [&](size_t k) {  // byte-balanced slices of the chunk's reads
+                const uint64_t lo_b = plane_bytes / parts * k, hi_b = k + 1 == parts ? plane_bytes : plane_bytes / parts * (k + 1);
+                const uint64_t lo = std::lower_bound(offsets.begin(), offsets.end(), lo_b) - offsets.begin();
+                const uint64_t hi = k + 1 == parts ? m : std::lower_bound(offsets.begin(), offsets.end(), hi_b) - offsets.begin();
+                for (uint64_t i = lo; i < hi; ++i) {
+                    const Record &r = recs[lo_rec + at + i];
+                    const View &src = kmers_empty ? r.qual : r.seq;  // Phred mode reads qual, k-mer mode reads seq
+                    if (!src.empty()) memcpy(plane + offsets[i], src.p, src.size());
+                    const uint64_t tail = offsets[i] + src.size();  // the staging buffer is reused: clear the padding behind the read
+                    const uint64_t next = i + 1 < m ? offsets[i + 1] : plane_bytes;
+                    if (next > tail) memset(plane + tail, 0, next - tail);
+                }
+            });
+            if (flx_pipeline_submit(pipe, plane_bytes, offsets.data(), lengths.data() + at, m) != FLX_OK) return fail_flx(ctx, "scoring");
+            at = end;
+            ++n_chunks;
+        }
+    }
+    flx_scores res;
+    uint64_t n_scored = 0;
+    if (flx_pipeline_finish(pipe, &res, &n_scored) != FLX_OK || n_scored != n) return fail_flx(ctx, "scoring");
+    const double *mean_q = res.mean_q, *window_q = res.window_q, *c_mean = res.child_mean_q, *c_window = res.child_window_q;
+    const uint8_t *passed = res.passed, *c_passed = res.child_passed;
+    const int32_t *c_ranges = res.child_ranges;
+    const uint64_t *child_off = res.child_offsets;
+    if (g_timing) fprintf(stderr, "[timing] %llu chunk(s) of <= %llu MiB\n", (unsigned long long)n_chunks, (unsigned long long)(chunk_bytes >> 20));
 
-    stage("score (H2D + kernels + D2H)");
+    stage("pack + H2D + score (streamed)");
     // ---- reads2: children replace their parents in place (src/main.cpp:138-147) -----------------------------
     struct Out { uint64_t rec; int start, end; bool child; std::string name; };
     std::vector<Out> reads2;
@@ -788,77 +878,125 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> r2_pass;
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t a = child_off[i], b = child_off[i + 1];
+        const Record &r = recs[lo_rec + i];
         if (a == b) {
-            reads2.push_back({i, 0, lengths[i], false, recs[i].name.str()});
+            reads2.push_back({lo_rec + i, 0, lengths[i], false, r.name.str()});
             r2_mean.push_back(mean_q[i]); r2_window.push_back(window_q[i]); r2_len.push_back(lengths[i]); r2_pass.push_back(passed[i]);
         } else {
             for (uint64_t k = a; k < b; ++k) {
-                const int s = c_ranges[2 * k], e = c_ranges[2 * k + 1];
-                reads2.push_back({i, s, e, true, recs[i].name.str() + "_" + std::to_string(s + 1) + "-" + std::to_string(e)});  // read.cpp:135-136
-                r2_mean.push_back(c_mean[k]); r2_window.push_back(c_window[k]); r2_len.push_back(e - s); r2_pass.push_back(c_passed[k]);
+                const int s0 = c_ranges[2 * k], e0 = c_ranges[2 * k + 1];
+                reads2.push_back({lo_rec + i, s0, e0, true, r.name.str() + "_" + std::to_string(s0 + 1) + "-" + std::to_string(e0)});  // read.cpp:135-136
+                r2_mean.push_back(c_mean[k]); r2_window.push_back(c_window[k]); r2_len.push_back(e0 - s0); r2_pass.push_back(c_passed[k]);
             }
         }
     }
     size_t longest_name = 0;
     for (auto &o : reads2) longest_name = std::max(longest_name, o.name.size());
 
-    if (args.verbose) {  // Read::print_verbose_read_info, src/read.cpp:169-194 (bad ranges are the complement of the children)
+    if (args.verbose) {  // Read::print_verbose_read_info, src/read.cpp:169-194, in file order like the pass-1 loop (main.cpp:110-111)
         for (uint64_t i = 0; i < n; ++i) {
-            std::cerr << "\n" << recs[i].name << "\n";
+            const Record &r = recs[lo_rec + i];
+            std::cerr << "\n" << r.name << "\n";
             std::cerr << "            length = " << pad(std::to_string(lengths[i]), 11) << "mean quality = " << double_to_string(mean_q[i])
                       << "      window quality = " << double_to_string(window_q[i]) << "\n";
             const uint64_t a = child_off[i], b = child_off[i + 1];
+            // m_bad_ranges (read.cpp:86-117): disjoint, non-adjacent and sorted, so with children they are exactly the gaps the
+            // children leave in [0, L); without children the only possibility is the whole read (no covered base at all and
+            // at least --split long)
+            std::vector<std::pair<int, int>> bad;
+            if (a != b) {
+                int from = 0;
+                for (uint64_t k = a; k < b; ++k) {
+                    if (c_ranges[2 * k] > from) bad.push_back({from, c_ranges[2 * k]});
+                    from = c_ranges[2 * k + 1];
+                }
+                if (from < lengths[i]) bad.push_back({from, lengths[i]});
+            } else if (!kmers_empty && args.split_set && res.first[i] == -1 && lengths[i] > 0 && lengths[i] >= args.split) {
+                bad.push_back({0, lengths[i]});
+            }
+            if (!bad.empty()) {
+                std::cerr << "        bad ranges = ";
+                for (size_t k = 0; k < bad.size(); ++k) std::cerr << bad[k].first << "-" << bad[k].second << (k + 1 < bad.size() ? ", " : "");
+                std::cerr << "\n";
+            }
             if (a != b) {
                 std::cerr << "      child ranges = ";
                 for (uint64_t k = a; k < b; ++k) std::cerr << c_ranges[2 * k] << "-" << c_ranges[2 * k + 1] << (k + 1 < b ? ", " : "");
                 std::cerr << "\n";
                 for (uint64_t k = a; k < b; ++k) {
-                    std::cerr << "\n" << recs[i].name << "_" << c_ranges[2 * k] + 1 << "-" << c_ranges[2 * k + 1] << "\n";
+                    std::cerr << "\n" << r.name << "_" << c_ranges[2 * k] + 1 << "-" << c_ranges[2 * k + 1] << "\n";
                     std::cerr << "            length = " << pad(std::to_string(c_ranges[2 * k + 1] - c_ranges[2 * k]), 11) << "mean quality = "
                               << double_to_string(c_mean[k]) << "      window quality = " << double_to_string(c_window[k]) << "\n";
                 }
             }
         }
+        std::cerr << "\n";  // the line main.cpp:129 prints after the loop
     }
 
-    if (args.trim || args.split_set) {  // src/main.cpp:155-166
-        long long after = 0;
-        for (auto v : r2_len) after += v;
+    // totals over all ranks (one rank: the local values)
+    uint64_t n2_local = reads2.size();
+    std::vector<uint64_t> n2_of((size_t)world, 0);
+    long long after_local = 0;
+    for (auto v : r2_len) after_local += v;
+    uint64_t n2_total = n2_local;
+    long long after_total = after_local;
+    if (world > 1) {
+        std::vector<uint64_t> sums((size_t)world + 1, 0);
+        sums[rank] = n2_local;
+        sums[world] = (uint64_t)after_local;
+        if (flx_comm_sum_u64(ctx, sums.data(), sums.size()) != FLX_OK) return fail_flx(ctx, "exchange");
+        n2_total = 0;
+        for (int r = 0; r < world; ++r) { n2_of[r] = sums[r]; n2_total += sums[r]; }
+        after_total = (long long)sums[world];
+    }
+    if ((args.trim || args.split_set) && rank == 0) {  // src/main.cpp:155-166
         if (args.trim && args.split_set) std::cerr << "  after trimming and splitting: ";
         else if (args.trim) std::cerr << "  after trimming: ";
         else std::cerr << "  after splitting: ";
-        std::cerr << int_to_string((long long)reads2.size()) << " reads (" << int_to_string(after) << " bp)\n";
+        std::cerr << int_to_string((long long)n2_total) << " reads (" << int_to_string(after_total) << " bp)\n";
     }
-    std::cerr << "\n";
+    if (rank == 0) std::cerr << "\n";
 
     // ---- global stage (src/main.cpp:169-261) ---------------------------------------------------------------
-    const uint64_t n2 = reads2.size();
-    std::vector<double> final_score(n2);
+    const uint64_t n2 = n2_local;
     flx_cut_report rep;
     memset(&rep, 0, sizeof rep);
     const bool cutting = args.target_bases_set || args.keep_percent_set;
-    if (n2 > 0 || cutting) {
-        if (flx_rank_and_cut(ctx, n2, r2_mean.data(), r2_window.data(), r2_len.data(), r2_pass.data(), args.length_weight,
-                             args.mean_q_weight, args.window_q_weight, args.target_bases_set, args.target_bases, args.keep_percent_set,
-                             args.keep_percent, total_bases, args.verbose ? final_score.data() : nullptr, &rep) != FLX_OK)
-            return fail_flx(ctx, "rank and cut");
+    if (n2_total > 0 || cutting) {
+        const int rc = world > 1
+            ? flx_rank_and_cut_comm(ctx, n2, r2_mean.data(), r2_window.data(), r2_len.data(), r2_pass.data(), args.length_weight,
+                                    args.mean_q_weight, args.window_q_weight, args.target_bases_set, args.target_bases,
+                                    args.keep_percent_set, args.keep_percent, total_bases, nullptr, &rep)
+            : flx_rank_and_cut(ctx, n2, r2_mean.data(), r2_window.data(), r2_len.data(), r2_pass.data(), args.length_weight,
+                               args.mean_q_weight, args.window_q_weight, args.target_bases_set, args.target_bases,
+                               args.keep_percent_set, args.keep_percent, total_bases, nullptr, &rep);
+        if (rc != FLX_OK) return fail_flx(ctx, "rank and cut");
     }
-    if (args.verbose) {  // src/main.cpp:199-214: the table shows the NORMALISED qualities; recompute them like main.cpp:203-208
+    if (args.verbose) {  // src/main.cpp:199-214: the table shows the NORMALISED qualities and the final score, host libm like the reference
         std::cerr << "\n\n" << "Read name" << "\t" << "Length score" << "\t" << "Mean quality score" << "\t" << "Window quality score"
                   << "\t" << "Final score" << "\n";
         const double zspan = rep.max_z - rep.min_z;
+        double (*volatile powfn)(double, double) = pow;
         for (uint64_t i = 0; i < n2; ++i) {
-            double ratio = r2_window[i] / r2_mean[i];
+            double ratio = r2_window[i] / r2_mean[i];  // main.cpp:203-208
             if (ratio > 1.0) ratio = 1.0;
             const double z = (r2_mean[i] - rep.mean_quality) / rep.stdev_quality;
             const double mq = 100.0 * (z - rep.min_z) / zspan;
+            const double wq = mq * ratio;
             const double lscore = 100.0 * (1.0 + (-5000.0 / (r2_len[i] + 5000.0)));
+            // Read::set_final_score, read.cpp:249-267
+            const double product = powfn(lscore, args.length_weight) * powfn(mq, args.mean_q_weight);
+            const double gm = powfn(product, 1.0 / (args.length_weight + args.mean_q_weight));
+            double scale = 1.0;
+            if (mq > 0.0) scale = std::min(wq / mq, 1.0);
+            const double wfrac = args.window_q_weight / (args.length_weight + args.mean_q_weight + args.window_q_weight);
+            const double fs = gm * ((1.0 - wfrac) + (scale * wfrac));
             std::cerr << pad(reads2[i].name, longest_name) << "\t" << double_to_string(lscore) << "\t" << double_to_string(mq) << "\t"
-                      << double_to_string(mq * ratio) << "\t" << double_to_string(final_score[i]) << "\n";
+                      << double_to_string(wq) << "\t" << double_to_string(fs) << "\n";
         }
         std::cerr << "\n";
     }
-    if (cutting) {
+    if (cutting && rank == 0) {
         std::cerr << "Filtering long reads\n";
         std::cerr << "  target: " << int_to_string(rep.target_bases) << " bp\n";
         if (rep.outcome == FLX_CUT_NOT_ENOUGH) std::cerr << "  not enough reads to reach target\n";
@@ -869,7 +1007,16 @@ int main(int argc, char **argv) {
 
     stage("rank and cut");
     // ---- output in input order (src/main.cpp:263-313) -----------------------------------------------------
-    std::cerr << "Outputting passed long reads\n";
+    // One rank: straight to stdout.  Several ranks: every rank writes the passed records of its own block to a part file,
+    // rank 0 streams the parts to stdout in rank (= file) order.
+    if (rank == 0) std::cerr << "Outputting passed long reads\n";
+    FILE *sink = stdout;
+    std::string part_path;
+    if (world > 1) {
+        part_path = g_part_prefix + ".part" + std::to_string(rank);
+        sink = fopen(part_path.c_str(), "wb");
+        if (!sink) { std::cerr << "Error: cannot write " << part_path << "\n"; return 1; }
+    }
     std::string out;
     out.reserve(1 << 24);
     for (uint64_t i = 0; i < n2; ++i) {
@@ -888,14 +1035,39 @@ int main(int argc, char **argv) {
             out.append(r.qual.p + o.start, (size_t)(o.end - o.start));
             out += '\n';
         }
-        if (out.size() > (1u << 24)) { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
+        if (out.size() > (1u << 24)) { fwrite(out.data(), 1, out.size(), sink); out.clear(); }
     }
-    fwrite(out.data(), 1, out.size(), stdout);
-    fflush(stdout);
+    fwrite(out.data(), 1, out.size(), sink);
+    fflush(sink);
+    if (world > 1) {
+        fclose(sink);
+        uint64_t done = 1;  // every part is complete before rank 0 reads it
+        if (flx_comm_sum_u64(ctx, &done, 1) != FLX_OK) return fail_flx(ctx, "exchange");
+        if (rank == 0) {
+            std::vector<char> buf(1 << 22);
+            for (int r = 0; r < world; ++r) {
+                const std::string pth = g_part_prefix + ".part" + std::to_string(r);
+                FILE *f = fopen(pth.c_str(), "rb");
+                if (!f) { std::cerr << "Error: cannot read " << pth << "\n"; return 1; }
+                size_t got;
+                while ((got = fread(buf.data(), 1, buf.size(), f)) > 0) fwrite(buf.data(), 1, got, stdout);
+                fclose(f);
+                unlink(pth.c_str());
+            }
+            fflush(stdout);
+        }
+    }
     stage("output");
 
+    flx_pipeline_destroy(pipe);
     if (kmers) flx_kmerset_destroy(kmers);
     flx_ctx_destroy(ctx);
-    std::cerr << "\n";
+    int status = 0;
+    for (pid_t c : children) {
+        int st = 0;
+        if (waitpid(c, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) status = 1;
+    }
+    if (status) { std::cerr << "Error: a rank failed\n"; return 1; }
+    if (rank == 0) std::cerr << "\n";
     return 0;
 }

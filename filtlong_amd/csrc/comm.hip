@@ -253,3 +253,33 @@ extern "C" int flx_rank_and_cut_comm_dev(flx_ctx *ctx, uint64_t n_local, const v
     FLX_HIP(ctx, hipStreamSynchronize(st));
     return FLX_OK;
 }
+
+// host arrays (the CLI's reads2 scalars): staged like flx_rank_and_cut
+extern "C" int flx_rank_and_cut_comm(flx_ctx *ctx, uint64_t n_local, const double *mean_q, const double *window_q,
+                                     const int32_t *length, uint8_t *passed, double lw, double mw, double ww,
+                                     int target_bases_set, int64_t target_bases, int keep_percent_set, double keep_percent,
+                                     int64_t total_bases, double *final_score, flx_cut_report *rep) {
+    if (!ctx) return FLX_ERR_INVALID;
+    if (n_local && (!mean_q || !window_q || !length || !passed)) return flx_fail(ctx, FLX_ERR_INVALID, "NULL input array");
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    flx_dbuf d_mean, d_win, d_len, d_pass, d_fs;
+    FLX_CHECK(flx_dalloc(ctx, d_mean, n_local * 8));
+    FLX_CHECK(flx_dalloc(ctx, d_win, n_local * 8));
+    FLX_CHECK(flx_dalloc(ctx, d_len, n_local * 4));
+    FLX_CHECK(flx_dalloc(ctx, d_pass, n_local));
+    if (final_score) FLX_CHECK(flx_dalloc(ctx, d_fs, n_local * 8));
+    if (n_local) {
+        FLX_HIP(ctx, hipMemcpyAsync(d_mean.p, mean_q, n_local * 8, hipMemcpyHostToDevice, ctx->stream));
+        FLX_HIP(ctx, hipMemcpyAsync(d_win.p, window_q, n_local * 8, hipMemcpyHostToDevice, ctx->stream));
+        FLX_HIP(ctx, hipMemcpyAsync(d_len.p, length, n_local * 4, hipMemcpyHostToDevice, ctx->stream));
+        FLX_HIP(ctx, hipMemcpyAsync(d_pass.p, passed, n_local, hipMemcpyHostToDevice, ctx->stream));
+    }
+    FLX_CHECK(flx_rank_and_cut_comm_dev(ctx, n_local, d_mean.p, d_win.p, d_len.p, d_pass.p, lw, mw, ww, target_bases_set, target_bases,
+                                        keep_percent_set, keep_percent, total_bases, final_score ? d_fs.p : nullptr, rep));
+    if (n_local) {
+        FLX_HIP(ctx, hipMemcpyAsync(passed, d_pass.p, n_local, hipMemcpyDeviceToHost, ctx->stream));
+        if (final_score) FLX_HIP(ctx, hipMemcpyAsync(final_score, d_fs.p, n_local * 8, hipMemcpyDeviceToHost, ctx->stream));
+        FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FLX_OK;
+}

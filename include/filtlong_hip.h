@@ -201,6 +201,28 @@ int flx_rank_and_cut_sharded_dev(flx_ctx *ctx, uint64_t n_total, const void *d_m
                                  int64_t total_bases, void *d_final_score, int rank, int world,
                                  flx_allreduce_u64_fn reduce, void *user, flx_cut_report *report);
 
+/* ------------------------------------------------------------------------------------------
+ * seam 2, streaming — replaces the pass-1 loop of src/main.cpp:70-127 for inputs larger than memory
+ *
+ * The caller parses its input chunk by chunk.  For every chunk:
+ *     flx_pipeline_next_buffer -> a PINNED staging buffer of `capacity_bytes` (blocks while both slots are in flight)
+ *     pack the chunk's reads into it (flx_plane_layout gives offsets and the byte count; Phred mode: quality strings,
+ *     k-mer mode: sequences — as for flx_score_batch)
+ *     flx_pipeline_submit      -> starts the H2D copy and returns; a worker thread scores the chunk when it has landed
+ * so chunk k is copied and scored on the GPU while the host packs chunk k+1 (two slots).  flx_pipeline_finish waits for
+ * everything and returns the per-read results of ALL submitted reads in submission order as host arrays owned by the
+ * pipeline (children in one global CSR); only these scalars survive between the chunks, like the reference, which keeps
+ * one Read object per record and drops the record's text.  The context must not be used for anything else between
+ * create and finish (its stream belongs to the worker).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct flx_pipeline flx_pipeline;
+int flx_pipeline_create(flx_ctx *ctx, const flx_kmerset *set /* NULL or empty: Phred mode */, const flx_params *params,
+                        uint64_t chunk_plane_bytes, uint64_t chunk_reads, flx_pipeline **out);
+int flx_pipeline_next_buffer(flx_pipeline *p, uint8_t **plane, uint64_t *capacity_bytes, uint64_t *capacity_reads);
+int flx_pipeline_submit(flx_pipeline *p, uint64_t plane_bytes, const uint64_t *offsets, const int32_t *lengths, uint64_t n_reads);
+int flx_pipeline_finish(flx_pipeline *p, flx_scores *all, uint64_t *n_reads);
+void flx_pipeline_destroy(flx_pipeline *p);
+
 /* Multi-GPU without a host framework: one process per GPU, each with one context; the library owns the RCCL communicator
  * (loaded with dlopen on first use) and does the exchange of the global stage itself, on device buffers on the context's
  * stream (no host synchronisation inside the 8 selection passes):
@@ -219,6 +241,11 @@ int flx_comm_destroy(flx_ctx *ctx);
 int flx_comm_rank(const flx_ctx *ctx);
 int flx_comm_world(const flx_ctx *ctx);
 int flx_comm_sum_u64(flx_ctx *ctx, uint64_t *host_buf, uint64_t count); /* element-wise sum over all ranks, in place */
+/* host-array variant (the arrays are staged through the device, like flx_rank_and_cut) */
+int flx_rank_and_cut_comm(flx_ctx *ctx, uint64_t n_local, const double *mean_q, const double *window_q, const int32_t *length,
+                          uint8_t *passed, double length_weight, double mean_q_weight, double window_q_weight,
+                          int target_bases_set, int64_t target_bases, int keep_percent_set, double keep_percent,
+                          int64_t total_bases, double *final_score, flx_cut_report *report);
 int flx_rank_and_cut_comm_dev(flx_ctx *ctx, uint64_t n_local, const void *d_mean_q, const void *d_window_q,
                               const void *d_length, void *d_passed, double length_weight, double mean_q_weight,
                               double window_q_weight, int target_bases_set, int64_t target_bases, int keep_percent_set,

@@ -17,16 +17,29 @@ BIN = os.path.join(ROOT, "filtlong_amd", "bin", "filtlong")
 FIX = _cases.FIXTURES
 
 
-def run(args, cwd):
-    p = subprocess.run([BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=cwd,
-                       env=dict(os.environ, LANG="C", LC_ALL="C"))
+def run(args, cwd, extra_env=None):
+    env = dict(os.environ, LANG="C", LC_ALL="C")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    p = subprocess.run([BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=cwd, env=env)
     err = p.stderr.decode(errors="replace")
     keep = [l.strip() for l in err.replace("\r", "\n").split("\n")
             if any(t in l for t in ("target:", "keeping", "not enough", "already fall", "after ", "Error", "16-mers"))]
     return p.returncode, p.stdout, keep, err
 
 
-def test_cli_matches_reference_binary_byte_for_byte():
+MODES = {
+    "default": {},
+    # streaming ingest forced into many small chunks (two pinned slots, worker thread): same bytes out
+    "chunked": {"FLX_CLI_CHUNK_BYTES": "20000"},
+    # the one-process-per-GPU path with a single rank: RCCL communicator, flx_rank_and_cut_comm, part files
+    "rank-env": {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "FLX_COMM_ID_FILE": "/tmp/flx_test_comm.id"},
+}
+
+
+@pytest.mark.parametrize("mode", sorted(MODES))
+def test_cli_matches_reference_binary_byte_for_byte(mode):
     gold = _e2e_checks.load_e2e()
     inp = _e2e_checks.Inputs()
     with tempfile.TemporaryDirectory() as td:
@@ -65,7 +78,7 @@ def test_cli_matches_reference_binary_byte_for_byte():
                 inpath = pin
             else:
                 inpath = kin
-            rc, out, keep, err = run(args + [inpath], td)
+            rc, out, keep, err = run(args + [inpath], td, MODES[mode])
             assert rc == g["rc"], (key, err)
             assert len(out) == g["stdout_len"] and hashlib.sha256(out).hexdigest() == g["stdout_sha256"], key
             # reference stderr lines hold the generator's temp file names in the hashing section; compare the rest
@@ -96,6 +109,29 @@ def test_cli_verbose_scores(tmp_path):
     assert rc == 0
     rows = {l.split("\t")[0].strip(): l.split("\t") for l in err.split("\n") if l.startswith("test_sort_") and "\t" in l}
     assert [rows["test_sort_%d" % i][4].strip() for i in (1, 2, 3)] == ["0.00", "70.70", "61.54"]
+
+
+def test_cli_verbose_matches_reference_stderr(tmp_path):
+    """--verbose stderr, character for character after the hashing section (tests/golden/verbose.json, written by
+    make_verbose_golden.py from the reference binary): per-read blocks with `bad ranges` / `child ranges`
+    (src/read.cpp:169-194), the blank line after them (main.cpp:129), the score table with host-libm final scores."""
+    gold = json.load(open(os.path.join(_cases.GOLDEN, "verbose.json")))
+    for key, g in sorted(gold.items()):
+        args = [os.path.join(FIX, "test_reference.fasta") if a == "REF" else a for a in g["args"]]
+        rc, out, keep, err = run(args + [os.path.join(FIX, g["input"])], str(tmp_path))
+        assert rc == g["rc"], (key, err)
+        cut = err.find("16-mers\n\n")
+        got = err[cut + len("16-mers\n\n"):] if cut >= 0 else err
+        assert got == g["stderr"], (key, got, g["stderr"])
+
+
+def test_cli_gpus_flag_single(tmp_path):
+    """--gpus 1 is the plain run; --gpus 0 / non-numeric are argument errors."""
+    fq = os.path.join(FIX, "test_sort.fastq")
+    a = run(["--target_bases", "10000", fq], str(tmp_path))
+    b = run(["--target_bases", "10000", "--gpus", "1", fq], str(tmp_path))
+    assert a[0] == b[0] == 0 and a[1] == b[1]
+    assert run(["--target_bases", "10000", "--gpus", "0", fq], str(tmp_path))[0] == 1
 
 
 def test_cli_unit_suffixes(tmp_path):
