@@ -573,11 +573,22 @@ static std::string g_part_prefix;             // where the ranks leave their par
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static bool g_timing = false;
 static double g_t0 = 0;
-static void stage(const char *what) {  // FLX_CLI_TIMING=1: per-stage wall clock on stderr (not part of the reference surface)
+static void stage(const char *what) {  // FLX_CLI_TIMING=1: per-stage wall clock + resident memory on stderr (not part of the reference surface)
     if (!g_timing) return;
     const double t = now_s();
-    fprintf(stderr, "[timing] %-28s %8.3f s\n", what, t - g_t0);
-    g_t0 = t;
+    long anon_kb = 0, file_kb = 0, hwm_kb = 0;
+    if (FILE *f = fopen("/proc/self/status", "r")) {  // RssAnon = what the process owns; RssFile = resident pages of the mapped input
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            sscanf(line, "RssAnon: %ld kB", &anon_kb);
+            sscanf(line, "RssFile: %ld kB", &file_kb);
+            sscanf(line, "VmHWM: %ld kB", &hwm_kb);
+        }
+        fclose(f);
+    }
+    fprintf(stderr, "[timing] %-30s %8.3f s   RssAnon %7ld MiB  RssFile %7ld MiB  VmHWM %7ld MiB\n", what, t - g_t0, anon_kb >> 10,
+            file_kb >> 10, hwm_kb >> 10);
+    g_t0 = now_s();
 }
 
 static int fail_flx(flx_ctx *ctx, const char *what) {
