@@ -414,6 +414,8 @@ int flx_launch_score_phred(flx_ctx *ctx, const uint8_t *d_plane, uint64_t plane_
     const char *env = getenv("FLX_PHRED_KERNEL");  // test hook: "direct" / "ring" force the older kernels
     const bool force_direct = env && strcmp(env, "direct") == 0;
     const bool force_ring = env && strcmp(env, "ring") == 0;
+    const bool force_stream = env && strcmp(env, "stream") == 0;
+    if (force_stream) return flx_launch_score_phred_stream(ctx, a);
     if (!force_direct && !force_ring) {  // default: the register-history kernel, where the window size has an instantiation
         bool launched = false;
         a.n_slots = 0;
@@ -456,6 +458,9 @@ int flx_launch_score_phred(flx_ctx *ctx, const uint8_t *d_plane, uint64_t plane_
             FLX_LAUNCH_RING(7)
         }
 #undef FLX_LAUNCH_RING
+    } else if (!force_direct) {
+        // the window does not fit the LDS ring (ws > ~2000): both window edges streamed from global memory, 16-byte loads
+        return flx_launch_score_phred_stream(ctx, a);
     } else {
         a.n_slots = 0;
         a.stride = 0;

@@ -94,3 +94,5 @@ __device__ __forceinline__ void finish_read(const PhredArgs &a, uint32_t rid, in
 // score_phred_regs.hip: the register-history kernel.  *launched = false when the window size has no instantiation
 // (the caller then uses the LDS-ring kernel).
 int flx_launch_score_phred_regs(flx_ctx *ctx, flx_phred::PhredArgs a, bool *launched);
+// score_phred_regs.hip: any window size, both window edges streamed from global memory (used where the LDS ring does not fit)
+int flx_launch_score_phred_stream(flx_ctx *ctx, flx_phred::PhredArgs a);

@@ -373,6 +373,120 @@ done:
 }
 
 #if FLX_REGS_PART == 0
+// ---------------------------------------------------------------------------------------------------------------------
+// stream kernel: ANY window size.  One lane per read again, but both edges of the window come straight from global memory
+// with 16-byte loads per lane: the leading piece [16 t, 16 t + 16) and the aligned piece that completes the trailing edge
+// [16 t - ws, 16 t - ws + 16) (its first part is the piece loaded one step earlier).  The trailing stream lags `ws` bytes
+// behind the leading one, so it is served by the L2 / Infinity Cache, not by HBM.  64 lanes = 64 lines per load
+// instruction: this is bound by the address path (~2.7x slower than the register-history kernel at ws = 250), but it has no
+// per-read on-chip state at all, so it replaces the byte-wise direct kernel wherever the LDS ring does not fit
+// (ws > ~2000: 283 -> see profiles/r02_microbench.txt ms per 1e10 bases at ws = 2500).  Plain tables, 16 waves per CU.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) flx_score_phred_stream(const PhredArgs a) {
+    using T = Tab<false>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    for (int i = threadIdx.x; i < 257; i += 1024) {
+        *reinterpret_cast<double *>(smem + T::QOFF + i * 8) = a.lut_q[i];
+        *reinterpret_cast<double *>(smem + T::DOFF + i * 8) = a.lut_d[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t zaddr = (uint32_t)(T::ZIDX * T::ROW);
+    const int ws = a.ws;
+    const int A = ws >> 4, B = ws & 15;
+    const int fD = (16 - B) >> 2;
+    const uint32_t fsh = (uint32_t)(16 - B) & 3u;
+    const double ws_d = a.ws_d;
+    for (;;) {
+        unsigned int group = 0;
+        if (lane == 0) group = atomicAdd(a.ticket, 1u);
+        group = (unsigned int)__builtin_amdgcn_readfirstlane((int)group);
+        if (group >= a.n_groups) break;
+        const uint64_t gslot = (uint64_t)group * 64 + lane;
+        const bool live = gslot < a.n_reads;
+        uint32_t rid = 0;
+        int L = 0;
+        uint64_t base = 0;
+        if (live) {
+            rid = a.order ? a.order[gslot] : (uint32_t)gslot;
+            L = a.lengths[rid];
+            base = a.offsets[rid];
+        }
+        const int Lmax = wave_max(L);
+        if (Lmax == 0) {
+            if (live) finish_read(a, rid, L, 0.0, 0.0);
+            continue;
+        }
+        const uint8_t *src = (L > 0) ? a.plane + base : a.plane;
+        const int maxoff = max(((L + 15) & ~15) - 16, 0);  // loads past the end of a read are clamped into it (never used: masked)
+        auto ld16 = [&](int off) { return *reinterpret_cast<const uint4 *>(src + min(max(off, 0), maxoff)); };
+        const int n_pieces = (Lmax + 15) >> 4;
+        double s = 0.0, w = 0.0, mn = 0.0;
+        uint4 lead = ld16(0), lead_next = ld16(16);
+        uint4 tr_prev = make_uint4(0, 0, 0, 0), tr_cur = tr_prev, tr_next = ld16(-16 * A);  // piece -A (clamped to piece 0)
+        // aligned trailing pieces: step t needs pieces t-A-1 and t-A of the stream; they exist from t = A on (piece 0)
+        for (int t = 0; t < n_pieces; ++t) {
+            const uint4 lw4 = lead;
+            lead = lead_next;
+            lead_next = ld16(16 * (t + 2));
+            tr_prev = tr_cur;   // piece t-A-1
+            tr_cur = tr_next;   // piece t-A
+            tr_next = ld16(16 * (t + 1 - A));  // piece t+1-A (clamped to the read while t+1 < A: unused)
+            const uint32_t lw[4] = {lw4.x, lw4.y, lw4.z, lw4.w};
+            const int rem = L - 16 * t;
+            if (t < A) {  // all 16 positions < window_size: only the running sum
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    uint32_t aj[4];
+                    aj[0] = tab_addr<false, 0>(lw[d], 0); aj[1] = tab_addr<false, 1>(lw[d], 0);
+                    aj[2] = tab_addr<false, 2>(lw[d], 0); aj[3] = tab_addr<false, 3>(lw[d], 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) aj[i] = (4 * d + i) < rem ? aj[i] : zaddr;
+                    head4<T::QOFF>(aj[0], aj[1], aj[2], aj[3], s);
+                }
+                if (t == A - 1 && B == 0) {
+                    w = s / ws_d;
+                    mn = w;
+                }
+                continue;
+            }
+            const uint32_t p0[4] = {tr_prev.x, tr_prev.y, tr_prev.z, tr_prev.w};
+            const uint32_t p1[4] = {tr_cur.x, tr_cur.y, tr_cur.z, tr_cur.w};
+            uint32_t tw[4];
+            funnel(p0, p1, fD, fsh, tw);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint32_t aj[4], ai[4];
+                aj[0] = tab_addr<false, 0>(lw[d], 0); aj[1] = tab_addr<false, 1>(lw[d], 0);
+                aj[2] = tab_addr<false, 2>(lw[d], 0); aj[3] = tab_addr<false, 3>(lw[d], 0);
+                ai[0] = tab_addr<false, 0>(tw[d], 0); ai[1] = tab_addr<false, 1>(tw[d], 0);
+                ai[2] = tab_addr<false, 2>(tw[d], 0); ai[3] = tab_addr<false, 3>(tw[d], 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool act = (4 * d + i) < rem;
+                    aj[i] = act ? aj[i] : zaddr;
+                    ai[i] = act ? ai[i] : zaddr;
+                }
+                if (t > A) {
+                    fold4<T::QOFF, T::DOFF>(aj[0], aj[1], aj[2], aj[3], ai[0], ai[1], ai[2], ai[3], s, w, mn);
+                } else {  // the piece that holds position window_size (src/read.cpp:219-224)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = 4 * d + i;
+                        if (k < B) head1<T::QOFF>(aj[i], s);
+                        else fold1<T::QOFF, T::DOFF>(aj[i], ai[i], s, w, mn);
+                        if (k == B - 1) {
+                            w = s / ws_d;
+                            mn = w;
+                        }
+                    }
+                }
+            }
+        }
+        if (live) finish_read(a, rid, L, s, mn);
+    }
+}
+
 // reads flagged by the bank-private variant (a byte >= 128): exact re-scoring, one lane per read
 __global__ void __launch_bounds__(256) flx_score_phred_redo(const PhredArgs a) {
     __shared__ double lq[LUT_PAD];
@@ -489,6 +603,23 @@ __global__ void __launch_bounds__(256) flx_phred_sample(const PhredArgs a, unsig
     atomicAdd(&hist[a.plane[a.offsets[r] + pos]], 1u);
 }
 }  // namespace
+
+int flx_launch_score_phred_stream(flx_ctx *ctx, PhredArgs a) {
+    void *scr;
+    FLX_CHECK(flx_scratch(ctx, 64, &scr));
+    FLX_HIP(ctx, hipMemsetAsync(scr, 0, 8, ctx->stream));
+    a.ticket = (unsigned int *)scr;
+    a.n_groups = (unsigned int)((a.n_reads + 63) / 64);
+    const size_t lds = 84 * 1024;  // one persistent workgroup of 16 waves per CU
+    FLX_HIP(ctx, hipFuncSetAttribute((const void *)flx_score_phred_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)a.n_groups + 15) / 16, (uint64_t)ctx->prop.multiProcessorCount);
+    ctx->last_phred_kernel = "flx_score_phred_stream";
+    flx_time_begin(ctx, ctx->last_phred_kernel);
+    hipLaunchKernelGGL(flx_score_phred_stream, dim3(grid), dim3(1024), lds, ctx->stream, a);
+    flx_time_end(ctx);
+    FLX_HIP(ctx, hipGetLastError());
+    return FLX_OK;
+}
 
 int flx_launch_score_phred_regs(flx_ctx *ctx, PhredArgs a, bool *launched) {
     *launched = false;

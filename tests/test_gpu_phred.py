@@ -47,13 +47,13 @@ def score_hip(ctx, reads, pkw, use_order=True):
 def select_kernel(monkeypatch, kernel):
     """default = register-history kernel where the window size has one (48..319, else LDS ring), table layout chosen from a
     sample of the data; "plain" / "private" force its table layout; "ring" / "direct" force the older kernels."""
-    if kernel in ("ring", "direct"):
+    if kernel in ("ring", "direct", "stream"):
         monkeypatch.setenv("FLX_PHRED_KERNEL", kernel)
     elif kernel in ("private", "plain"):
         monkeypatch.setenv("FLX_PHRED_TABLES", kernel)
 
 
-@pytest.mark.parametrize("kernel", ["default", "plain", "private", "ring", "direct"])
+@pytest.mark.parametrize("kernel", ["default", "plain", "private", "ring", "direct", "stream"])
 def test_golden_synth_phred(ctx, kernel, monkeypatch):
     select_kernel(monkeypatch, kernel)
     gold = json.load(open(os.path.join(_cases.GOLDEN, "probe_synth_phred.json")))
@@ -150,9 +150,11 @@ def test_device_generator_matches_numpy(ctx, profile):
         assert (got[o + L:o + ((L + 15) & ~15)] == 0).all()
 
 
-def test_randomised_configurations_vs_oracle(ctx):
+@pytest.mark.parametrize("kernel", ["default", "stream"])
+def test_randomised_configurations_vs_oracle(ctx, kernel, monkeypatch):
     """40 random (window_size, cut-offs, batch shape) configurations: window sizes around every 16/64-byte boundary and up
     to the ring/direct switch, batches smaller than a wave, reads shorter than the window, unsorted order."""
+    select_kernel(monkeypatch, kernel)
     rng = np.random.RandomState(2024)
     ws_pool = [1, 2, 15, 16, 17, 31, 32, 48, 63, 64, 65, 127, 128, 129, 192, 249, 250, 251, 255, 256, 257, 320, 511, 512,
                1000, 1999, 2000, 2047, 2048, 2100, 3000]
