@@ -468,10 +468,11 @@ static void parse_sequential(const Input &d, Parsed &out) {
     }
 }
 
-// A position that is certainly the start of a record: beginning of a line, '>' (sequence lines never start with it) or
-// '@' whose line + 2 starts with '+' and whose lines + 1 and + 3 have equal lengths (a quality line can start with '@',
-// but then the line after it is a header or a sequence, not '+').  Returns d.size() if none is found before `limit`.
-static size_t find_record_start(const Input &d, size_t from, size_t limit) {
+// A position that is certainly the start of a record.  FASTQ input (`fastq`: the file's first record is one): the beginning
+// of a line starting with '@' (or '>') whose line + 2 starts with '+' and whose lines + 1 and + 3 have equal lengths — a
+// quality line can start with '@' or '>' (Phred 31 / 29) too, but then the line after it is a header or a sequence, not '+'.
+// FASTA input: a line starting with '>' (sequence lines never start with it).  Returns d.size() if none is found before `limit`.
+static size_t find_record_start(const Input &d, size_t from, size_t limit, bool fastq) {
     const char *b = d.p;
     const size_t n = d.n;
     auto line_end = [&](size_t at) -> size_t { return at >= n ? n : (size_t)(std::find(b + at, b + n, '\n') - b); };
@@ -479,8 +480,8 @@ static size_t find_record_start(const Input &d, size_t from, size_t limit) {
     if (at > 0) at = line_end(at - 1) + 1;  // first line start >= from
     while (at < limit && at < n) {
         const size_t e0 = line_end(at);
-        if (b[at] == '>') return at;
-        if (b[at] == '@' && e0 < n) {
+        if (b[at] == '>' && !fastq) return at;
+        if ((b[at] == '@' || b[at] == '>') && fastq && e0 < n) {
             const size_t s1 = e0 + 1, e1 = line_end(s1);
             const size_t s2 = e1 + 1;
             if (e1 < n && s2 < n && b[s2] == '+') {
@@ -505,8 +506,11 @@ static bool parse_parallel(const Input &d, Parsed &out) {
     if (t < 2 || d.n < min_bytes || d.n < t) return false;
     std::vector<size_t> start(t + 1, d.n);
     start[0] = 0;
+    size_t h0 = 0;  // the kind of the first record decides which lines can start a record
+    while (h0 < d.n && d.p[h0] != '>' && d.p[h0] != '@') ++h0;
+    const bool fastq = h0 < d.n && d.p[h0] == '@';
     for (unsigned k = 1; k < t; ++k) {
-        start[k] = find_record_start(d, d.n / t * k, d.n / t * (k + 1));
+        start[k] = find_record_start(d, d.n / t * k, d.n / t * (k + 1), fastq);
         if (start[k] >= d.n || start[k] <= start[k - 1]) return false;
     }
     struct Chunk { std::vector<Record> recs; std::deque<std::string> arena; bool ok = false; };

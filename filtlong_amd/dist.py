@@ -155,10 +155,17 @@ def make_reduce(group=None, device=None):
     return reduce
 
 
-def sharded_rank_and_cut(ctx, mean, window, length, passed, group=None, **cut):
+def sharded_rank_and_cut(ctx, mean, window, length, passed, group=None, final_score=None, **cut):
     """Global stage over the reads2 entries of all ranks; `mean`/`window`/`length`/`passed` are this rank's device
     tensors (f64, f64, i32, u8), `passed` is updated in place with the final flags.  `cut` = the keyword arguments of
-    Context.rank_and_cut_dev (weights, target_bases, keep_percent, total_bases).  Returns the (global) report."""
+    Context.rank_and_cut_dev (weights, target_bases, keep_percent, total_bases — the GLOBAL total, required with a
+    threshold); `final_score` (optional f64 tensor of the local size) receives the local final scores.  Returns the
+    (global) report."""
+    if "d_final_score" in cut:
+        raise ValueError("pass final_score=<local f64 tensor>, not a raw d_final_score pointer (the replicated fallback "
+                         "needs a buffer of the global size)")
+    if (cut.get("target_bases") is not None or cut.get("keep_percent") is not None) and not cut.get("total_bases"):
+        raise ValueError("total_bases (global sum of the original read lengths, src/main.cpp:89) is required with a threshold")
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n_local = mean.numel()
@@ -167,7 +174,8 @@ def sharded_rank_and_cut(ctx, mean, window, length, passed, group=None, **cut):
     torch.cuda.synchronize(mean.device)  # the library works on its own stream
     rep, need_replicated = ctx.rank_and_cut_sharded_dev(
         sum(counts), g_mean.data_ptr(), first, n_local, window.data_ptr(), length.data_ptr(), passed.data_ptr(),
-        rank, world, reduce=make_reduce(group, mean.device), **cut)
+        rank, world, reduce=make_reduce(group, mean.device),
+        d_final_score=final_score.data_ptr() if final_score is not None else None, **cut)
     if not need_replicated:
         return rep
     # exact tie / NaN fallback: everything to every rank, the single-GPU stage replicated
@@ -176,8 +184,12 @@ def sharded_rank_and_cut(ctx, mean, window, length, passed, group=None, **cut):
     m.copy_(mean); w.copy_(window); l.copy_(length); p.copy_(passed)
     a_mean, a_win, a_len, a_pass, counts = gather_records(buf, n_local, group)
     torch.cuda.synchronize(mean.device)
-    rep = ctx.rank_and_cut_dev(sum(counts), a_mean.data_ptr(), a_win.data_ptr(), a_len.data_ptr(), a_pass.data_ptr(), **cut)
+    all_scores = torch.empty(sum(counts), dtype=torch.float64, device=mean.device) if final_score is not None else None
+    rep = ctx.rank_and_cut_dev(sum(counts), a_mean.data_ptr(), a_win.data_ptr(), a_len.data_ptr(), a_pass.data_ptr(),
+                               d_final_score=all_scores.data_ptr() if all_scores is not None else None, **cut)
     lo, hi = local_slice(counts, rank)
     passed.copy_(a_pass[lo:hi])
+    if final_score is not None:
+        final_score.copy_(all_scores[lo:hi])
     torch.cuda.synchronize(mean.device)
     return rep

@@ -68,6 +68,21 @@ def test_parallel_parse_equals_sequential(tmp_path, style, threads):
         assert seq == par, (style, threads, rep, "truncated at %d" % cut, accepted)
 
 
+def test_parallel_parse_is_taken_when_quality_lines_start_with_gt(tmp_path):
+    """Phred 29 is '>': a FASTQ quality line starting with it must not be mistaken for a record start (which made every
+    chunk boundary fail its exact-stop check and the whole file fall back to the sequential parser)."""
+    rng = np.random.RandomState(9)
+    out = bytearray()
+    for i in range(600):
+        L = int(rng.randint(20, 300))
+        out += b"@q%d\n" % i + bytes(rng.choice(list(b"ACGT"), size=L).astype(np.uint8)) + b"\n+\n" + b">" * L + b"\n"
+    path = str(tmp_path / "gt.fastq")
+    open(path, "wb").write(bytes(out))
+    seq, _ = digest(path, "seq")
+    par, accepted = digest(path, "par", 8)
+    assert accepted and seq == par
+
+
 def test_parallel_parse_is_taken_on_plain_fastq_and_fasta(tmp_path):
     rng = np.random.RandomState(1)
     path = str(tmp_path / "plain.fastq")
