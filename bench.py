@@ -39,6 +39,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 RANDOM_REQ_PEAK_G = 55.0     # tools/randbench: random 4-byte reads from a table beyond the L2, G requests/s (64 B each)
+L2_LOOKUP_PEAK_G = 265.0     # tools/randbench: the same from an L2-resident table (<= 4 MiB)
 REF_LEN = 5_000_000
 
 
@@ -143,7 +144,7 @@ class Batch:
         self.d_ids = torch.arange(first, first + n, dtype=torch.int64, device=dev)
 
 
-def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac):
+def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
     """C3 / C4 on one GPU: k-mer scoring + reads2 gather + global stage; returns the result dictionary."""
     from filtlong_amd import api, synth, _lib
     ref = synth.bases_read(synth.STREAM_REF, 0, 0, REF_LEN)
@@ -156,7 +157,7 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac):
         ks.add_assembly_fasta([ref.tobytes()])
     ks.finalize()
     build_s = time.time() - t0
-    b = Batch(ctx, torch, dev, n, 0, 0)
+    b = Batch(ctx, torch, dev, n, 0, fixed_len)
     d_ref = torch.from_numpy(ref).to(dev)
     torch.cuda.synchronize()
     ctx.synth_seq_dev(synth.SEED, b.d_plane.data_ptr(), b.plane_bytes, b.d_off.data_ptr(), b.d_len.data_ptr(),
@@ -224,7 +225,8 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac):
     if os.path.exists(fpath):
         rec = json.load(open(fpath)).get(cfg)
         if rec:  # per-base figures measured at 1e6 reads, scaled to this batch (the mix of reads is the same)
-            far = {"far_requests": rec["far_requests_per_base"] * b.bases, "traffic_bytes": rec["traffic_bytes_per_base"] * b.bases}
+            far = {"far_requests": rec["far_requests_per_base"] * b.bases, "traffic_bytes": rec["traffic_bytes_per_base"] * b.bases,
+                   "l2_hits": rec["l2_hit_requests_per_base"] * b.bases}
     algo_bytes = b.bases + 33 * n + 25 * nc  # L + 8 + 25 per read, 8 + 17 per child
     out = {
         "workload": "%s: %s reads x gamma(k=4) mean 10 kbp from a 5 Mbp reference, %s, --target_bases %d" % (
@@ -237,14 +239,17 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac):
         "lookups_per_s_G": round(lookups / (cover * 1e-3) / 1e9, 2),
         "roofline": {
             "bound": "hbm", "kernel": "k_kmer_cover",
-            "note": "bound by random 64-byte fabric requests into the 512 MiB exact 16-mer bitmap, not by streaming: `achieved` = "
-                    "far requests x 64 B / kernel time (requests from the PMC pass recorded in profiles/, not from this run), "
-                    "`peak` = the measured random-request ceiling (tools/randbench: 55 G requests/s x 64 B); the streamed "
-                    "bytes (SURVEY §8d, `algorithmic_bytes`) are %.1f %% of the 8 TB/s HBM peak over the whole step" % (
+            "note": "not a streaming kernel: per position ONE random L2-hit lookup (2 MiB 12-mer prefilter) and, for candidates, a random "
+                    "64-byte fabric request into the 512 MiB exact bitmap; both go through the same vector-memory path.  `achieved` = far "
+                    "requests x 64 B / kernel time, `peak` = the measured random-request ceiling (tools/randbench: 55 G requests/s x 64 B); "
+                    "`l2_lookup_frac` = L2-hit lookups/s over the 265 G/s an L2-resident table delivers alone; the two fractions add up to "
+                    "~1 (request counts from the PMC pass recorded in profiles/, not from this run).  The streamed bytes (SURVEY §8d, "
+                    "`algorithmic_bytes`) are %.1f %% of the 8 TB/s HBM peak over the whole step" % (
                         100.0 * algo_bytes / el / 1e9 / HBM_PEAK_GBS),
             "achieved": round(far["far_requests"] * 64 / (cover * 1e-3) / 1e9, 1) if far else None,
             "peak": RANDOM_REQ_PEAK_G * 64, "unit": "GB/s",
             "frac": round(far["far_requests"] / (cover * 1e-3) / 1e9 / RANDOM_REQ_PEAK_G, 4) if far else None,
+            "l2_lookup_frac": round(far["l2_hits"] / (cover * 1e-3) / 1e9 / L2_LOOKUP_PEAK_G, 4) if far else None,
             "traffic": int(far["traffic_bytes"]) if far else None, "avg_kernel_ms": round(cover, 3),
             "algorithmic_bytes": int(algo_bytes)},
         "cut": {"target_bases": int(rep.target_bases), "kept_bases": int(rep.kept_bases), "outcome": int(rep.outcome)},
@@ -313,7 +318,7 @@ def main():
     if args.config in ("c3", "c4"):
         if multi:
             sys.exit("bench.py --config %s is a single-GPU configuration" % args.config)
-        r = run_kmer(ctx, torch, dev, args.config, n, args.steps, args.warmup, args.target_frac)
+        r = run_kmer(ctx, torch, dev, args.config, n, args.steps, args.warmup, args.target_frac, args.fixed_len)
         info = ctx.device_info()
         out = {"metric": "Mbases/s scored+sorted", "value": r["value"], "unit": "Mbases/s", "n_gpus": 1, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",

@@ -65,10 +65,9 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
             const bool active = p0 < L && L >= 16;
             uint32_t hits = 0;
             uint32_t kmers[16];
-            uint32_t kleft[4] = {0, 0, 0, 0};  // the 16-mers ending at p0-4 .. p0-1 (their low 24 bits are the 12-mers there)
-            uint32_t p12 = 0;                  // bit j: the 12-mer ending at p0 + j occurs in the set
-            uint32_t p12_left = 0;             // the same for p0-4 .. p0-1 (only the first thread of a span looks them up itself)
-            bool anchor_hit = false;
+            uint32_t kleft[5] = {0, 0, 0, 0, 0};  // the 16-mers ending at p0-5 .. p0-1 (their low 24 bits are the 12-mers there)
+            uint32_t p12 = 0;                     // bit j: the 12-mer ending at p0 + j occurs in the set
+            uint32_t p12_left = 0;                // the same for p0-5 .. p0-1 (only the first thread of a span looks them up itself)
             if (active) {
                 // bases [p0-16, p0+16): both loads are 16-byte aligned (read starts are)
                 uint4 a = make_uint4(0, 0, 0, 0);
@@ -79,7 +78,7 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
 #pragma unroll
                 for (int j = 1; j < 16; ++j) {
                     k = (k << 2) | code_fwd((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
-                    if (j >= 12) kleft[j - 12] = k;
+                    if (j >= 11) kleft[j - 11] = k;
                 }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
@@ -87,7 +86,11 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
                     kmers[j] = k;  // 16-mer ending at position p0 + j
                 }
                 // 12-mer prefilter (kmerset.h): one L2 lookup per position, all 16 in flight
+#ifdef FLX_ABL_NOL2
+                if (false) {
+#else
                 if (prefilter) {
+#endif
                     uint32_t pw[16];
 #pragma unroll
                     for (int j = 0; j < 16; ++j) pw[j] = prefilter[flx_sub12(kmers[j], 0) >> 5];
@@ -98,45 +101,87 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
                     }
                     if (t == 0 && p0 > 0) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (p0 - 4 + j >= 11) p12_left |= ((prefilter[flx_sub12(kleft[j], 0) >> 5] >> (kleft[j] & 31)) & 1u) << j;
+                        for (int j = 0; j < 5; ++j)
+                            if (p0 - 5 + j >= 11) p12_left |= ((prefilter[flx_sub12(kleft[j], 0) >> 5] >> (kleft[j] & 31)) & 1u) << j;
                     }
                 } else {
                     p12 = 0xffffu;
-                    p12_left = 0xfu;
+                    p12_left = 0x1fu;
                 }
             }
             sh_p12[t] = (uint16_t)p12;
             __syncthreads();
-            uint32_t cand = 0;  // bit j: the 16-mer ending at p0 + j may be present (all five of its 12-mers are)
+            // Candidates: bit j = the 16-mer ending at p0 + j may be present (all five of its 12-mers are, and it lies in the read).
+            // Lookups: a base is covered iff ANY 16-mer over it is present, so of a run of consecutive candidates only
+            // the END points matter as long as they are present — their spans [j-15, j] overlap inside a thread's 16
+            // positions and cover everything the run's other members could.  Per thread: probe the first and last
+            // candidate of every run (the first one is skipped when the run continues from the left neighbour and that
+            // neighbour's last probe hit); only if a probe MISSES (a filter false positive, ~2 %) are the run's other
+            // members looked up too.  Coverage is identical to looking all of them up; far requests per position drop
+            // from one per present 16-mer to ~2 per clean stretch.
+            uint32_t cand = 0, probed = 0;
+            bool left_run = false;  // the candidate run at bit 0 continues from the left neighbour's bit 15
             if (active) {
-                if (t > 0) p12_left = prefilter ? (uint32_t)(sh_p12[t - 1] >> 12) : 0xfu;
-                const uint32_t m = p12_left | (p12 << 4);  // bit i: the 12-mer ending at p0 - 4 + i
+                if (t > 0) p12_left = prefilter ? (uint32_t)(sh_p12[t - 1] >> 11) : 0x1fu;
+                const uint32_t m = (p12_left >> 1) | (p12 << 4);  // bit i: the 12-mer ending at p0 - 4 + i
                 cand = m & (m >> 1) & (m >> 2) & (m >> 3) & (m >> 4) & 0xffffu;
-                // Anchor first: the 16-mer ending at p0+15 spans exactly this thread's 16 bases, so if it is present they
-                // are all covered and the other 15 lookups of the block cannot change them.  Those 15 are needed only
-                // when this anchor misses (own bases) or the LEFT neighbour's anchor misses (its bases reach up to
-                // p0-1 and can be covered by 16-mers ending at p0 .. p0+14).  Every hit that can influence a coverage
-                // bit is still evaluated, so the result is identical; on clean reads it is 1 lookup per 16 bases
-                // instead of 16 — the bitmap lookups are bound by the fabric's random-request rate.
-                const int ia = p0 + 15;
-                const bool a_hit = ia < L && ((cand >> 15) & 1u) && ((bitmap[kmers[15] >> 5] >> (kmers[15] & 31)) & 1u);
-                anchor_hit = a_hit;
-                if (a_hit) hits = 1u << 15;
+                uint32_t valid = 0xffffu;  // 16-mers end at positions 15 .. L-1
+                if (p0 < 15) valid &= ~((1u << (15 - p0)) - 1u);
+                if (p0 + 16 > L) valid &= (1u << (L - p0)) - 1u;
+                cand &= valid;
+                left_run = t > 0 && p12_left == 0x1fu && p0 - 1 >= 15;  // the left neighbour's bit 15 is a candidate
+                const uint32_t starts = cand & ~(cand << 1), ends = cand & ~(cand >> 1);
+                probed = ends | (left_run ? starts & ~1u : starts);
+#ifdef FLX_ABL_NOFAR
+                hits = probed;
+#else
+                uint32_t words[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) words[j] = ((probed >> j) & 1u) ? bitmap[kmers[j] >> 5] : 0u;  // independent, in flight
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if ((probed >> j) & 1u) hits |= ((words[j] >> (kmers[j] & 31)) & 1u) << j;
+#endif
             }
-            sh_anchor[t] = anchor_hit ? 1 : 0;
+            sh_anchor[t] = (uint8_t)((hits >> 15) & 1u);
             __syncthreads();
             if (active) {
-                const bool left_hit = (t > 0) ? (sh_anchor[t - 1] != 0) : false;  // first thread of a span: assume a miss
-                if (!anchor_hit || !left_hit) {
-                    uint32_t words[15];
+                if ((cand & 1u) && !(probed & 1u)) {  // run continuing from the left: its start is needed only if the neighbour's end missed
+                    if (!sh_anchor[t - 1]) {
+                        probed |= 1u;
+                        hits |= (bitmap[kmers[0] >> 5] >> (kmers[0] & 31)) & 1u;
+                    }
+                }
+                // A probe that missed (typically a false candidate right behind a clean stretch: the 12-mers it shares with the
+                // stretch are genuine, so the filter passes it with probability ~0.45): what is still needed for an exact answer
+                // are the run members OUTSIDE the span of its confirmed ones (or all of it, if none is confirmed yet).  Round 2
+                // asks for those within 4 positions of a missed probe (a false extension is rarely longer), round 3 for the rest.
+                auto still_needed = [&]() -> uint32_t {
+                    uint32_t up = hits, dn = hits, m = cand;  // flood the confirmed bits along their candidate runs
+                    up |= (up << 1) & m; dn |= (dn >> 1) & m;
+                    uint32_t mu = m & (m << 1), md = m & (m >> 1);
+                    up |= (up << 2) & mu; dn |= (dn >> 2) & md;
+                    mu &= mu << 2; md &= md >> 2;
+                    up |= (up << 4) & mu; dn |= (dn >> 4) & md;
+                    mu &= mu << 4; md &= md >> 4;
+                    up |= (up << 8) & mu; dn |= (dn >> 8) & md;
+                    const uint32_t inside = up & dn;  // between the lowest and the highest confirmed member of a run
+                    return cand & ~inside & ~probed & 0xffffu;
+                };
+                if (probed & ~hits) {
+                    const uint32_t miss = probed & ~hits;
+                    uint32_t near = (miss << 1) | (miss << 2) | (miss << 3) | (miss << 4) | (miss >> 1) | (miss >> 2) | (miss >> 3) | (miss >> 4);
+                    for (int round = 0; round < 2; ++round) {
+                        const uint32_t ask = still_needed() & (round == 0 ? near : 0xffffu);
+                        if (ask) {
+                            uint32_t words[16];
 #pragma unroll
-                    for (int j = 0; j < 15; ++j) words[j] = ((cand >> j) & 1u) ? bitmap[kmers[j] >> 5] : 0u;  // independent, in flight
+                            for (int j = 0; j < 16; ++j) words[j] = ((ask >> j) & 1u) ? bitmap[kmers[j] >> 5] : 0u;
 #pragma unroll
-                    for (int j = 0; j < 15; ++j) {
-                        const int i = p0 + j;
-                        const bool valid = i >= 15 && i < L;
-                        if (valid && ((words[j] >> (kmers[j] & 31)) & 1u)) hits |= 1u << j;
+                            for (int j = 0; j < 16; ++j)
+                                if ((ask >> j) & 1u) hits |= ((words[j] >> (kmers[j] & 31)) & 1u) << j;
+                            probed |= ask;
+                        }
                     }
                 }
             }
