@@ -36,14 +36,18 @@ __device__ __forceinline__ uint32_t code_fwd(uint32_t c) {  // src/kmers.cpp:176
 // ---------------------------------------------------------------------------------------------------
 // coverage
 // ---------------------------------------------------------------------------------------------------
-constexpr int COVER_THREADS = 256;
-constexpr int COVER_SPAN = COVER_THREADS * 16;  // positions per workgroup iteration
+// One workgroup per read, COVER_THREADS * 16 positions per iteration.  Two instantiations share the batch: 256 threads
+// (spans of 4096 positions) for reads longer than kCoverShort, one wavefront (spans of 1024) for the short ones, which
+// would leave most of a 256-thread workgroup idle (500 bp reads: 206 -> see profiles/r02_microbench.txt ms per 1e10 bases).
+constexpr int kCoverShort = 3072;
 
+template <int COVER_THREADS>
 __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *plane, const uint64_t *offsets,
                                                               const int32_t *lengths, const uint32_t *order,
                                                               uint64_t n_reads, const uint32_t *bitmap,
                                                               const uint32_t *prefilter, uint32_t *cov, const uint64_t *cov_off, int32_t *count,
                                                               int32_t *first, int32_t *last) {
+    constexpr int COVER_SPAN = COVER_THREADS * 16;  // positions per workgroup iteration
     __shared__ uint32_t sh_hits[COVER_THREADS];
     __shared__ uint16_t sh_p12[COVER_THREADS];
     __shared__ uint8_t sh_anchor[COVER_THREADS];
@@ -52,6 +56,7 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
     for (uint64_t slot = blockIdx.x; slot < n_reads; slot += gridDim.x) {
         const uint32_t rid = order ? order[slot] : (uint32_t)slot;
         const int L = lengths[rid];
+        if ((L > kCoverShort) != (COVER_THREADS > 64)) continue;  // the other instantiation's read (uniform for the workgroup)
         const uint8_t *seq = plane + offsets[rid];
         uint32_t *row = cov + (cov_off[rid] >> 2);
         const int row_words = (((L + 7) / 8 + 15) & ~15) >> 2;
@@ -614,7 +619,10 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     {
         const unsigned grid = (unsigned)std::min<uint64_t>(n_reads, 1u << 20);
         flx_time_begin(ctx, "flx_score_kmer_cover");
-        hipLaunchKernelGGL(k_kmer_cover, dim3(grid), dim3(COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
+        hipLaunchKernelGGL(k_kmer_cover<256>, dim3(grid), dim3(256), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
+                           flx_kmerset_bitmap(set), flx_kmerset_prefilter(set), d_cov.as<uint32_t>(), d_covoff.as<uint64_t>(), d_cnt.as<int32_t>(), first,
+                           last);
+        hipLaunchKernelGGL(k_kmer_cover<64>, dim3(grid), dim3(64), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
                            flx_kmerset_bitmap(set), flx_kmerset_prefilter(set), d_cov.as<uint32_t>(), d_covoff.as<uint64_t>(), d_cnt.as<int32_t>(), first,
                            last);
         flx_time_end(ctx);
