@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "flx_ctx_synchronize", "flx_ctx_device_info", "flx_timing_enable", "flx_timing_reset", "flx_timing_get",
     "flx_plane_layout", "flx_length_order", "flx_score_batch", "flx_score_batch_dev", "flx_rank_and_cut",
     "flx_rank_and_cut_dev", "flx_rank_and_cut_sharded_dev", "flx_rank_and_cut_comm_dev", "flx_rank_and_cut_comm", "flx_comm_unique_id",
-    "flx_pipeline_create", "flx_pipeline_next_buffer", "flx_pipeline_submit", "flx_pipeline_finish", "flx_pipeline_destroy",
+    "flx_pipeline_create", "flx_pipeline_reserve", "flx_pipeline_next_buffer", "flx_pipeline_submit", "flx_pipeline_finish", "flx_pipeline_destroy",
     "flx_comm_init", "flx_comm_destroy", "flx_comm_rank", "flx_comm_world", "flx_comm_sum_u64", "flx_kmerset_create", "flx_kmerset_destroy", "flx_kmerset_add_assembly",
     "flx_kmerset_add_short_reads", "flx_kmerset_finalize", "flx_kmerset_size", "flx_kmerset_contains",
     "flx_last_phred_kernel", "flx_synth_qual_dev", "flx_synth_qual_profile_dev", "flx_synth_seq_dev",
@@ -128,6 +128,7 @@ def load():
     L.flx_rank_and_cut_comm_dev.argtypes = rank_args
     L.flx_rank_and_cut_comm.argtypes = rank_args
     L.flx_pipeline_create.argtypes = [vp, vp, C.POINTER(Params), u64, u64, C.POINTER(vp)]
+    L.flx_pipeline_reserve.argtypes = [vp, u64, u64]
     L.flx_pipeline_next_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.flx_pipeline_submit.argtypes = [vp, u64, vp, vp, u64]
     L.flx_pipeline_finish.argtypes = [vp, C.POINTER(Scores), C.POINTER(u64)]

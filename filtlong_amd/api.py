@@ -160,6 +160,54 @@ class Context:
         out["child_mean_q"], out["child_window_q"], out["child_passed"] = cm[:nc], cw[:nc], cp[:nc]
         return out
 
+    # ---- seam 2, streaming ----------------------------------------------------------------------
+    def score_stream(self, chunks, params, kmers=None, chunk_bytes=1 << 20, chunk_reads=1 << 12, grow=False):
+        """flx_pipeline_*: `chunks` is an iterable of lists of byte strings (Phred mode: qualities, k-mer mode: sequences).
+        Every chunk is packed into the pipeline's pinned buffer and submitted; returns the same dict as score_reads for
+        all reads in submission order.  grow: enlarge the slots (flx_pipeline_reserve) for a chunk that does not fit."""
+        L = self.L
+        pipe = C.c_void_p()
+        self._check(L.flx_pipeline_create(self.h, kmers.h if kmers is not None else None, C.byref(params), chunk_bytes,
+                                          chunk_reads, C.byref(pipe)))
+        try:
+            for strings in chunks:
+                n = len(strings)
+                lengths = np.array([len(x) for x in strings], dtype=np.int32)
+                offsets = np.zeros(max(n, 1), dtype=np.uint64)
+                pb = C.c_uint64()
+                self._check(L.flx_plane_layout(lengths.ctypes.data, n, offsets.ctypes.data, C.byref(pb)))
+                if grow:
+                    self._check(L.flx_pipeline_reserve(pipe, pb.value, n))
+                buf, cap_b, cap_r = C.c_void_p(), C.c_uint64(), C.c_uint64()
+                self._check(L.flx_pipeline_next_buffer(pipe, C.byref(buf), C.byref(cap_b), C.byref(cap_r)))
+                if pb.value <= cap_b.value:  # an oversized chunk is submitted as is: the library must refuse it
+                    view = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(max(int(pb.value), 1),))
+                    view[:pb.value] = 0
+                    for x, o in zip(strings, offsets):
+                        if len(x):
+                            view[int(o):int(o) + len(x)] = np.frombuffer(bytes(x), dtype=np.uint8)
+                self._check(L.flx_pipeline_submit(pipe, pb.value, offsets.ctypes.data, lengths.ctypes.data, n))
+            s, n_all = Scores(), C.c_uint64()
+            self._check(L.flx_pipeline_finish(pipe, C.byref(s), C.byref(n_all)))
+            n, nc = int(n_all.value), int(s.n_children)
+
+            def take(ptr, dtype, count):
+                if count == 0:
+                    return np.zeros(0, dtype=dtype)
+                ct = np.ctypeslib.as_ctypes_type(dtype)
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(count,)).copy()
+
+            out = {"mean_q": take(s.mean_q, np.float64, n), "window_q": take(s.window_q, np.float64, n),
+                   "passed": take(s.passed, np.uint8, n), "first": take(s.first, np.int32, n),
+                   "last": take(s.last, np.int32, n), "child_offsets": take(s.child_offsets, np.uint64, n + 1),
+                   "child_ranges": take(s.child_ranges, np.int32, 2 * nc).reshape(-1, 2),
+                   "child_mean_q": take(s.child_mean_q, np.float64, nc),
+                   "child_window_q": take(s.child_window_q, np.float64, nc),
+                   "child_passed": take(s.child_passed, np.uint8, nc)}
+            return out
+        finally:
+            L.flx_pipeline_destroy(pipe)
+
     # ---- seam 2, device-resident ---------------------------------------------------------------
     def score_reads_dev(self, d_plane, plane_bytes, d_offsets, d_lengths, d_order, n, params, d_mean_q, d_window_q,
                         d_passed, kmers=None):
@@ -259,7 +307,6 @@ class Context:
     def synth_qual_dev(self, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n, profile=0):
         self._check(self.L.flx_synth_qual_profile_dev(self.h, seed, profile, d_plane, plane_bytes, d_offsets, d_lengths,
                                                       d_read_ids, n))
-
 
     def synth_seq_dev(self, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n, d_ref, ref_len):
         self._check(self.L.flx_synth_seq_dev(self.h, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n, d_ref,

@@ -550,21 +550,104 @@ static bool parse_all(const Input &d, Parsed &out) {  // true: the concurrent pa
     return false;
 }
 
-// FLX_CLI_PARSE_ONLY=seq|par: parse the input, print a digest of every field and exit (no GPU needed).  The CPU tests
-// compare the sequential parser with the concurrent one on generated odd files.
+// ---- block-wise parse of a compressed input -----------------------------------------------------------------------------
+// A gzip file cannot be mapped, and inflating all of it costs its uncompressed size in memory (the reference never holds
+// more than one record, src/kseq.h:87-110).  BlockReader inflates a block at a time and parses the records that are complete
+// inside it with the same Parser; the unfinished tail moves to the front of the next block.  A record is complete when the
+// parser stopped BEFORE the end of the buffer: it then never saw the end, so more data behind it cannot change the record.
+// Views of a batch are valid until the next call.  A record larger than the block doubles the buffer.
+struct BlockReader {
+    gzFile fp = nullptr;
+    std::vector<char> buf;
+    size_t have = 0, carry_from = 0;
+    bool eof = false, done = false, io_error = false;
+    BlockReader() = default;
+    BlockReader(const BlockReader &) = delete;
+    BlockReader &operator=(const BlockReader &) = delete;
+    ~BlockReader() { if (fp) gzclose(fp); }
+    static size_t block_bytes() {
+        if (const char *e = getenv("FLX_CLI_BLOCK_BYTES")) return std::max<size_t>(64, (size_t)atoll(e));  // tests force tiny blocks
+        if (const char *e = getenv("FLX_CLI_BLOCK_MB")) return std::max<size_t>(1, (size_t)atoll(e)) << 20;
+        return (size_t)256 << 20;
+    }
+    bool open(const std::string &path) {
+        fp = gzopen(path.c_str(), "r");  // transparent for uncompressed data too
+        if (!fp) return false;
+        gzbuffer(fp, 1 << 20);
+        buf.resize(block_bytes());
+        return true;
+    }
+    bool next(Parsed &out) {  // false: nothing left (or io_error)
+        out = Parsed();
+        if (done) return false;
+        if (carry_from > 0) {
+            if (carry_from < have) memmove(buf.data(), buf.data() + carry_from, have - carry_from);
+            have -= carry_from;
+            carry_from = 0;
+        }
+        for (;;) {
+            while (!eof && have < buf.size()) {
+                const int got = gzread(fp, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, 1u << 30));
+                if (got < 0) { io_error = true; done = true; return false; }
+                if (got == 0) eof = true;
+                else have += (size_t)got;
+            }
+            view.p = buf.data();
+            view.n = have;
+            out.arenas.emplace_back();
+            Parser ps(view, out.arenas.back());
+            Record r;
+            size_t consumed = have;
+            for (;;) {
+                const size_t header = ps.peek_header();
+                const long long len = ps.next(r);
+                if (!eof && ps.pos >= have) { consumed = std::min(header, have); break; }  // ran into the end of the block: unfinished
+                if (len == -1) break;
+                if (len == -2) { out.status = -2; out.bad = r; done = true; break; }
+                out.recs.push_back(r);
+            }
+            if (out.recs.empty() && !done && !eof && consumed == 0) {  // one record fills the whole block
+                buf.resize(buf.size() * 2);
+                out = Parsed();
+                continue;
+            }
+            carry_from = consumed;
+            if (eof) done = true;
+            return true;
+        }
+    }
+
+private:
+    Input view;  // non-owning window on buf
+};
+
+// FLX_CLI_PARSE_ONLY=seq|par|blk: parse the input, print a digest of every field and exit (no GPU needed).  The CPU tests
+// compare the sequential parser with the concurrent one and with the block-wise reader on generated odd files.
 static int parse_only(const std::string &path, const char *mode) {
-    Input data;
-    if (!data.open(path)) { std::cerr << "Error reading " << path << "\n"; return 1; }
-    Parsed parsed;
-    bool par = false;
-    if (mode[0] == 's') parse_sequential(data, parsed);
-    else par = parse_all(data, parsed);
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](const View &v) {
         for (size_t i = 0; i < v.n; ++i) { h ^= (unsigned char)v.p[i]; h *= 1099511628211ull; }
         h ^= 0xff; h *= 1099511628211ull;
     };
-    for (const Record &r : parsed.recs) { mix(r.name); mix(r.comment); mix(r.seq); mix(r.qual); h ^= r.is_fastq; h *= 1099511628211ull; }
+    auto mix_all = [&](const Parsed &pd) {
+        for (const Record &r : pd.recs) { mix(r.name); mix(r.comment); mix(r.seq); mix(r.qual); h ^= r.is_fastq; h *= 1099511628211ull; }
+    };
+    Parsed parsed;
+    bool par = false;
+    size_t n_records = 0;
+    if (mode[0] == 'b') {  // blocks: the streaming reader, FLX_CLI_BLOCK_BYTES per block
+        BlockReader rd;
+        if (!rd.open(path)) { std::cerr << "Error reading " << path << "\n"; return 1; }
+        while (rd.next(parsed)) { mix_all(parsed); n_records += parsed.recs.size(); if (parsed.status == -2) break; }
+        if (rd.io_error) { std::cerr << "Error reading " << path << "\n"; return 1; }
+        std::cout << "records " << n_records << " status " << parsed.status << " bad " << parsed.bad.name << " parallel 0 digest " << h << "\n";
+        return 0;
+    }
+    Input data;
+    if (!data.open(path)) { std::cerr << "Error reading " << path << "\n"; return 1; }
+    if (mode[0] == 's') parse_sequential(data, parsed);
+    else par = parse_all(data, parsed);
+    mix_all(parsed);
     std::cout << "records " << parsed.recs.size() << " status " << parsed.status << " bad " << parsed.bad.name << " parallel "
               << (par ? 1 : 0) << " digest " << h << "\n";
     return 0;
@@ -764,20 +847,132 @@ int main(int argc, char **argv) {
     stage("reference 16-mers");
     // ---- pass 1: parse, checks (src/main.cpp:63-130) -----------------------------------------------------
     if (!args.verbose) std::cerr << "Scoring long reads\n";
+    // Two kinds of input.  A plain file is mapped and parsed in one piece (one batch): its record views stay valid, so the
+    // output pass needs no second parse, and every rank can index it.  A gzip file is STREAMED on one GPU: a block is
+    // inflated, its complete records are checked, packed and submitted, and the block's memory is reused; the output pass
+    // inflates the file a second time, like the reference's pass 2 (src/main.cpp:263-313).  Pipes cannot be read twice and
+    // several ranks need the record count before they score: both are inflated into memory.
+    const int world = g_world, rank = g_rank;
     Input data;
-    if (!data.open(args.input_reads)) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
+    BlockReader blocks;
+    bool streamed = false;
+    {
+        const int fd = ::open(args.input_reads.c_str(), O_RDONLY);
+        if (fd < 0) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
+        unsigned char magic[2] = {0, 0};
+        struct stat st;
+        const bool regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0;
+        const bool gz = regular && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        ::close(fd);
+        streamed = regular && world == 1 && !getenv("FLX_CLI_NO_STREAM") && (gz || getenv("FLX_CLI_FORCE_STREAM"));
+    }
+    if (streamed ? !blocks.open(args.input_reads) : !data.open(args.input_reads)) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
     stage("read input file");
-    Parsed parsed;
-    parse_all(data, parsed);
-    stage("parse");
-    std::vector<Record> &recs = parsed.recs;
+
+    flx_params prm;
+    memset(&prm, 0, sizeof prm);
+    prm.window_size = (int32_t)args.window_size;
+    prm.min_length_set = args.min_length_set; prm.min_length = args.min_length;
+    prm.max_length_set = args.max_length_set; prm.max_length = args.max_length;
+    prm.min_mean_q_set = args.min_mean_q_set; prm.min_mean_q = args.min_mean_q;
+    prm.min_window_q_set = args.min_window_q_set; prm.min_window_q = args.min_window_q;
+    prm.trim = args.trim; prm.split_set = args.split_set; prm.split = args.split;
+    uint64_t chunk_bytes = streamed ? std::max<uint64_t>(4096, BlockReader::block_bytes()) : 1ull << 30, chunk_reads = 4u << 20;
+    if (const char *e = getenv("FLX_CLI_CHUNK_MB")) chunk_bytes = std::max<uint64_t>(1, (uint64_t)atoll(e)) << 20;
+    if (const char *e = getenv("FLX_CLI_CHUNK_BYTES")) chunk_bytes = std::max<uint64_t>(4096, (uint64_t)atoll(e));  // tests force many chunks
+
+    // what survives pass 1 for this rank's records: lengths and names (views into the mapped input, or copies when streaming)
+    Parsed kept;                          // the single batch of a mapped / in-memory input
+    std::vector<int32_t> lengths;
+    std::vector<std::string_view> names;
+    std::deque<std::string> name_arena;
+    uint64_t lo_rec = 0;                  // first record of this rank's contiguous block of file order
     long long total_bases = 0, last_progress = 0;
     bool any_fasta = false, any_fastq = false;
-    {
+    std::unordered_set<std::string_view> seen_names;
+    uint64_t n_records = 0, n_chunks = 0, n_batches = 0;
+    flx_pipeline *pipe = nullptr;
+    std::vector<uint64_t> offsets;
+
+    // Pack records [lo, lo + cnt) of a batch chunk by chunk into the pipeline's pinned staging buffers (two slots: the GPU
+    // copies and scores chunk k while the host threads pack chunk k+1); only per-read scalars survive a chunk.
+    auto score_records = [&](const std::vector<Record> &recs, uint64_t lo, uint64_t cnt) -> int {
+        const uint64_t base = lengths.size();
+        int32_t longest = 0;
+        for (uint64_t i = 0; i < cnt; ++i) {
+            lengths.push_back((int32_t)recs[lo + i].seq.size());
+            longest = std::max(longest, lengths.back());
+        }
+        const uint64_t need = (((uint64_t)longest + 15) & ~15ull) + 256;  // a read is never split over chunks
+        if (!pipe) {
+            if (!streamed) {  // everything is known: no larger slots than this rank's reads need
+                uint64_t total = 4096;
+                for (uint64_t i = 0; i < cnt; ++i) total += (((uint64_t)lengths[base + i] + 15) & ~15ull) + (lengths[base + i] >= 1024 ? 128 : 0);
+                chunk_bytes = std::min(chunk_bytes, total);
+                chunk_reads = std::min<uint64_t>(chunk_reads, std::max<uint64_t>(1, cnt));
+            }
+            chunk_bytes = std::max(chunk_bytes, need);
+            if (flx_pipeline_create(ctx, kmers_empty ? nullptr : kmers, &prm, chunk_bytes, chunk_reads, &pipe) != FLX_OK) return fail_flx(ctx, "pipeline");
+        } else if (need > chunk_bytes) {
+            chunk_bytes = need;
+            if (flx_pipeline_reserve(pipe, chunk_bytes, chunk_reads) != FLX_OK) return fail_flx(ctx, "pipeline");
+        }
+        const int32_t *len = lengths.data() + base;
+        for (uint64_t at = 0; at < cnt;) {
+            // the next chunk: as many records as fit the slot (flx_plane_layout's rule: 16-byte slots, 128-byte starts for long reads)
+            uint64_t end = at, bytes = 0;
+            while (end < cnt && end - at < chunk_reads) {
+                uint64_t off = bytes;
+                if (len[end] >= 1024) off = (off + 127u) & ~(uint64_t)127u;
+                const uint64_t nb = off + (((uint64_t)len[end] + 15u) & ~(uint64_t)15u);
+                if (nb > chunk_bytes && end > at) break;
+                bytes = nb;
+                ++end;
+            }
+            const uint64_t m = end - at;
+            offsets.assign(m, 0);
+            uint64_t plane_bytes = 0;
+            flx_plane_layout(len + at, m, offsets.data(), &plane_bytes);
+            uint8_t *plane = nullptr;
+            if (flx_pipeline_next_buffer(pipe, &plane, nullptr, nullptr) != FLX_OK) return fail_flx(ctx, "scoring");
+            const size_t parts = std::min<uint64_t>(m, (uint64_t)host_threads() * 8);
+            parallel_for(parts, [&](size_t k) {  // byte-balanced slices of the chunk's reads
+                const uint64_t lo_b = plane_bytes / parts * k, hi_b = k + 1 == parts ? plane_bytes : plane_bytes / parts * (k + 1);
+                const uint64_t first = std::lower_bound(offsets.begin(), offsets.end(), lo_b) - offsets.begin();
+                const uint64_t last = k + 1 == parts ? m : std::lower_bound(offsets.begin(), offsets.end(), hi_b) - offsets.begin();
+                for (uint64_t i = first; i < last; ++i) {
+                    const Record &r = recs[lo + at + i];
+                    const View &src = kmers_empty ? r.qual : r.seq;  // Phred mode reads qual, k-mer mode reads seq
+                    if (!src.empty()) memcpy(plane + offsets[i], src.p, src.size());
+                    const uint64_t tail = offsets[i] + src.size();  // the staging buffer is reused: clear the padding behind the read
+                    const uint64_t next = i + 1 < m ? offsets[i + 1] : plane_bytes;
+                    if (next > tail) memset(plane + tail, 0, next - tail);
+                }
+            });
+            if (flx_pipeline_submit(pipe, plane_bytes, offsets.data(), len + at, m) != FLX_OK) return fail_flx(ctx, "scoring");
+            at = end;
+            ++n_chunks;
+        }
+        return 0;
+    };
+
+    for (;;) {
+        Parsed batch_store;
+        Parsed &batch = streamed ? batch_store : kept;
+        if (streamed) {
+            if (!blocks.next(batch)) {
+                if (blocks.io_error) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
+                break;
+            }
+        } else {
+            if (n_batches > 0) break;
+            parse_all(data, batch);
+            stage("parse");
+        }
+        ++n_batches;
+        const std::vector<Record> &recs = batch.recs;
         // the per-record checks of src/main.cpp:84-117, in file order, then the parser's own end status
-        std::unordered_set<std::string_view> names;
-        names.reserve(recs.size() * 2);
-        uint64_t count = 0;
+        if (!streamed) seen_names.reserve(recs.size() * 2);
         for (const Record &r : recs) {
             total_bases += (long long)r.seq.size();
             const bool fasta_format = r.qual.empty() && !r.seq.empty();
@@ -793,88 +988,39 @@ int main(int argc, char **argv) {
                 std::cerr << "\n\n" << "Error: FASTA input not supported without an external reference" << "\n";
                 return 1;
             }
-            if (!names.insert(r.name.sv()).second) { std::cerr << "Error: duplicate read name: " << r.name << "\n"; return 1; }
-            ++count;
+            std::string_view name = r.name.sv();
+            if (streamed) {  // the block's memory is reused: keep a copy
+                name_arena.emplace_back(name);
+                name = name_arena.back();
+            }
+            if (!seen_names.insert(name).second) { std::cerr << "Error: duplicate read name: " << r.name << "\n"; return 1; }
+            if (streamed) names.push_back(name);
+            ++n_records;
             if (total_bases - last_progress >= 483611) {
                 last_progress = total_bases;
-                if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)count) << " reads (" << int_to_string(total_bases) << " bp)";
+                if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)n_records) << " reads (" << int_to_string(total_bases) << " bp)";
             }
         }
-        if (parsed.status == -2) { std::cerr << "Error: incorrect FASTQ format for read " << parsed.bad.name << "\n"; return 1; }
+        if (batch.status == -2) { std::cerr << "Error: incorrect FASTQ format for read " << batch.bad.name << "\n"; return 1; }
+        if (!streamed) stage("record checks");
+        // this rank's share of the batch: everything when streaming (one rank), else a contiguous block of file order by count
+        uint64_t lo = 0, cnt = recs.size();
+        if (!streamed) {
+            const uint64_t n_all = recs.size();
+            lo = n_all / (uint64_t)world * (uint64_t)rank + std::min<uint64_t>((uint64_t)rank, n_all % (uint64_t)world);
+            cnt = n_all / (uint64_t)world + ((uint64_t)rank < n_all % (uint64_t)world ? 1 : 0);
+            lo_rec = lo;
+            names.reserve(cnt);
+            for (uint64_t i = 0; i < cnt; ++i) names.push_back(recs[lo + i].name.sv());
+        }
+        if (const int rc = score_records(recs, lo, cnt)) return rc;
     }
-    if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)recs.size()) << " reads (" << int_to_string(total_bases) << " bp)";
+    { std::unordered_set<std::string_view>().swap(seen_names); }
+    if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)n_records) << " reads (" << int_to_string(total_bases) << " bp)";
     if (!args.verbose) std::cerr << "\n";  // verbose: after the per-read blocks, as in main.cpp:110-129
     const bool fasta_output = any_fasta, fastq_output = any_fastq;
-
-    stage("record checks");
-    // ---- pack and score (replaces one Read::Read per record, src/main.cpp:108) ---------------------------
-    // Streaming: the records of this rank are packed chunk by chunk into the pipeline's pinned staging buffers (two slots:
-    // the GPU copies and scores chunk k while the host threads pack chunk k+1); only per-read scalars survive a chunk.
-    // The input stays mapped, so the record views — and the output pass below — need no second parse.
-    const uint64_t n_all = recs.size();
-    const int world = g_world, rank = g_rank;
-    const uint64_t lo_rec = n_all / (uint64_t)world * (uint64_t)rank + std::min<uint64_t>((uint64_t)rank, n_all % (uint64_t)world);
-    const uint64_t n = n_all / (uint64_t)world + ((uint64_t)rank < n_all % (uint64_t)world ? 1 : 0);  // this rank's contiguous block of file order
-    std::vector<int32_t> lengths(n);
-    for (uint64_t i = 0; i < n; ++i) lengths[i] = (int32_t)recs[lo_rec + i].seq.size();
-    flx_params prm;
-    memset(&prm, 0, sizeof prm);
-    prm.window_size = (int32_t)args.window_size;
-    prm.min_length_set = args.min_length_set; prm.min_length = args.min_length;
-    prm.max_length_set = args.max_length_set; prm.max_length = args.max_length;
-    prm.min_mean_q_set = args.min_mean_q_set; prm.min_mean_q = args.min_mean_q;
-    prm.min_window_q_set = args.min_window_q_set; prm.min_window_q = args.min_window_q;
-    prm.trim = args.trim; prm.split_set = args.split_set; prm.split = args.split;
-
-    uint64_t chunk_bytes = 1ull << 30, chunk_reads = 4u << 20;
-    if (const char *e = getenv("FLX_CLI_CHUNK_MB")) chunk_bytes = std::max<uint64_t>(1, (uint64_t)atoll(e)) << 20;
-    if (const char *e = getenv("FLX_CLI_CHUNK_BYTES")) chunk_bytes = std::max<uint64_t>(4096, (uint64_t)atoll(e));  // tests force many chunks
-    {
-        int32_t longest = 0;
-        for (uint64_t i = 0; i < n; ++i) longest = std::max(longest, lengths[i]);
-        chunk_bytes = std::max<uint64_t>(chunk_bytes, (((uint64_t)longest + 15) & ~15ull) + 256);  // a read is never split over chunks
-    }
-    flx_pipeline *pipe = nullptr;
-    if (flx_pipeline_create(ctx, kmers_empty ? nullptr : kmers, &prm, chunk_bytes, chunk_reads, &pipe) != FLX_OK) return fail_flx(ctx, "pipeline");
-    uint64_t n_chunks = 0;
-    {
-        std::vector<uint64_t> offsets;
-        for (uint64_t at = 0; at < n;) {
-            // the next chunk: as many records as fit the slot (flx_plane_layout's rule: 16-byte slots, 128-byte starts for long reads)
-            uint64_t end = at, bytes = 0;
-            while (end < n && end - at < chunk_reads) {
-                uint64_t off = bytes;
-                if (lengths[end] >= 1024) off = (off + 127u) & ~(uint64_t)127u;
-                const uint64_t nb = off + (((uint64_t)lengths[end] + 15u) & ~(uint64_t)15u);
-                if (nb > chunk_bytes && end > at) break;
-                bytes = nb;
-                ++end;
-            }
-            const uint64_t m = end - at;
-            offsets.assign(m, 0);
-            uint64_t plane_bytes = 0;
-            flx_plane_layout(lengths.data() + at, m, offsets.data(), &plane_bytes);
-            uint8_t *plane = nullptr;
-            if (flx_pipeline_next_buffer(pipe, &plane, nullptr, nullptr) != FLX_OK) return fail_flx(ctx, "scoring");
-            const size_t parts = std::min<uint64_t>(m, (uint64_t)host_threads() * 8);
-            parallel_for(parts, [&](size_t k) {  // byte-balanced slices of the chunk's reads
-                const uint64_t lo_b = plane_bytes / parts * k, hi_b = k + 1 == parts ? plane_bytes : plane_bytes / parts * (k + 1);
-                const uint64_t lo = std::lower_bound(offsets.begin(), offsets.end(), lo_b) - offsets.begin();
-                const uint64_t hi = k + 1 == parts ? m : std::lower_bound(offsets.begin(), offsets.end(), hi_b) - offsets.begin();
-                for (uint64_t i = lo; i < hi; ++i) {
-                    const Record &r = recs[lo_rec + at + i];
-                    const View &src = kmers_empty ? r.qual : r.seq;  // Phred mode reads qual, k-mer mode reads seq
-                    if (!src.empty()) memcpy(plane + offsets[i], src.p, src.size());
-                    const uint64_t tail = offsets[i] + src.size();  // the staging buffer is reused: clear the padding behind the read
-                    const uint64_t next = i + 1 < m ? offsets[i + 1] : plane_bytes;
-                    if (next > tail) memset(plane + tail, 0, next - tail);
-                }
-            });
-            if (flx_pipeline_submit(pipe, plane_bytes, offsets.data(), lengths.data() + at, m) != FLX_OK) return fail_flx(ctx, "scoring");
-            at = end;
-            ++n_chunks;
-        }
-    }
+    const uint64_t n = lengths.size();
+    if (!pipe && flx_pipeline_create(ctx, kmers_empty ? nullptr : kmers, &prm, chunk_bytes, chunk_reads, &pipe) != FLX_OK) return fail_flx(ctx, "pipeline");
     flx_scores res;
     uint64_t n_scored = 0;
     if (flx_pipeline_finish(pipe, &res, &n_scored) != FLX_OK || n_scored != n) return fail_flx(ctx, "scoring");
@@ -893,14 +1039,14 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> r2_pass;
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t a = child_off[i], b = child_off[i + 1];
-        const Record &r = recs[lo_rec + i];
+        const std::string name(names[i]);
         if (a == b) {
-            reads2.push_back({lo_rec + i, 0, lengths[i], false, r.name.str()});
+            reads2.push_back({lo_rec + i, 0, lengths[i], false, name});
             r2_mean.push_back(mean_q[i]); r2_window.push_back(window_q[i]); r2_len.push_back(lengths[i]); r2_pass.push_back(passed[i]);
         } else {
             for (uint64_t k = a; k < b; ++k) {
                 const int s0 = c_ranges[2 * k], e0 = c_ranges[2 * k + 1];
-                reads2.push_back({lo_rec + i, s0, e0, true, r.name.str() + "_" + std::to_string(s0 + 1) + "-" + std::to_string(e0)});  // read.cpp:135-136
+                reads2.push_back({lo_rec + i, s0, e0, true, name + "_" + std::to_string(s0 + 1) + "-" + std::to_string(e0)});  // read.cpp:135-136
                 r2_mean.push_back(c_mean[k]); r2_window.push_back(c_window[k]); r2_len.push_back(e0 - s0); r2_pass.push_back(c_passed[k]);
             }
         }
@@ -910,8 +1056,8 @@ int main(int argc, char **argv) {
 
     if (args.verbose) {  // Read::print_verbose_read_info, src/read.cpp:169-194, in file order like the pass-1 loop (main.cpp:110-111)
         for (uint64_t i = 0; i < n; ++i) {
-            const Record &r = recs[lo_rec + i];
-            std::cerr << "\n" << r.name << "\n";
+            const std::string_view rname = names[i];
+            std::cerr << "\n" << rname << "\n";
             std::cerr << "            length = " << pad(std::to_string(lengths[i]), 11) << "mean quality = " << double_to_string(mean_q[i])
                       << "      window quality = " << double_to_string(window_q[i]) << "\n";
             const uint64_t a = child_off[i], b = child_off[i + 1];
@@ -939,7 +1085,7 @@ int main(int argc, char **argv) {
                 for (uint64_t k = a; k < b; ++k) std::cerr << c_ranges[2 * k] << "-" << c_ranges[2 * k + 1] << (k + 1 < b ? ", " : "");
                 std::cerr << "\n";
                 for (uint64_t k = a; k < b; ++k) {
-                    std::cerr << "\n" << r.name << "_" << c_ranges[2 * k] + 1 << "-" << c_ranges[2 * k + 1] << "\n";
+                    std::cerr << "\n" << rname << "_" << c_ranges[2 * k] + 1 << "-" << c_ranges[2 * k + 1] << "\n";
                     std::cerr << "            length = " << pad(std::to_string(c_ranges[2 * k + 1] - c_ranges[2 * k]), 11) << "mean quality = "
                               << double_to_string(c_mean[k]) << "      window quality = " << double_to_string(c_window[k]) << "\n";
                 }
@@ -1034,11 +1180,10 @@ int main(int argc, char **argv) {
     }
     std::string out;
     out.reserve(1 << 24);
-    for (uint64_t i = 0; i < n2; ++i) {
-        if (!r2_pass[i]) continue;
+    auto emit = [&](uint64_t i, const Record &r) {  // output read i of reads2, cut out of its record
+        if (!r2_pass[i]) return;
         const Out &o = reads2[i];
-        const Record &r = recs[o.rec];
-        if (o.child && o.end - o.start <= 0) continue;
+        if (o.child && o.end - o.start <= 0) return;
         out += fasta_output ? '>' : '@';
         out += o.name;
         if (!r.comment.empty()) { out += ' '; out.append(r.comment.p, r.comment.n); }
@@ -1051,6 +1196,26 @@ int main(int argc, char **argv) {
             out += '\n';
         }
         if (out.size() > (1u << 24)) { fwrite(out.data(), 1, out.size(), sink); out.clear(); }
+    };
+    if (!streamed) {
+        for (uint64_t i = 0; i < n2; ++i) emit(i, kept.recs[reads2[i].rec]);
+    } else {
+        // second pass over the compressed input (src/main.cpp:263-313 re-reads the file too); reads2 is in record order
+        BlockReader again;
+        if (!again.open(args.input_reads)) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
+        Parsed batch;
+        uint64_t rec = 0, cur = 0;
+        while (cur < n2 && again.next(batch)) {
+            for (const Record &r : batch.recs) {
+                if (rec >= n || r.name.sv() != names[rec] || (int32_t)r.seq.size() != lengths[rec]) {
+                    std::cerr << "Error: " << args.input_reads << " changed while it was being filtered\n";
+                    return 1;
+                }
+                for (; cur < n2 && reads2[cur].rec == rec; ++cur) emit(cur, r);
+                ++rec;
+            }
+        }
+        if (again.io_error || cur < n2) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
     }
     fwrite(out.data(), 1, out.size(), sink);
     fflush(sink);

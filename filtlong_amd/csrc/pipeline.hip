@@ -238,6 +238,35 @@ extern "C" int flx_pipeline_create(flx_ctx *ctx, const flx_kmerset *set, const f
     return FLX_OK;
 }
 
+extern "C" int flx_pipeline_reserve(flx_pipeline *p, uint64_t chunk_plane_bytes, uint64_t chunk_reads) {
+    if (!p) return FLX_ERR_INVALID;
+    flx_ctx *ctx = p->ctx;
+    if (p->handed_out) return flx_fail(ctx, FLX_ERR_STATE, "flx_pipeline_reserve between flx_pipeline_next_buffer and flx_pipeline_submit");
+    const uint64_t want_bytes = std::max<uint64_t>(p->cap_bytes, (chunk_plane_bytes + 4095) & ~4095ull);
+    const uint64_t want_reads = std::max<uint64_t>(p->cap_reads, chunk_reads);
+    if (want_reads > 0xffffffffull) return flx_fail(ctx, FLX_ERR_INVALID, "chunk of %llu reads", (unsigned long long)want_reads);
+    if (want_bytes == p->cap_bytes && want_reads == p->cap_reads) return FLX_OK;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv.wait(lk, [&] { return p->queue.empty(); });  // both slots idle: the worker has appended their results
+        if (p->error != FLX_OK) {
+            ctx->err = p->error_msg;
+            return p->error;
+        }
+    }
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FLX_HIP(ctx, hipStreamSynchronize(p->copy_stream));
+    for (int k = 0; k < 2; ++k) free_slot(p->slot[k]);
+    p->cap_bytes = want_bytes;
+    p->cap_reads = want_reads;
+    for (int k = 0; k < 2; ++k) {
+        const int rc = alloc_slot(p, p->slot[k]);
+        if (rc != FLX_OK) return rc;
+    }
+    return FLX_OK;
+}
+
 extern "C" int flx_pipeline_next_buffer(flx_pipeline *p, uint8_t **plane, uint64_t *capacity_bytes, uint64_t *capacity_reads) {
     if (!p || !plane) return FLX_ERR_INVALID;
     std::unique_lock<std::mutex> lk(p->mu);

@@ -219,6 +219,9 @@ typedef struct flx_pipeline flx_pipeline;
 int flx_pipeline_create(flx_ctx *ctx, const flx_kmerset *set /* NULL or empty: Phred mode */, const flx_params *params,
                         uint64_t chunk_plane_bytes, uint64_t chunk_reads, flx_pipeline **out);
 int flx_pipeline_next_buffer(flx_pipeline *p, uint8_t **plane, uint64_t *capacity_bytes, uint64_t *capacity_reads);
+/* Grow both slots to at least this capacity (never shrinks; waits for the chunks in flight first).  For callers that learn
+ * the longest read only while streaming.  Not between next_buffer and submit. */
+int flx_pipeline_reserve(flx_pipeline *p, uint64_t chunk_plane_bytes, uint64_t chunk_reads);
 int flx_pipeline_submit(flx_pipeline *p, uint64_t plane_bytes, const uint64_t *offsets, const int32_t *lengths, uint64_t n_reads);
 int flx_pipeline_finish(flx_pipeline *p, flx_scores *all, uint64_t *n_reads);
 void flx_pipeline_destroy(flx_pipeline *p);

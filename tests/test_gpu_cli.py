@@ -33,6 +33,9 @@ MODES = {
     "default": {},
     # streaming ingest forced into many small chunks (two pinned slots, worker thread): same bytes out
     "chunked": {"FLX_CLI_CHUNK_BYTES": "20000"},
+    # the gzip path: input read block by block (tail carried over, blocks and pipeline slots grown for long records),
+    # nothing of the input kept but names and lengths, second pass over the file for the output
+    "blocks": {"FLX_CLI_FORCE_STREAM": "1", "FLX_CLI_BLOCK_BYTES": "6000"},
     # the one-process-per-GPU path with a single rank: RCCL communicator, flx_rank_and_cut_comm, part files
     "rank-env": {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "FLX_COMM_ID_FILE": "/tmp/flx_test_comm.id"},
 }
@@ -104,6 +107,10 @@ def test_cli_fasta_input_and_gz(tmp_path):
     gz.write_bytes(gzip.compress(open(os.path.join(FIX, "test_sort.fastq"), "rb").read()))
     rc, out, keep, err = run(["--target_bases", "5000", str(gz)], str(tmp_path))
     assert rc == 0 and out.startswith(b"@test_sort_2")
+    # gzip input is streamed block by block by default; the in-memory path must give the same bytes
+    rc2, out2, keep2, err2 = run(["--target_bases", "5000", str(gz)], str(tmp_path), {"FLX_CLI_NO_STREAM": "1"})
+    rc3, out3, keep3, err3 = run(["--target_bases", "5000", str(gz)], str(tmp_path), {"FLX_CLI_BLOCK_BYTES": "700"})
+    assert (rc2, out2, keep2) == (rc, out, keep) and (rc3, out3, keep3) == (rc, out, keep)
 
 
 def test_cli_verbose_scores(tmp_path):
@@ -114,14 +121,15 @@ def test_cli_verbose_scores(tmp_path):
     assert [rows["test_sort_%d" % i][4].strip() for i in (1, 2, 3)] == ["0.00", "70.70", "61.54"]
 
 
-def test_cli_verbose_matches_reference_stderr(tmp_path):
+@pytest.mark.parametrize("mode", ["default", "blocks"])
+def test_cli_verbose_matches_reference_stderr(tmp_path, mode):
     """--verbose stderr, character for character after the hashing section (tests/golden/verbose.json, written by
     make_verbose_golden.py from the reference binary): per-read blocks with `bad ranges` / `child ranges`
     (src/read.cpp:169-194), the blank line after them (main.cpp:129), the score table with host-libm final scores."""
     gold = json.load(open(os.path.join(_cases.GOLDEN, "verbose.json")))
     for key, g in sorted(gold.items()):
         args = [os.path.join(FIX, "test_reference.fasta") if a == "REF" else a for a in g["args"]]
-        rc, out, keep, err = run(args + [os.path.join(FIX, g["input"])], str(tmp_path))
+        rc, out, keep, err = run(args + [os.path.join(FIX, g["input"])], str(tmp_path), MODES[mode])
         assert rc == g["rc"], (key, err)
         cut = err.find("16-mers\n\n")
         got = err[cut + len("16-mers\n\n"):] if cut >= 0 else err

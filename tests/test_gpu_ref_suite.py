@@ -27,10 +27,13 @@ def shown(err, fixdir):
     return [l.replace(fixdir + "/", "FIXDIR/") for l in lines]
 
 
-def test_every_invocation_of_the_reference_suite(tmp_path):
+@pytest.mark.parametrize("ingest", ["default", "blocks"])
+def test_every_invocation_of_the_reference_suite(tmp_path, ingest):
     gold = json.load(open(os.path.join(_cases.GOLDEN, "ref_suite.json")))
     assert gold["n_tests"] == 93 and len(gold["invocations"]) == 100
     env = dict(os.environ, LANG="C", LC_ALL="C")
+    if ingest == "blocks":  # every input through the block-wise reader of the gzip path, in blocks of a few records
+        env.update(FLX_CLI_FORCE_STREAM="1", FLX_CLI_BLOCK_BYTES="30000")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     # the recorded stderr holds the generator's fixture directory; find it from a recorded hashing line
