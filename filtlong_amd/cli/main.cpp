@@ -16,6 +16,9 @@
 #include <cmath>
 #include <deque>
 #include <string_view>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -39,6 +42,7 @@
 #include <unistd.h>
 
 #include "../../include/filtlong_hip.h"
+#include "inflate_stream.h"
 
 #define PROGRAM_VERSION "0.3.1"
 
@@ -556,62 +560,103 @@ static bool parse_all(const Input &d, Parsed &out) {  // true: the concurrent pa
 // inside it with the same Parser; the unfinished tail moves to the front of the next block.  A record is complete when the
 // parser stopped BEFORE the end of the buffer: it then never saw the end, so more data behind it cannot change the record.
 // Views of a batch are valid until the next call.  A record larger than the block doubles the buffer.
+struct MappedFile {  // read-only mapping of a regular file (the compressed input)
+    const unsigned char *p = nullptr;
+    size_t n = 0;
+    MappedFile() = default;
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+    ~MappedFile() { if (p) munmap((void *)p, n); }
+    bool open(const std::string &path) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) { ::close(fd); return false; }
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) return false;
+        p = (const unsigned char *)m;
+        n = (size_t)st.st_size;
+        madvise(m, n, MADV_SEQUENTIAL);
+        return true;
+    }
+    bool gz() const { return n >= 2 && p[0] == 0x1f && p[1] == 0x8b; }
+};
+
 struct BlockReader {
-    gzFile fp = nullptr;
+    static constexpr size_t kHistory = 32768;  // output kept in front of the write position: the window of an access point
+    MappedFile file;
+    InflateStream z;
     std::vector<char> buf;
-    size_t have = 0, carry_from = 0;
-    bool eof = false, done = false, io_error = false;
+    size_t have = 0;        // valid bytes in buf
+    size_t view_from = 0;   // the parse window is [view_from, have); bytes before it are history
+    size_t carry_from = 0;  // where the next window starts (set by next())
+    uint64_t buf_offset = 0;  // uncompressed offset of buf[0]
+    bool done = false, io_error = false;
+    std::vector<GzPoint> points;  // access points for a concurrent second pass (the first is the beginning of the file)
+    uint64_t span = 0;
     BlockReader() = default;
     BlockReader(const BlockReader &) = delete;
     BlockReader &operator=(const BlockReader &) = delete;
-    ~BlockReader() { if (fp) gzclose(fp); }
     static size_t block_bytes() {
         if (const char *e = getenv("FLX_CLI_BLOCK_BYTES")) return std::max<size_t>(64, (size_t)atoll(e));  // tests force tiny blocks
         if (const char *e = getenv("FLX_CLI_BLOCK_MB")) return std::max<size_t>(1, (size_t)atoll(e)) << 20;
         return (size_t)256 << 20;
     }
-    bool open(const std::string &path) {
-        fp = gzopen(path.c_str(), "r");  // transparent for uncompressed data too
-        if (!fp) return false;
-        gzbuffer(fp, 1 << 20);
-        buf.resize(block_bytes());
+    static uint64_t point_span() {  // uncompressed bytes between access points = the work unit of the output pass
+        if (const char *e = getenv("FLX_CLI_SPAN_BYTES")) return std::max<uint64_t>(1, (uint64_t)atoll(e));
+        return (uint64_t)32 << 20;
+    }
+    bool open(const std::string &path, bool want_points) {
+        if (!file.open(path) || !z.open(file.p, file.n, file.gz())) return false;
+        buf.resize(block_bytes() + kHistory);
+        span = want_points ? point_span() : 0;
+        points.clear();
+        if (want_points) points.emplace_back();
         return true;
     }
+    // uncompressed offset of a byte of the current batch
+    uint64_t offset_of(const char *p) const { return buf_offset + (uint64_t)(p - buf.data()); }
+    uint64_t end_offset() const { return buf_offset + have; }
     bool next(Parsed &out) {  // false: nothing left (or io_error)
         out = Parsed();
         if (done) return false;
-        if (carry_from > 0) {
-            if (carry_from < have) memmove(buf.data(), buf.data() + carry_from, have - carry_from);
-            have -= carry_from;
+        if (carry_from > 0) {  // drop what has been parsed, keep the history in front of the unfinished tail
+            const size_t drop = carry_from > kHistory ? carry_from - kHistory : 0;
+            if (drop > 0) {
+                memmove(buf.data(), buf.data() + drop, have - drop);
+                have -= drop;
+                buf_offset += drop;
+            }
+            view_from = carry_from - drop;
             carry_from = 0;
         }
         for (;;) {
-            while (!eof && have < buf.size()) {
-                const int got = gzread(fp, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, 1u << 30));
-                if (got < 0) { io_error = true; done = true; return false; }
-                if (got == 0) eof = true;
-                else have += (size_t)got;
+            if (!z.eof() && have < buf.size()) {
+                have += z.read(buf.data() + have, buf.size() - have, span ? &points : nullptr, span);
+                if (z.error()) { io_error = true; done = true; return false; }
             }
-            view.p = buf.data();
-            view.n = have;
+            const bool eof = z.eof();
+            view.p = buf.data() + view_from;
+            view.n = have - view_from;
             out.arenas.emplace_back();
             Parser ps(view, out.arenas.back());
             Record r;
-            size_t consumed = have;
+            size_t consumed = view.n;
             for (;;) {
                 const size_t header = ps.peek_header();
                 const long long len = ps.next(r);
-                if (!eof && ps.pos >= have) { consumed = std::min(header, have); break; }  // ran into the end of the block: unfinished
+                if (!eof && ps.pos >= view.n) { consumed = std::min(header, view.n); break; }  // ran into the end of the block: unfinished
                 if (len == -1) break;
                 if (len == -2) { out.status = -2; out.bad = r; done = true; break; }
                 out.recs.push_back(r);
             }
             if (out.recs.empty() && !done && !eof && consumed == 0) {  // one record fills the whole block
-                buf.resize(buf.size() * 2);
+                buf.resize((buf.size() - kHistory) * 2 + kHistory);
                 out = Parsed();
                 continue;
             }
-            carry_from = consumed;
+            carry_from = view_from + consumed;
             if (eof) done = true;
             return true;
         }
@@ -620,6 +665,40 @@ struct BlockReader {
 private:
     Input view;  // non-owning window on buf
 };
+
+// The work units of the output pass over a streamed input: unit j is the text from the first record that starts at or
+// after access point j up to the first record of unit j + 1, so every unit is a whole number of records and can be
+// inflated (from its point) and parsed on its own.
+struct UnitIndex {
+    std::vector<uint64_t> start, first_rec;  // per access point, plus one closing entry (total size, record count)
+    void note_record(const std::vector<GzPoint> &points, uint64_t header_offset, uint64_t rec) {
+        while (start.size() < points.size() && points[start.size()].out <= header_offset) {
+            start.push_back(header_offset);
+            first_rec.push_back(rec);
+        }
+    }
+    void finish(const std::vector<GzPoint> &points, uint64_t total_bytes, uint64_t n_records) {
+        while (start.size() < points.size() + 1) {
+            start.push_back(total_bytes);
+            first_rec.push_back(n_records);
+        }
+    }
+    size_t units() const { return start.empty() ? 0 : start.size() - 1; }
+};
+
+// bytes [from, to) of the uncompressed stream, inflated from an access point at or before `from`
+static bool inflate_range(const MappedFile &file, const GzPoint &pt, uint64_t from, uint64_t to, std::vector<char> &text) {
+    InflateStream z;
+    if (pt.out > from || !z.open_at(file.p, file.n, file.gz(), pt)) return false;
+    std::vector<char> skip(std::min<uint64_t>(from - pt.out, 1u << 20));
+    for (uint64_t left = from - pt.out; left > 0;) {
+        const size_t got = z.read(skip.data(), (size_t)std::min<uint64_t>(left, skip.size()));
+        if (got == 0) return false;
+        left -= got;
+    }
+    text.resize((size_t)(to - from));
+    return z.read(text.data(), text.size()) == text.size() && !z.error();
+}
 
 // FLX_CLI_PARSE_ONLY=seq|par|blk: parse the input, print a digest of every field and exit (no GPU needed).  The CPU tests
 // compare the sequential parser with the concurrent one and with the block-wise reader on generated odd files.
@@ -635,11 +714,40 @@ static int parse_only(const std::string &path, const char *mode) {
     Parsed parsed;
     bool par = false;
     size_t n_records = 0;
-    if (mode[0] == 'b') {  // blocks: the streaming reader, FLX_CLI_BLOCK_BYTES per block
+    if (mode[0] == 'b' || mode[0] == 'u') {  // blocks: the streaming reader, FLX_CLI_BLOCK_BYTES per block
         BlockReader rd;
-        if (!rd.open(path)) { std::cerr << "Error reading " << path << "\n"; return 1; }
-        while (rd.next(parsed)) { mix_all(parsed); n_records += parsed.recs.size(); if (parsed.status == -2) break; }
+        if (!rd.open(path, true)) { std::cerr << "Error reading " << path << "\n"; return 1; }
+        UnitIndex idx;
+        const uint64_t h_blocks_start = h;
+        while (rd.next(parsed)) {
+            mix_all(parsed);
+            for (const Record &r : parsed.recs) idx.note_record(rd.points, rd.offset_of(r.name.p - 1), n_records++);
+            if (parsed.status == -2) break;
+        }
         if (rd.io_error) { std::cerr << "Error reading " << path << "\n"; return 1; }
+        if (mode[0] == 'u' && parsed.status != -2) {
+            // units: every piece between two access points (FLX_CLI_SPAN_BYTES apart) inflated and parsed on its own, on
+            // several threads, as the output pass does; digest of the pieces in order
+            idx.finish(rd.points, rd.end_offset(), n_records);
+            std::vector<Parsed> got(idx.units());
+            std::vector<std::vector<char>> texts(idx.units());
+            std::vector<int> ok(idx.units(), 1);
+            parallel_for(idx.units(), [&](size_t j) {
+                if (idx.start[j + 1] == idx.start[j]) return;
+                if (!inflate_range(rd.file, rd.points[j], idx.start[j], idx.start[j + 1], texts[j])) { ok[j] = 0; return; }
+                Input view;
+                view.p = texts[j].data();
+                view.n = texts[j].size();
+                parse_sequential(view, got[j]);
+                if (got[j].recs.size() != idx.first_rec[j + 1] - idx.first_rec[j]) ok[j] = 0;
+            });
+            h = h_blocks_start;
+            for (size_t j = 0; j < idx.units(); ++j) {
+                if (!ok[j]) { std::cerr << "unit " << j << " failed\n"; return 1; }
+                mix_all(got[j]);
+            }
+            std::cerr << "units " << idx.units() << " points " << rd.points.size() << "\n";
+        }
         std::cout << "records " << n_records << " status " << parsed.status << " bad " << parsed.bad.name << " parallel 0 digest " << h << "\n";
         return 0;
     }
@@ -866,7 +974,7 @@ int main(int argc, char **argv) {
         ::close(fd);
         streamed = regular && world == 1 && !getenv("FLX_CLI_NO_STREAM") && (gz || getenv("FLX_CLI_FORCE_STREAM"));
     }
-    if (streamed ? !blocks.open(args.input_reads) : !data.open(args.input_reads)) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
+    if (streamed ? !blocks.open(args.input_reads, true) : !data.open(args.input_reads)) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
     stage("read input file");
 
     flx_params prm;
@@ -891,7 +999,12 @@ int main(int argc, char **argv) {
     bool any_fasta = false, any_fastq = false;
     std::unordered_set<std::string_view> seen_names;
     uint64_t n_records = 0, n_chunks = 0, n_batches = 0;
+    UnitIndex units;                      // streamed input: the record-aligned pieces the output pass inflates concurrently
     flx_pipeline *pipe = nullptr;
+    struct PipeGuard {  // an error return must not leave the worker thread running into the runtime's teardown
+        flx_pipeline *&p;
+        ~PipeGuard() { if (p) { flx_pipeline_destroy(p); p = nullptr; } }
+    } pipe_guard{pipe};
     std::vector<uint64_t> offsets;
 
     // Pack records [lo, lo + cnt) of a batch chunk by chunk into the pipeline's pinned staging buffers (two slots: the GPU
@@ -994,7 +1107,10 @@ int main(int argc, char **argv) {
                 name = name_arena.back();
             }
             if (!seen_names.insert(name).second) { std::cerr << "Error: duplicate read name: " << r.name << "\n"; return 1; }
-            if (streamed) names.push_back(name);
+            if (streamed) {
+                names.push_back(name);
+                units.note_record(blocks.points, blocks.offset_of(r.name.p - 1), n_records);
+            }
             ++n_records;
             if (total_bases - last_progress >= 483611) {
                 last_progress = total_bases;
@@ -1016,6 +1132,7 @@ int main(int argc, char **argv) {
         if (const int rc = score_records(recs, lo, cnt)) return rc;
     }
     { std::unordered_set<std::string_view>().swap(seen_names); }
+    if (streamed) units.finish(blocks.points, blocks.end_offset(), n_records);
     if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)n_records) << " reads (" << int_to_string(total_bases) << " bp)";
     if (!args.verbose) std::cerr << "\n";  // verbose: after the per-read blocks, as in main.cpp:110-129
     const bool fasta_output = any_fasta, fastq_output = any_fastq;
@@ -1178,9 +1295,7 @@ int main(int argc, char **argv) {
         sink = fopen(part_path.c_str(), "wb");
         if (!sink) { std::cerr << "Error: cannot write " << part_path << "\n"; return 1; }
     }
-    std::string out;
-    out.reserve(1 << 24);
-    auto emit = [&](uint64_t i, const Record &r) {  // output read i of reads2, cut out of its record
+    auto emit = [&](std::string &out, uint64_t i, const Record &r) {  // output read i of reads2, cut out of its record
         if (!r2_pass[i]) return;
         const Out &o = reads2[i];
         if (o.child && o.end - o.start <= 0) return;
@@ -1195,27 +1310,90 @@ int main(int argc, char **argv) {
             out.append(r.qual.p + o.start, (size_t)(o.end - o.start));
             out += '\n';
         }
-        if (out.size() > (1u << 24)) { fwrite(out.data(), 1, out.size(), sink); out.clear(); }
     };
+    std::string out;
     if (!streamed) {
-        for (uint64_t i = 0; i < n2; ++i) emit(i, kept.recs[reads2[i].rec]);
+        out.reserve(1 << 24);
+        for (uint64_t i = 0; i < n2; ++i) {
+            emit(out, i, kept.recs[reads2[i].rec]);
+            if (out.size() > (1u << 24)) { fwrite(out.data(), 1, out.size(), sink); out.clear(); }
+        }
     } else {
-        // second pass over the compressed input (src/main.cpp:263-313 re-reads the file too); reads2 is in record order
-        BlockReader again;
-        if (!again.open(args.input_reads)) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
-        Parsed batch;
-        uint64_t rec = 0, cur = 0;
-        while (cur < n2 && again.next(batch)) {
-            for (const Record &r : batch.recs) {
-                if (rec >= n || r.name.sv() != names[rec] || (int32_t)r.seq.size() != lengths[rec]) {
-                    std::cerr << "Error: " << args.input_reads << " changed while it was being filtered\n";
-                    return 1;
-                }
-                for (; cur < n2 && reads2[cur].rec == rec; ++cur) emit(cur, r);
-                ++rec;
+        // Second pass over the compressed input (src/main.cpp:263-313 re-reads the file too), but not front to back on one
+        // thread: pass 1 left access points in the deflate stream, the pieces between them (whole records, ~32 MiB of text)
+        // are inflated and parsed concurrently and written in order.  Pieces without a passing read are not inflated at all.
+        const size_t n_units = units.units();
+        std::vector<uint64_t> r2_at(n_units + 1, n2);  // first reads2 entry of every unit (reads2 is in record order)
+        {
+            uint64_t cur = 0;
+            for (size_t j = 0; j < n_units; ++j) {
+                while (cur < n2 && reads2[cur].rec < units.first_rec[j]) ++cur;
+                r2_at[j] = cur;
             }
         }
-        if (again.io_error || cur < n2) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
+        std::vector<std::string> piece(n_units);
+        std::vector<char> state(n_units, 0);  // 1: ready, 2: failed
+        std::mutex mu;
+        std::condition_variable cv;
+        std::atomic<size_t> next_unit{0};
+        size_t written = 0;
+        const unsigned n_workers = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads(), n_units));
+        const size_t ahead = 2 * (size_t)n_workers;  // bounds the text in flight
+        auto worker = [&] {
+            std::vector<char> text;
+            for (;;) {
+                const size_t j = next_unit.fetch_add(1);
+                if (j >= n_units) return;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return j < written + ahead; });
+                }
+                bool ok = true, any = false;
+                for (uint64_t i = r2_at[j]; i < r2_at[j + 1] && !any; ++i) any = r2_pass[i] != 0;
+                if (any) {
+                    Parsed got;
+                    ok = inflate_range(blocks.file, blocks.points[j], units.start[j], units.start[j + 1], text);
+                    if (ok) {
+                        Input view;
+                        view.p = text.data();
+                        view.n = text.size();
+                        parse_sequential(view, got);
+                        ok = got.recs.size() == units.first_rec[j + 1] - units.first_rec[j];
+                    }
+                    uint64_t cur = r2_at[j];
+                    for (size_t k = 0; ok && k < got.recs.size(); ++k) {
+                        const uint64_t rec = units.first_rec[j] + k;
+                        const Record &r = got.recs[k];
+                        if (r.name.sv() != names[rec] || (int32_t)r.seq.size() != lengths[rec]) { ok = false; break; }
+                        for (; cur < r2_at[j + 1] && reads2[cur].rec == rec; ++cur) emit(piece[j], cur, r);
+                    }
+                }
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    state[j] = ok ? 1 : 2;
+                }
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_workers; ++t) pool.emplace_back(worker);
+        bool failed = false;
+        for (size_t j = 0; j < n_units; ++j) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return state[j] != 0; });
+                failed = failed || state[j] == 2;
+            }
+            if (!failed) fwrite(piece[j].data(), 1, piece[j].size(), sink);
+            std::string().swap(piece[j]);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                written = j + 1;
+            }
+            cv.notify_all();
+        }
+        for (auto &t : pool) t.join();
+        if (failed) { std::cerr << "Error: " << args.input_reads << " could not be read a second time (did it change?)\n"; return 1; }
     }
     fwrite(out.data(), 1, out.size(), sink);
     fflush(sink);
@@ -1240,6 +1418,7 @@ int main(int argc, char **argv) {
     stage("output");
 
     flx_pipeline_destroy(pipe);
+    pipe = nullptr;
     if (kmers) flx_kmerset_destroy(kmers);
     flx_ctx_destroy(ctx);
     int status = 0;

@@ -13,10 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "filtlong_amd", "bin", "filtlong")
 
 
-def digest(path, mode, threads=4, block=None):
+def digest(path, mode, threads=4, block=None, span=None):
     env = dict(os.environ, FLX_CLI_PARSE_ONLY=mode, FLX_CLI_PARALLEL_PARSE_MIN="1", FLX_CLI_THREADS=str(threads), LANG="C", LC_ALL="C")
     if block:
         env["FLX_CLI_BLOCK_BYTES"] = str(block)
+    if span:
+        env["FLX_CLI_SPAN_BYTES"] = str(span)
     p = subprocess.run([BIN, "--target_bases", "1", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
     assert p.returncode == 0, p.stderr.decode()
     out = p.stdout.decode().strip()
@@ -146,3 +148,52 @@ def test_blockwise_parse_fasta_and_fixtures(tmp_path):
         for block in (333, 1 << 15):
             blk, _ = digest(path, "blk", block=block)
             assert seq == blk, (name, block)
+
+
+@pytest.mark.parametrize("style", ["plain", "crlf", "multiline", "blank", "mixedlen"])
+@pytest.mark.parametrize("span", [1, 300, 5000, 70000])
+def test_access_point_units_equal_sequential(tmp_path, style, span):
+    """The output pass over gzip input: pass 1 leaves access points in the deflate stream (zran-style: bit position + 32 KiB
+    window at block boundaries `span` output bytes apart); every piece between two points, cut at record starts, inflated
+    from its point and parsed on its own must give exactly the records of the sequential parse.  Also for files of several
+    concatenated gzip members, for stored (level 0) blocks and for uncompressed input."""
+    import gzip
+    import zlib
+    rng = np.random.RandomState(hash((style, span)) % 2 ** 31)
+    data = random_fastq(rng, 400, style)
+    plain = str(tmp_path / "in.fastq")
+    open(plain, "wb").write(data)
+    seq, _ = digest(plain, "seq")
+    variants = {
+        "plain": data,
+        "gz6": gzip.compress(data, 6),
+        "gz1": gzip.compress(data, 1),
+        "gz0": gzip.compress(data, 0),
+        "members": b"".join(gzip.compress(data[a:b], 5) for a, b in zip([0, 1000, 1001, len(data) // 2],
+                                                                        [1000, 1001, len(data) // 2, len(data)])),
+    }
+    # many small deflate blocks: a full flush every few hundred bytes
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    parts = []
+    for at in range(0, len(data), 777):
+        parts.append(co.compress(data[at:at + 777]))
+        parts.append(co.flush(zlib.Z_FULL_FLUSH if (at // 777) % 2 else zlib.Z_SYNC_FLUSH))
+    parts.append(co.flush())
+    variants["flushed"] = b"".join(parts)
+    for name, blob in variants.items():
+        path = str(tmp_path / ("v_" + name))
+        open(path, "wb").write(blob)
+        for block in (4096, 1 << 20):
+            got, _ = digest(path, "unit", threads=5, block=block, span=span)
+            assert got == seq, (style, span, name, block)
+
+
+def test_access_point_units_on_fixture_gz():
+    for name in sorted(os.listdir(_cases.FIXTURES)):
+        if not name.endswith(".gz"):
+            continue
+        path = os.path.join(_cases.FIXTURES, name)
+        seq, _ = digest(path, "seq")
+        for span in (10000, 1 << 20):
+            got, _ = digest(path, "unit", threads=8, block=1 << 16, span=span)
+            assert got == seq, (name, span)

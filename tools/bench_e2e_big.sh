@@ -20,7 +20,7 @@ for rep in 1 2; do
   AMD_S=$(python -c "print(($E - $S) / 1e9)")
   echo "filtlong-amd run $rep: $AMD_S s"
 done
-grep "timing" /tmp/amd.err
+tr '\r' '\n' < /tmp/amd.err | grep timing
 S=$(date +%s%N)
 $R/oracle/_ref/filtlong --target_bases $TARGET /tmp/big.fastq > /tmp/ref.out 2> /tmp/ref.err
 E=$(date +%s%N)
@@ -29,7 +29,7 @@ echo "reference: $REF_S s"
 if cmp /tmp/ref.out /tmp/amd.out; then IDENT=true; echo "stdout identical ($(stat -c %s /tmp/amd.out) bytes)"; else IDENT=false; echo "STDOUT DIFFERS"; fi
 grep -E "target|keeping" /tmp/ref.err /tmp/amd.err
 } > $OUT/r02_e2e_big.log 2>&1
-ANON=$(grep timing /tmp/amd.err | sed -E 's/.*RssAnon +([0-9]+) MiB.*/\1/' | sort -n | tail -1)
+ANON=$(tr '\r' '\n' < /tmp/amd.err | grep timing | sed -E 's/.*RssAnon +([0-9]+) MiB.*/\1/' | sort -n | tail -1)
 python - <<PY
 import json
 amd, ref = float("$AMD_S"), float("$REF_S")
