@@ -549,6 +549,15 @@ def main():
                     "pcie": "the streamed ingest moves 1 byte per base host -> device in pinned 1 GiB chunks (two slots); at the "
                             "measured %.1f Gbases/s end to end the link carries %.1f GB/s of its ~55 GB/s: parse, pack and output "
                             "on the host bound the run, not PCIe or the GPU" % (e["e2e_gbases_per_s"], e["e2e_gbases_per_s"])}
+            gpath = os.path.join(ROOT, "profiles", "r02_e2e_gz.json")
+            if os.path.exists(gpath):
+                e = json.load(open(gpath))
+                extras["end_to_end_cli_gzip"] = {
+                    "source": "profiles/r02_e2e_gz.json (tools/bench_e2e_gz.sh on a GPU box; not measured in this run)",
+                    "fastq_bytes": e["fastq_bytes"], "gz_bytes": e["gz_bytes"], "bases": e["bases"],
+                    "seconds": round(e["filtlong_amd_streamed_s"], 2), "reference_seconds": round(e["reference_s"], 1),
+                    "stdout_identical_to_reference": e["stdout_identical"], "peak_rss_anon_mib": e["peak_rss_anon_mib_streamed"],
+                    "note": e["note"]}
             out["extras"] = extras
         print(json.dumps(out), flush=True)
     if multi:

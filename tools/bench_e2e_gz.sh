@@ -50,7 +50,7 @@ json.dump({"reads": $N, "bases": $BASES, "fastq_bytes": $RAW, "gz_bytes": $SIZE,
            "gzip_dc_alone_s": float("$INFLATE_S"), "filtlong_amd_streamed_s": amd, "filtlong_amd_in_memory_s": mem, "reference_s": ref,
            "speedup": ref / amd, "stdout_identical": "$IDENT" == "true",
            "peak_rss_anon_mib_streamed": int("$ANON" or 0), "peak_rss_anon_mib_in_memory": int("$ANON2" or 0),
-           "note": "both passes inflate the file with one zlib thread, as the reference does; that is the floor of this path"},
+           "note": "pass 1 inflates on one zlib thread (the floor of this path); the output pass inflates the record-aligned pieces between the access points pass 1 left, on up to 16 threads; the reference inflates the file twice on one thread"},
           open("$OUT/r02_e2e_gz.json", "w"), indent=1)
 PY
 tail -40 $OUT/r02_e2e_gz.log; cat $OUT/r02_e2e_gz.json
