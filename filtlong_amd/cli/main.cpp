@@ -1313,11 +1313,94 @@ int main(int argc, char **argv) {
     };
     std::string out;
     if (!streamed) {
-        out.reserve(1 << 24);
-        for (uint64_t i = 0; i < n2; ++i) {
-            emit(out, i, kept.recs[reads2[i].rec]);
-            if (out.size() > (1u << 24)) { fwrite(out.data(), 1, out.size(), sink); out.clear(); }
+        // The passed records are cut out of the mapped input by several threads, ~16 MiB of output per piece.  Every piece's
+        // place in the output is known beforehand, so when the sink is a regular file each thread writes its pieces itself
+        // (pwrite at the piece's offset); a pipe or terminal gets the pieces in order from this thread.
+        auto out_bytes = [&](uint64_t i) -> uint64_t {
+            if (!r2_pass[i]) return 0;
+            const Out &o = reads2[i];
+            if (o.child && o.end - o.start <= 0) return 0;
+            const Record &r = kept.recs[o.rec];
+            const uint64_t L = (uint64_t)(o.end - o.start);
+            return 1 + o.name.size() + (r.comment.empty() ? 0 : 1 + r.comment.n) + 1 + L + 1 + (fastq_output ? 2 + L + 1 : 0);
+        };
+        std::vector<uint64_t> piece_first{0}, piece_at{0};  // reads2 range and byte offset of every piece
+        {
+            uint64_t bytes = 0, in_piece = 0;
+            for (uint64_t i = 0; i < n2; ++i) {
+                const uint64_t b = out_bytes(i);
+                bytes += b;
+                in_piece += b;
+                if (in_piece >= (16u << 20) && i + 1 < n2) { piece_first.push_back(i + 1); piece_at.push_back(bytes); in_piece = 0; }
+            }
+            piece_first.push_back(n2);
+            piece_at.push_back(bytes);
         }
+        const size_t n_pieces = piece_first.size() - 1;
+        fflush(sink);
+        const int fd = fileno(sink);
+        struct stat st;
+        const int fl = fcntl(fd, F_GETFL);
+        const off_t base = lseek(fd, 0, SEEK_CUR);
+        const bool direct = !getenv("FLX_CLI_ORDERED_OUTPUT") && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 &&
+                            !(fl & O_APPEND) && base >= 0;
+        std::vector<std::string> piece(n_pieces);
+        std::vector<char> state(n_pieces, 0);  // 1: ready (or written), 2: write failed
+        std::mutex mu;
+        std::condition_variable cv;
+        std::atomic<size_t> next_piece{0};
+        size_t written = 0;
+        const unsigned n_workers = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads(), n_pieces));
+        const size_t ahead = 2 * (size_t)n_workers;
+        auto worker = [&] {
+            for (;;) {
+                const size_t j = next_piece.fetch_add(1);
+                if (j >= n_pieces) return;
+                if (!direct) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return j < written + ahead; });
+                }
+                std::string &buf = piece[j];
+                buf.reserve((size_t)(piece_at[j + 1] - piece_at[j]));
+                for (uint64_t i = piece_first[j]; i < piece_first[j + 1]; ++i) emit(buf, i, kept.recs[reads2[i].rec]);
+                bool ok = buf.size() == piece_at[j + 1] - piece_at[j];
+                if (direct) {
+                    for (size_t done = 0; ok && done < buf.size();) {
+                        const ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, base + (off_t)(piece_at[j] + done));
+                        if (w <= 0) ok = false;
+                        else done += (size_t)w;
+                    }
+                    std::string().swap(buf);
+                }
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    state[j] = ok ? 1 : 2;
+                }
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_workers; ++t) pool.emplace_back(worker);
+        bool failed = false;
+        for (size_t j = 0; j < n_pieces; ++j) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return state[j] != 0; });
+                failed = failed || state[j] == 2;
+            }
+            if (!direct) {
+                if (!failed) fwrite(piece[j].data(), 1, piece[j].size(), sink);
+                std::string().swap(piece[j]);
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    written = j + 1;
+                }
+                cv.notify_all();
+            }
+        }
+        for (auto &t : pool) t.join();
+        if (direct && !failed && lseek(fd, base + (off_t)piece_at[n_pieces], SEEK_SET) < 0) failed = true;
+        if (failed) { std::cerr << "Error: could not write the output\n"; return 1; }
     } else {
         // Second pass over the compressed input (src/main.cpp:263-313 re-reads the file too), but not front to back on one
         // thread: pass 1 left access points in the deflate stream, the pieces between them (whole records, ~32 MiB of text)

@@ -3,7 +3,8 @@
 // One process per GPU; every process holds one flx_ctx with one RCCL communicator.  The reference has no counterpart (it
 // is a single process, src/main.cpp:37-321); what is exchanged is what main.cpp:169-261 needs from ALL reads2 entries:
 //   * ONE all-gather of the mean qualities (the statistics of main.cpp:170-196 are order-dependent folds over all of
-//     them; 8 bytes per entry, ncclBroadcast per root inside one group = all-gather with unequal counts);
+//     them; 8 bytes per entry; ncclAllGather when every rank holds the same count, else ncclBroadcast per root inside one
+//     group = all-gather with unequal counts);
 //   * the 8 selection histograms (257 x u64) are ncclAllReduce'd on the device, on the context's stream, between the
 //     histogram kernel and the kernel that picks the next key byte — no host synchronisation per pass;
 //   * three small host-side sums (passed bases, band sizes, boundary-audit candidates);
@@ -28,6 +29,7 @@ struct RcclApi {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -52,6 +54,7 @@ int load_rccl(flx_ctx *ctx) {
     FLX_SYM(CommDestroy, "ncclCommDestroy")
     FLX_SYM(AllReduce, "ncclAllReduce")
     FLX_SYM(Broadcast, "ncclBroadcast")
+    FLX_SYM(AllGather, "ncclAllGather")
     FLX_SYM(GroupStart, "ncclGroupStart")
     FLX_SYM(GroupEnd, "ncclGroupEnd")
     FLX_SYM(GetErrorString, "ncclGetErrorString")
@@ -160,9 +163,16 @@ extern "C" int flx_comm_sum_u64(flx_ctx *ctx, uint64_t *buf, uint64_t count) {
 }
 
 // all-gather with per-rank counts: rank r's `elems[r]` elements of `esize` bytes land at offset sum(elems[0..r)) of recv.
-// One ncclBroadcast per root inside a group: the transfers of all roots run concurrently over xGMI.
+// Equal counts (a batch sharded evenly, the benchmark's case): ncclAllGather, RCCL's own multi-ring schedule over the
+// xGMI links.  Unequal counts (children, a remainder): one ncclBroadcast per root inside a group.
 static int allgather_v(flx_ctx *ctx, const void *d_send, void *d_recv, const std::vector<uint64_t> &elems, size_t esize) {
     flx_comm *c = ctx->comm;
+    bool equal = elems[0] > 0;
+    for (int r = 1; r < c->world; ++r) equal = equal && elems[r] == elems[0];
+    if (equal) {
+        FLX_NCCL(ctx, g_rccl.AllGather(d_send, d_recv, (size_t)elems[0] * esize, ncclUint8, c->comm, ctx->stream));
+        return FLX_OK;
+    }
     FLX_NCCL(ctx, g_rccl.GroupStart());
     uint64_t at = 0;
     for (int r = 0; r < c->world; ++r) {

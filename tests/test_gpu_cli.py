@@ -167,3 +167,35 @@ def test_cli_unit_suffixes(tmp_path):
     a = run(["--target_bases", "10k", fq], str(tmp_path))[1]
     b = run(["--target_bases", "10000", fq], str(tmp_path))[1]
     assert a == b and len(a) > 0
+
+
+def test_cli_output_sinks(tmp_path):
+    """The output pass writes a regular-file stdout with concurrent pwrite()s at precomputed offsets, a pipe or an
+    O_APPEND file in order: the same bytes every way (the reference writes through std::cout, src/main.cpp:263-313)."""
+    fq = tmp_path / "c1.fastq"
+    fq.write_bytes(_cases.c1_fastq_bytes())
+    args = [BIN, "--target_bases", "20000000", str(fq)]
+    env = dict(os.environ, LANG="C", LC_ALL="C")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    piped = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert piped.returncode == 0 and len(piped.stdout) > 30_000_000
+    f1 = tmp_path / "direct.out"
+    with open(f1, "wb") as fh:
+        assert subprocess.run(args, stdout=fh, stderr=subprocess.PIPE, env=env).returncode == 0
+    assert f1.read_bytes() == piped.stdout
+    f2 = tmp_path / "append.out"
+    f2.write_bytes(b"HEAD\n")
+    with open(f2, "ab") as fh:
+        assert subprocess.run(args, stdout=fh, stderr=subprocess.PIPE, env=env).returncode == 0
+    assert f2.read_bytes() == b"HEAD\n" + piped.stdout
+    f3 = tmp_path / "offset.out"   # a file descriptor that is not at offset 0 and whose file is longer than the output
+    f3.write_bytes(b"x" * 7 + b"y" * (len(piped.stdout) + 100))
+    with open(f3, "r+b") as fh:
+        fh.seek(7)
+        assert subprocess.run(args, stdout=fh, stderr=subprocess.PIPE, env=env).returncode == 0
+    got = f3.read_bytes()
+    assert got[:7] == b"x" * 7 and got[7:7 + len(piped.stdout)] == piped.stdout and got[7 + len(piped.stdout):] == b"y" * 100
+    with open(f1, "wb") as fh:
+        assert subprocess.run(args, stdout=fh, stderr=subprocess.PIPE, env=dict(env, FLX_CLI_ORDERED_OUTPUT="1")).returncode == 0
+    assert f1.read_bytes() == piped.stdout

@@ -14,6 +14,7 @@ TARGET=$((BASES / 2))
 echo "file /tmp/big.fastq: $N reads, $BASES bases, $SIZE bytes; --target_bases $TARGET; host cores $(nproc)"
 free -g | head -2
 for rep in 1 2; do
+  rm -f /tmp/amd.out; sync  # the shell would truncate the previous 10 GB output inside the timed window otherwise (1-2 s)
   S=$(date +%s%N)
   FLX_CLI_TIMING=1 $R/filtlong_amd/bin/filtlong --target_bases $TARGET /tmp/big.fastq > /tmp/amd.out 2> /tmp/amd.err
   E=$(date +%s%N)
@@ -21,6 +22,18 @@ for rep in 1 2; do
   echo "filtlong-amd run $rep: $AMD_S s"
 done
 tr '\r' '\n' < /tmp/amd.err | grep timing
+for T in 8 32 64; do
+  rm -f /tmp/amd_t.out
+  S=$(date +%s%N)
+  FLX_CLI_THREADS=$T FLX_CLI_TIMING=1 $R/filtlong_amd/bin/filtlong --target_bases $TARGET /tmp/big.fastq > /tmp/amd_t.out 2> /tmp/amd_t.err
+  E=$(date +%s%N)
+  echo "filtlong-amd with FLX_CLI_THREADS=$T: $(python -c "print(($E - $S) / 1e9)") s;$(tr '\r' '\n' < /tmp/amd_t.err | grep -E "pack|output" | sed -E 's/\[timing\] ([a-z +A-Z0-9()]+[a-z)]) +([0-9.]+) s.*/ \1 \2 s;/' | tr '\n' ' ')"
+done
+S=$(date +%s%N)
+FLX_CLI_TIMING=1 $R/filtlong_amd/bin/filtlong --target_bases $TARGET /tmp/big.fastq 2> /tmp/amd_t.err | cat > /tmp/amd_pipe.out
+E=$(date +%s%N)
+echo "filtlong-amd into a pipe (ordered writes): $(python -c "print(($E - $S) / 1e9)") s; identical: $(cmp /tmp/amd_pipe.out /tmp/amd.out && echo yes)"
+rm -f /tmp/amd_t.out /tmp/amd_pipe.out
 S=$(date +%s%N)
 $R/oracle/_ref/filtlong --target_bases $TARGET /tmp/big.fastq > /tmp/ref.out 2> /tmp/ref.err
 E=$(date +%s%N)

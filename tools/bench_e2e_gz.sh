@@ -20,6 +20,7 @@ S=$(date +%s%N); gzip -dc /tmp/gzin.fastq.gz > /dev/null; E=$(date +%s%N)
 INFLATE_S=$(t $S $E)
 echo "gzip -dc alone: $INFLATE_S s"
 for rep in 1 2; do
+  rm -f /tmp/amd.out
   S=$(date +%s%N)
   FLX_CLI_TIMING=1 $R/filtlong_amd/bin/filtlong --target_bases $TARGET /tmp/gzin.fastq.gz > /tmp/amd.out 2> /tmp/amd.err
   E=$(date +%s%N)
