@@ -256,7 +256,56 @@ __device__ __forceinline__ bool apply_map(double &S, int e, long long a0, long l
     return true;
 }
 
-// single wavefront: the exact fold.  Three levels: batches of 64 chunks -> chunks of 512 elements -> elements.
+// Ordered inclusive scan of maps over the lanes of a wavefront: lane l ends with m_0 o m_1 o ... o m_l (m_0 applied first).
+__device__ __forceinline__ Map2 wave_scan_maps(Map2 m, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        Map2 prev;
+        prev.a0 = __shfl_up(m.a0, o, 64);
+        prev.a1 = __shfl_up(m.a1, o, 64);
+        if (lane >= o) m = compose(prev, m);
+    }
+    return m;
+}
+
+__device__ __forceinline__ bool normal_positive(double S) {
+    const unsigned long long sb = (unsigned long long)__double_as_longlong(S);
+    const int eb = (int)((sb >> 52) & 0x7ff);
+    return (sb >> 63) == 0 && eb >= 1 && eb <= 2046;
+}
+
+// Advances S (positive, normal, in binade e) through the maps of lanes start, start + 1, ... for as long as they are usable
+// (a map for binade e with non-negative increments) and S stays in the binade, ALL AT ONCE: an ordered scan composes the
+// maps, every lane applies its prefix to the entering S, and the first lane whose prefix leaves the binade is found with a
+// ballot.  Increments are >= 0, so the mantissa only grows: a prefix that stays inside implies every shorter one does.
+// Returns the first lane that was NOT applied (64: all of them were).
+__device__ __forceinline__ int wave_apply_prefix(double &S, int e, Map2 m, bool usable, int start, int lane) {
+    const bool good = usable && m.a0 >= 0 && m.a1 >= 0;
+    const unsigned long long bad = __ballot(lane >= start && !good);
+    const int first_bad = bad ? (int)__ffsll((long long)bad) - 1 : 64;
+    if (lane < start || lane >= first_bad) m.a0 = m.a1 = 0;
+    const Map2 P = wave_scan_maps(m, lane);
+    const unsigned long long sb = (unsigned long long)__double_as_longlong(S);
+    const unsigned long long ms = (sb & 0x000fffffffffffffull) | (1ull << 52);
+    const unsigned long long m2 = ms + (unsigned long long)((ms & 1) ? P.a1 : P.a0);
+    const bool inside = m2 <= (1ull << 53);  // reaching 2^(e+1) exactly is still on this binade's grid
+    const unsigned long long out = __ballot(lane >= start && lane < first_bad && !inside);
+    const int f = out ? (int)__ffsll((long long)out) - 1 : first_bad;
+    if (f > start) {
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(m2 & 0xffffffffull), f - 1);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(m2 >> 32), f - 1);
+        const unsigned long long r = ((unsigned long long)hi << 32) | lo;
+        if (r == (1ull << 53)) S = __longlong_as_double((long long)(((unsigned long long)(e + 1 + 1023)) << 52));
+        else S = __longlong_as_double((long long)((((unsigned long long)(e + 1023)) << 52) | (r & 0x000fffffffffffffull)));
+    }
+    return f;
+}
+
+// single wavefront: the exact fold.  Three levels: batches of 64 chunks -> chunks of 512 elements -> lanes of 8 elements.
+// At every level the 64 maps in hand are applied with ONE scan up to the first that does not fit (a binade crossing, a
+// wrong guess, a negative or non-finite value); only that one is opened: a batch into its chunks, a chunk into per-lane
+// maps computed for the binade S is really in, a lane into 8 serial additions.  A fold has ~25 binade crossings, so
+// ~25 descents, each two dependent loads and a handful of scans long.
 template <typename F>
 __global__ void __launch_bounds__(64) k_walk(uint64_t n, const double *x, F f, const ChunkMeta *meta, const ChunkMeta *batch,
                                              uint64_t n_chunks, double *result, unsigned long long *serial_chunks) {
@@ -264,36 +313,45 @@ __global__ void __launch_bounds__(64) k_walk(uint64_t n, const double *x, F f, c
     double S = 0.0;
     unsigned long long n_serial = 0;
     const uint64_t n_batches = (n_chunks + 63) / 64;
-    for (uint64_t bb = 0; bb < n_batches && S == S; bb += 64) {
+    for (uint64_t bb = 0; bb < n_batches && S == S; bb += 64) {  // NaN is absorbing
         ChunkMeta bm;
         bm.a0 = bm.a1 = 0;
         bm.e = NO_MAP;
         if (bb + lane < n_batches) bm = batch[bb + lane];
         const int bcnt = (int)((n_batches - bb) < 64 ? (n_batches - bb) : 64);
-        for (int kb = 0; kb < bcnt && S == S; ++kb) {  // NaN is absorbing
-            const int be = __builtin_amdgcn_readlane(bm.e, kb);
-            if (be != NO_MAP) {
-                const long long a0 = __double_as_longlong(readlane_f64(__longlong_as_double(bm.a0), kb));
-                const long long a1 = __double_as_longlong(readlane_f64(__longlong_as_double(bm.a1), kb));
-                if (apply_map(S, be, a0, a1)) continue;
+        int bs = 0;
+        while (bs < bcnt && S == S) {
+            int fb = bs;
+            if (normal_positive(S)) {
+                const int e = exponent_of(S);
+                Map2 m;
+                m.a0 = bm.a0;
+                m.a1 = bm.a1;
+                fb = wave_apply_prefix(S, e, m, lane < bcnt && bm.e == e, bs, lane);
             }
-            // the batch map does not apply: walk its chunks
-            const uint64_t cb = (bb + kb) * 64;
+            if (fb >= bcnt) break;
+            // batch bb + fb does not apply: open it
+            const uint64_t cb = (bb + fb) * 64;
             ChunkMeta mine;
             mine.a0 = mine.a1 = 0;
             mine.e = NO_MAP;
             if (cb + lane < n_chunks) mine = meta[cb + lane];
             const int cnt = (int)((n_chunks - cb) < 64 ? (n_chunks - cb) : 64);
-            for (int k = 0; k < cnt && S == S; ++k) {
-                const int e = __builtin_amdgcn_readlane(mine.e, k);
-                if (e != NO_MAP) {
-                    const long long a0 = __double_as_longlong(readlane_f64(__longlong_as_double(mine.a0), k));
-                    const long long a1 = __double_as_longlong(readlane_f64(__longlong_as_double(mine.a1), k));
-                    if (apply_map(S, e, a0, a1)) continue;
+            int cs = 0;
+            while (cs < cnt && S == S) {
+                int fc = cs;
+                if (normal_positive(S)) {
+                    const int e = exponent_of(S);
+                    Map2 m;
+                    m.a0 = mine.a0;
+                    m.a1 = mine.a1;
+                    fc = wave_apply_prefix(S, e, m, lane < cnt && mine.e == e, cs, lane);
                 }
-                // serial, element by element, exactly like the reference loop
+                if (fc >= cnt) break;
+                // chunk cb + fc does not apply: open it (lane l holds elements [8 l, 8 l + 8), lane order == element order)
                 ++n_serial;
-                const uint64_t base = (cb + k) * CHUNK;
+                const uint64_t chunk = cb + fc;
+                const uint64_t base = chunk * CHUNK;
                 double v[PER_LANE];
 #pragma unroll
                 for (int j = 0; j < PER_LANE; ++j) {
@@ -301,12 +359,38 @@ __global__ void __launch_bounds__(64) k_walk(uint64_t n, const double *x, F f, c
                     v[j] = i < n ? f(x[i]) : 0.0;
                 }
                 const int m_el = (int)((n - base) < CHUNK ? (n - base) : CHUNK);
-                for (int l = 0; l * PER_LANE < m_el; ++l) {
+                const int n_lanes = (m_el + PER_LANE - 1) / PER_LANE;
+                int ls = 0, opened = 0;
+                while (ls < n_lanes && S == S) {
+                    int fl = ls;
+                    // the very first chunk climbs through a binade every few elements, and a chunk that keeps failing is not
+                    // worth more scans: fold those lane by lane
+                    if (chunk != 0 && opened < 4 && normal_positive(S)) {
+                        const int e = exponent_of(S);
+                        Map2 m;
+                        m.a0 = m.a1 = 0;
+                        bool ok = true;
+#pragma unroll
+                        for (int j = 0; j < PER_LANE; ++j) {
+                            if (lane * PER_LANE + j < m_el) {
+                                const double xv = v[j];
+                                if (xv >= 0.0 && xv < __longlong_as_double(0x7ff0000000000000ll)) m = compose(m, elem_map(xv, e, ok));
+                                else ok = false;
+                            }
+                        }
+                        fl = wave_apply_prefix(S, e, m, ok && lane < n_lanes, ls, lane);
+                    }
+                    if (fl >= n_lanes) break;
+                    // serial, element by element, exactly like the reference loop
 #pragma unroll
                     for (int j = 0; j < PER_LANE; ++j)
-                        if (l * PER_LANE + j < m_el) S += readlane_f64(v[j], l);
+                        if (fl * PER_LANE + j < m_el) S += readlane_f64(v[j], fl);
+                    ++opened;
+                    ls = fl + 1;
                 }
+                cs = fc + 1;
             }
+            bs = fb + 1;
         }
     }
     if (lane == 0) {

@@ -180,6 +180,16 @@ def test_exact_serial_statistics_hard_cases(ctx):
     cases.append(rng.uniform(0, 100, 513))
     # exact multiples of 2^-44 around 90: with the running sum near 2^23..2^26 these hit half-ulp ties often
     cases.append(np.round(rng.uniform(80, 100, 400_000) * 2.0 ** 28) / 2.0 ** 28)
+    # the walk opens a chunk into per-lane maps for the binade the sum is really in: crossings inside a lane, addends larger
+    # than the running sum, long runs of zeros, powers of two over 40 binades, a sum that stays subnormal, infinity
+    cases.append(np.concatenate([np.zeros(3000), rng.uniform(0, 100, 2000), np.zeros(5000), rng.uniform(0, 1e-3, 40_000)]))
+    cases.append(2.0 ** rng.randint(-20, 21, 150_000).astype(np.float64))
+    cases.append(np.concatenate([rng.uniform(0, 1e-6, 30_000), [1e9], rng.uniform(0, 100, 30_000), [1e15], rng.uniform(0, 100, 30_000)]))
+    cases.append(np.full(20_000, 5e-324))
+    cases.append(np.where(rng.uniform(0, 1, 200_000) < 0.97, 0.0, rng.uniform(0, 100, 200_000)))
+    y = rng.uniform(0, 100, 40_000); y[31_000] = np.inf
+    cases.append(y)
+    cases.append(np.concatenate([np.full(1500, 2.0 ** 52), np.full(70_000, 0.5), np.full(70_000, 1.5)]))  # ties at 2^52..2^53
     for i, mean in enumerate(cases):
         n = len(mean)
         window = mean * 0.9
