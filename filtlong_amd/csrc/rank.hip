@@ -95,13 +95,24 @@ __global__ void k_final_score(uint64_t n, const double *mean_q, const double *wi
     }
 }
 
-__global__ void k_passed_bases(uint64_t n, const int32_t *length, const uint8_t *passed,
+// one atomic per workgroup (256 threads): thousands of same-address atomics cost more than the pass over the data
+__device__ __forceinline__ void block_add(unsigned long long acc, unsigned long long *out) {
+    __shared__ unsigned long long part[4];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(out, t);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_passed_bases(uint64_t n, const int32_t *length, const uint8_t *passed,
                                unsigned long long *out) {
     unsigned long long acc = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         if (passed[i]) acc += (unsigned long long)length[i];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+    block_add(acc, out);
 }
 
 // weights in sorted order: bases a read contributes to the walk (main.cpp:251-257)
@@ -272,8 +283,7 @@ __global__ void __launch_bounds__(256) k_select_band(uint64_t n, const uint64_t 
             if (at < cap) band_idx[at] = (uint32_t)i;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(weight_before, acc);
+    block_add(acc, weight_before);
 }
 
 // everything at or beyond the band fails; the kept members of the band are switched back on by the host

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_rank.py tests/test_gpu_fullsize.py -x -q -k "not kmer" 2>&1 | tail -8 | cut -c1-600
+timeout 900 python -m pytest tests/test_gpu_rank.py tests/test_gpu_sharded.py -x -q 2>&1 | tail -8 | cut -c1-600
 timeout 600 python bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline > gpurun_out/bench_walk.json 2> gpurun_out/bench_walk.err
 python - <<'PY'
 import json
