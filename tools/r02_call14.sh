@@ -1,0 +1,8 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_phred.py -x -q 2>&1 | tail -4 | cut -c1-400
+timeout 300 python tools/bench_phred_kernel.py 3000000 2>&1 | tail -4
+FLX_PHRED_TABLES=private timeout 300 python tools/bench_phred_kernel.py 3000000 2>&1 | tail -2
+timeout 600 python bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_kernel_ms'])"
