@@ -81,6 +81,8 @@ extern "C" void flx_ctx_destroy(flx_ctx *ctx) {
     if (ctx->d_lut_q) (void)hipFree(ctx->d_lut_q);
     if (ctx->d_lut_d) (void)hipFree(ctx->d_lut_d);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (void *w : ctx->ws)
+        if (w) (void)hipFree(w);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -196,6 +198,22 @@ int flx_scratch(flx_ctx *ctx, size_t bytes, void **out) {
         ctx->scratch_bytes = want;
     }
     *out = ctx->scratch;
+    return FLX_OK;
+}
+
+int flx_workspace(flx_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (slot < 0 || slot >= 2) return flx_fail(ctx, FLX_ERR_INVALID, "workspace slot %d", slot);
+    if (bytes > ctx->ws_bytes[slot]) {
+        FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->ws[slot]) (void)hipFree(ctx->ws[slot]);
+        ctx->ws[slot] = nullptr;
+        ctx->ws_bytes[slot] = 0;
+        const size_t want = bytes + bytes / 16 + 4096;
+        hipError_t e = hipMalloc(&ctx->ws[slot], want);
+        if (e != hipSuccess) return flx_fail(ctx, FLX_ERR_NOMEM, "device workspace of %zu bytes: %s", want, hipGetErrorString(e));
+        ctx->ws_bytes[slot] = want;
+    }
+    *out = ctx->ws[slot];
     return FLX_OK;
 }
 

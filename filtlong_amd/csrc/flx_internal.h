@@ -46,6 +46,10 @@ struct flx_ctx {
     // reusable device scratch (grown on demand)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    // grow-only workspaces of the k-mer scoring path (kept between calls: a 12 GB hipMalloc + hipFree per batch costs
+    // more than the fold kernels)
+    void *ws[2] = {nullptr, nullptr};
+    size_t ws_bytes[2] = {0, 0};
 };
 
 int flx_fail(flx_ctx *ctx, int code, const char *fmt, ...);
@@ -70,6 +74,9 @@ void flx_time_end(flx_ctx *ctx);
 
 // grow-only scratch on the device
 int flx_scratch(flx_ctx *ctx, size_t bytes, void **out);
+// grow-only workspace `slot` (0: per-read arrays of the k-mer path, 1: its coverage bit plane); valid until the next call
+// with the same slot
+int flx_workspace(flx_ctx *ctx, int slot, size_t bytes, void **out);
 
 // simple device buffer owned by a call (freed in destructor)
 struct flx_dbuf {

@@ -591,51 +591,53 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     const unsigned nb = (unsigned)((n_reads + 255) / 256);
 
     // ---- coverage plane layout: row i = ceil(L/8) bytes rounded up to 16, rows packed by an exclusive scan ----
-    flx_dbuf d_rowb, d_covoff, d_cnt, d_first_tmp, d_last_tmp, d_scanws, d_nchild;
-    FLX_CHECK(flx_dalloc(ctx, d_rowb, (n_reads + 1) * 8));
-    FLX_CHECK(flx_dalloc(ctx, d_covoff, (n_reads + 1) * 8));
-    FLX_CHECK(flx_dalloc(ctx, d_cnt, n_reads * 4));
+    // All device memory of this path comes from the context's two grow-only workspaces: nothing is allocated or freed per
+    // batch once they have reached their size.
     const size_t scan_ws = flx_radix_sort_workspace(n_reads + 1);
-    FLX_CHECK(flx_dalloc(ctx, d_scanws, scan_ws));
-    int32_t *first = out->first, *last = out->last;
-    if (!first) {
-        FLX_CHECK(flx_dalloc(ctx, d_first_tmp, n_reads * 4));
-        first = d_first_tmp.as<int32_t>();
-    }
-    if (!last) {
-        FLX_CHECK(flx_dalloc(ctx, d_last_tmp, n_reads * 4));
-        last = d_last_tmp.as<int32_t>();
-    }
-    FLX_HIP(ctx, hipMemsetAsync(d_rowb.p, 0, (n_reads + 1) * 8, st));
-    hipLaunchKernelGGL(k_cov_row_bytes, dim3(nb), dim3(256), 0, st, n_reads, d_lengths, d_rowb.as<int64_t>());
-    FLX_CHECK(flx_exclusive_scan_i64(ctx, n_reads + 1, d_rowb.as<int64_t>(), d_covoff.as<int64_t>(), d_scanws.p, scan_ws));
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t small_bytes = 2 * up((n_reads + 1) * 8) + 3 * up(n_reads * 4) + up((n_reads + 1) * 4) + up(scan_ws);
+    void *small = nullptr;
+    FLX_CHECK(flx_workspace(ctx, 0, small_bytes, &small));
+    char *wp = (char *)small;
+    auto carve = [&](size_t bytes) { void *q = wp; wp += up(bytes); return q; };
+    int64_t *d_rowb = (int64_t *)carve((n_reads + 1) * 8);
+    int64_t *d_covoff = (int64_t *)carve((n_reads + 1) * 8);
+    int32_t *d_cnt = (int32_t *)carve(n_reads * 4);
+    int32_t *d_first_tmp = (int32_t *)carve(n_reads * 4);
+    int32_t *d_last_tmp = (int32_t *)carve(n_reads * 4);
+    uint32_t *d_nchild = (uint32_t *)carve((n_reads + 1) * 4);
+    void *d_scanws = carve(scan_ws);
+    int32_t *first = out->first ? out->first : d_first_tmp, *last = out->last ? out->last : d_last_tmp;
+    FLX_HIP(ctx, hipMemsetAsync(d_rowb, 0, (n_reads + 1) * 8, st));
+    hipLaunchKernelGGL(k_cov_row_bytes, dim3(nb), dim3(256), 0, st, n_reads, d_lengths, d_rowb);
+    FLX_CHECK(flx_exclusive_scan_i64(ctx, n_reads + 1, d_rowb, d_covoff, d_scanws, scan_ws));
     int64_t cov_bytes = 0;
-    FLX_HIP(ctx, hipMemcpyAsync(&cov_bytes, d_covoff.as<int64_t>() + n_reads, 8, hipMemcpyDeviceToHost, st));
+    FLX_HIP(ctx, hipMemcpyAsync(&cov_bytes, d_covoff + n_reads, 8, hipMemcpyDeviceToHost, st));
     FLX_HIP(ctx, hipStreamSynchronize(st));
-    flx_dbuf d_cov;
-    FLX_CHECK(flx_dalloc(ctx, d_cov, (size_t)cov_bytes + 64));
+    void *d_cov = nullptr;
+    FLX_CHECK(flx_workspace(ctx, 1, (size_t)cov_bytes + 64, &d_cov));
 
     // ---- kernel 1: lookups -> coverage bits ----
     {
         const unsigned grid = (unsigned)std::min<uint64_t>(n_reads, 1u << 20);
         flx_time_begin(ctx, "flx_score_kmer_cover");
         hipLaunchKernelGGL(k_kmer_cover<256>, dim3(grid), dim3(256), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
-                           flx_kmerset_bitmap(set), flx_kmerset_prefilter(set), d_cov.as<uint32_t>(), d_covoff.as<uint64_t>(), d_cnt.as<int32_t>(), first,
+                           flx_kmerset_bitmap(set), flx_kmerset_prefilter(set), (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first,
                            last);
         hipLaunchKernelGGL(k_kmer_cover<64>, dim3(grid), dim3(64), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
-                           flx_kmerset_bitmap(set), flx_kmerset_prefilter(set), d_cov.as<uint32_t>(), d_covoff.as<uint64_t>(), d_cnt.as<int32_t>(), first,
+                           flx_kmerset_bitmap(set), flx_kmerset_prefilter(set), (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first,
                            last);
         flx_time_end(ctx);
     }
 
     // ---- kernel 2: serial fold ----
     FoldArgs a;
-    a.cov = d_cov.as<uint32_t>();
-    a.cov_off = d_covoff.as<uint64_t>();
+    a.cov = (uint32_t *)d_cov;
+    a.cov_off = (const uint64_t *)d_covoff;
     a.lengths = d_lengths;
     a.order = d_order;
     a.n_reads = n_reads;
-    a.count = d_cnt.as<int32_t>();
+    a.count = d_cnt;
     a.first = first;
     a.last = last;
     a.ws = params->window_size;
@@ -666,9 +668,8 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
         return FLX_OK;
     }
 
-    FLX_CHECK(flx_dalloc(ctx, d_nchild, (n_reads + 1) * 4));
-    FLX_HIP(ctx, hipMemsetAsync(d_nchild.p, 0, (n_reads + 1) * 4, st));
-    a.n_child = d_nchild.as<uint32_t>();
+    FLX_HIP(ctx, hipMemsetAsync(d_nchild, 0, (n_reads + 1) * 4, st));
+    a.n_child = d_nchild;
     flx_time_begin(ctx, "flx_score_kmer_fold");
     // FLX_KMER_FOLD=bits forces the bit-level passes (tests compare the two implementations on every read)
     const char *fold_env = getenv("FLX_KMER_FOLD");
@@ -680,8 +681,8 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     flx_time_end(ctx);
     // child_offsets = exclusive scan of the counts (n + 1 entries; the last one is the total)
     hipLaunchKernelGGL(k_widen_u32_i64, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, st, n_reads + 1,
-                       d_nchild.as<uint32_t>(), d_rowb.as<int64_t>());
-    FLX_CHECK(flx_exclusive_scan_i64(ctx, n_reads + 1, d_rowb.as<int64_t>(), (int64_t *)out->child_offsets, d_scanws.p, scan_ws));
+                       d_nchild, d_rowb);
+    FLX_CHECK(flx_exclusive_scan_i64(ctx, n_reads + 1, d_rowb, (int64_t *)out->child_offsets, d_scanws, scan_ws));
     int64_t total_children = 0;
     FLX_HIP(ctx, hipMemcpyAsync(&total_children, (int64_t *)out->child_offsets + n_reads, 8, hipMemcpyDeviceToHost, st));
     FLX_HIP(ctx, hipStreamSynchronize(st));
