@@ -38,7 +38,7 @@ __device__ __forceinline__ uint32_t code_fwd(uint32_t c) {  // src/kmers.cpp:176
 // ---------------------------------------------------------------------------------------------------
 // One workgroup per read, COVER_THREADS * 16 positions per iteration.  Two instantiations share the batch: 256 threads
 // (spans of 4096 positions) for reads longer than kCoverShort, one wavefront (spans of 1024) for the short ones, which
-// would leave most of a 256-thread workgroup idle (500 bp reads: 206 -> see profiles/r02_microbench.txt ms per 1e10 bases).
+// would leave most of a 256-thread workgroup idle (500 bp reads: 206 -> 98 ms per 1e10 bases, 2 kbp: 83 -> 71; profiles/r02_microbench.txt).
 constexpr int kCoverShort = 3072;
 
 template <int COVER_THREADS>

@@ -380,7 +380,7 @@ done:
 // behind the leading one, so it is served by the L2 / Infinity Cache, not by HBM.  64 lanes = 64 lines per load
 // instruction: this is bound by the address path (~2.7x slower than the register-history kernel at ws = 250), but it has no
 // per-read on-chip state at all, so it replaces the byte-wise direct kernel wherever the LDS ring does not fit
-// (ws > ~2000: 283 -> see profiles/r02_microbench.txt ms per 1e10 bases at ws = 2500).  Plain tables, 16 waves per CU.
+// (ws > ~2000: 283 -> 21 ms per 1e10 bases at ws = 2500, profiles/r02_microbench.txt).  Plain tables, 16 waves per CU.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) flx_score_phred_stream(const PhredArgs a) {
     using T = Tab<false>;
