@@ -290,6 +290,24 @@ class Context:
         self._check(self.L.flx_comm_sum_u64(self.h, a.ctypes.data, a.size))
         return a
 
+    def rank_and_cut_comm(self, mean_q, window_q, length, passed, length_weight=1.0, mean_q_weight=1.0, window_q_weight=1.0,
+                          target_bases=None, keep_percent=None, total_bases=0, want_scores=False):
+        """flx_rank_and_cut_comm: this rank's reads2 scalars as host arrays (what the CLI holds); `total_bases` is the global
+        sum.  Returns the same dictionary as rank_and_cut for the local block."""
+        n = len(mean_q)
+        mq = np.ascontiguousarray(mean_q, dtype=np.float64)
+        wq = np.ascontiguousarray(window_q, dtype=np.float64)
+        ln = np.ascontiguousarray(length, dtype=np.int32)
+        ps = np.array(passed, dtype=np.uint8)
+        fs = np.zeros(n, dtype=np.float64) if want_scores else None
+        rep = CutReport()
+        self._check(self.L.flx_rank_and_cut_comm(self.h, n, mq.ctypes.data, wq.ctypes.data, ln.ctypes.data, ps.ctypes.data,
+                                                 length_weight, mean_q_weight, window_q_weight,
+                                                 1 if target_bases is not None else 0, int(target_bases or 0),
+                                                 1 if keep_percent is not None else 0, float(keep_percent or 0.0),
+                                                 int(total_bases), fs.ctypes.data if want_scores else None, C.byref(rep)))
+        return {"passed": ps, "final_score": fs, "report": rep}
+
     def rank_and_cut_comm_dev(self, n_local, d_mean_q, d_window_q, d_length, d_passed, length_weight=1.0, mean_q_weight=1.0,
                               window_q_weight=1.0, target_bases=None, keep_percent=None, total_bases=0, d_final_score=None):
         """flx_rank_and_cut_comm_dev: the global stage over all ranks of the context's RCCL communicator (one all-gather of
