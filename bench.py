@@ -298,8 +298,8 @@ def main():
     device_index = local_rank % max(torch.cuda.device_count(), 1)  # == local_rank except in the one-GPU gloo test
     torch.cuda.set_device(device_index)
     multi = world > 1 or args.force_dist
-    if args.backend != "nccl" and args.global_stage == "rccl":
-        args.global_stage = "sharded"  # the library's communicator is RCCL only
+    if args.backend != "nccl" and args.global_stage == "rccl" and not os.environ.get("FLX_RCCL_LIB"):
+        args.global_stage = "sharded"  # the library's communicator is RCCL only (FLX_RCCL_LIB: the tests' loopback stand-in)
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -357,7 +357,7 @@ def main():
         total_bases = int(tb.item())
         if args.global_stage == "rccl":
             # the library's own RCCL communicator: rank 0 draws the id, torch.distributed only carries its 128 bytes
-            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev if args.backend == "nccl" else "cpu")
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, 0)

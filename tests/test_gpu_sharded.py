@@ -158,12 +158,17 @@ def test_single_rank_equals_unsharded():
     assert check([(0, n)], mean, window, length, passed, target_bases=tot // 3, total_bases=tot)[0] == "ok"
 
 
-@pytest.mark.parametrize("stage", ["sharded", "replicated"])
+@pytest.mark.parametrize("stage", ["sharded", "replicated", "rccl"])
 def test_bench_two_processes_one_gpu(tmp_path, stage):
     """bench.py's N > 1 path as two real processes (gloo, both on GPU 0): every rank's flags equal the slice of the
-    single-process run over the same 2 x 20 000 reads."""
+    single-process run over the same 2 x 20 000 reads.  "rccl" is the driver's default stage (the library's own
+    communicator); two ranks on one GPU get the loopback stand-in for RCCL's entry points (tests/shim)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.pop("FLX_RANK_SORT", None)
+    if stage == "rccl":
+        shim_dir = os.path.join(ROOT, "tests", "shim")
+        subprocess.check_call(["make", "-s", "-C", shim_dir])
+        env["FLX_RCCL_LIB"] = os.path.join(shim_dir, "libloopback_rccl.so")
     one = str(tmp_path / "one")
     two = str(tmp_path / "two")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--reads", "40000",
@@ -178,6 +183,8 @@ def test_bench_two_processes_one_gpu(tmp_path, stage):
     line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["reads_total"] == 40000 and j["scaling"] == "weak"
+    if stage == "rccl":
+        assert "library-owned RCCL communicator" in j["config"]["parallelism"]
     want = np.load(one + ".rank0.npy")
     got = np.concatenate([np.load(two + ".rank%d.npy" % k) for k in range(2)])
     assert want.shape == got.shape and (want == got).all()
