@@ -92,6 +92,20 @@ def test_regs_kernel_every_window_remainder(ctx, kernel, monkeypatch):
             q = rng.randint(0, 256, size=L).astype(np.uint8)        # any byte
         elif i % 9 == 1:
             q = rng.randint(33, 127, size=L).astype(np.uint8)       # the full FASTQ alphabet
+        elif i % 9 == 2 and L > 4:
+            # bytes at the top of the 7-bit range (the bank-private tables hold rows 0..127) and just above it, also
+            # alone, at either end, or next to 0xff / 0xfe
+            q = rng.randint(120, 127, size=L).astype(np.uint8)
+            where = (i // 9) % 4
+            if where == 0:
+                q[L // 2] = 127
+            elif where == 1:
+                q[0] = 127
+            elif where == 2:
+                q[-1] = 127
+                q[-2] = 0xff
+            else:
+                q[L // 3] = 0xfe   # 0xfe + 1 = 0xff: still no carry, but >= 128 anyway
         else:
             q = synth.qual_read(5000 + i, int(L), 17)
         reads.append(("x%d" % i, b"", q.tobytes()))
