@@ -126,7 +126,7 @@ def test_cli_two_ranks_on_one_gpu(tmp_path, shim):
                  ["-a", str(fa), "--trim", "--split", "100", "--target_bases", "200000", str(kq)],
                  ["-a", str(fa), "--trim", "--split", "100", str(kq)]):
         one = subprocess.run([BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1, timeout=300)
-        for gpus in ("2", "3"):
+        for gpus in ("2", "3") + (("8",) if args[0] == "--target_bases" else ()):
             two = subprocess.run([BIN, "--gpus", gpus] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env2, timeout=300)
             assert one.returncode == 0 and two.returncode == 0, (args, gpus, two.stderr.decode()[-1500:])
             assert len(one.stdout) > 0 and two.stdout == one.stdout, (args, gpus)
