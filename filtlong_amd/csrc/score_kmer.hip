@@ -24,13 +24,18 @@
 
 namespace {
 
-__device__ __forceinline__ uint32_t code_fwd(uint32_t c) {  // src/kmers.cpp:176-196; anything else -> 0
-    switch (c) {
-        case 'C': case 'c': return 1u;
-        case 'G': case 'g': return 2u;
-        case 'T': case 't': return 3u;
-        default: return 0u;
-    }
+// The 2-bit codes of the four bases of a dword (src/kmers.cpp:176-196: C/c 1, G/g 2, T/t 3, anything else 0) packed into 8
+// bits, first base (lowest byte) in the top two.  Branch free: a switch per base compiles into divergent control flow — half
+// of the cover kernel's run time before — while three exact SWAR byte comparisons serve four bases at once.
+__device__ __forceinline__ uint32_t codes4(uint32_t w) {
+    const uint32_t x = w & 0xDFDFDFDFu;  // folds the case (bit 5); x == 'C' exactly for 'C' and 'c', likewise G and T
+    auto eq = [](uint32_t v, uint32_t k) {  // bit 7 of every byte of v that equals the byte of k
+        const uint32_t y = v ^ k;
+        return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
+    };
+    const uint32_t zc = eq(x, 0x43434343u), zg = eq(x, 0x47474747u), zt = eq(x, 0x54545454u);
+    const uint32_t t = ((zc | zt) >> 7) | ((zg | zt) >> 6);  // bits 0-1 of every byte: its code
+    return ((t << 6) | (t >> 4) | (t >> 14) | (t >> 24)) & 0xffu;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -78,18 +83,15 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
                 uint4 a = make_uint4(0, 0, 0, 0);
                 if (p0 > 0) a = *reinterpret_cast<const uint4 *>(seq + p0 - 16);
                 const uint4 b = *reinterpret_cast<const uint4 *>(seq + p0);
-                const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                uint32_t k = 0;
+                // 2 bits per base: hi = bases p0-16 .. p0-1, lo = bases p0 .. p0+15 (earliest base in the top bits); the 16-mer
+                // ending at p0 + j is a 32-bit window of hi:lo
+                const uint32_t hi = (codes4(a.x) << 24) | (codes4(a.y) << 16) | (codes4(a.z) << 8) | codes4(a.w);
+                const uint32_t lo = (codes4(b.x) << 24) | (codes4(b.y) << 16) | (codes4(b.z) << 8) | codes4(b.w);
 #pragma unroll
-                for (int j = 1; j < 16; ++j) {
-                    k = (k << 2) | code_fwd((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
-                    if (j >= 11) kleft[j - 11] = k;
-                }
+                for (int j = 0; j < 15; ++j) kmers[j] = __builtin_amdgcn_alignbit(hi, lo, 2 * (15 - j));
+                kmers[15] = lo;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    k = (k << 2) | code_fwd((w[4 + (j >> 2)] >> (8 * (j & 3))) & 0xffu);
-                    kmers[j] = k;  // 16-mer ending at position p0 + j
-                }
+                for (int j = 0; j < 5; ++j) kleft[j] = hi >> (2 * (4 - j));  // low 24 bits: the 12-mer ending at p0 - 5 + j
                 // 12-mer prefilter (kmerset.h): one L2 lookup per position, all 16 in flight
 #ifdef FLX_ABL_NOL2
                 if (false) {
