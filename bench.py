@@ -242,8 +242,8 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
             "note": "not a streaming kernel: per position ONE random L2-hit lookup (2 MiB 12-mer prefilter) and, for candidates, a random "
                     "64-byte fabric request into the 512 MiB exact bitmap; both go through the same vector-memory path.  `achieved` = far "
                     "requests x 64 B / kernel time, `peak` = the measured random-request ceiling (tools/randbench: 55 G requests/s x 64 B); "
-                    "`l2_lookup_frac` = L2-hit lookups/s over the 265 G/s an L2-resident table delivers alone; the two fractions add up to "
-                    "~1 (request counts from the PMC pass recorded in profiles/, not from this run).  The streamed bytes (SURVEY §8d, "
+                    "`l2_lookup_frac` = L2-hit lookups/s over the 265 G/s an L2-resident table delivers alone; both ceilings are "
+                    "approached at the same time, the classes overlap only partly (request counts from the PMC pass recorded in profiles/, not from this run).  The streamed bytes (SURVEY §8d, "
                     "`algorithmic_bytes`) are %.1f %% of the 8 TB/s HBM peak over the whole step" % (
                         100.0 * algo_bytes / el / 1e9 / HBM_PEAK_GBS),
             "achieved": round(far["far_requests"] * 64 / (cover * 1e-3) / 1e9, 1) if far else None,
