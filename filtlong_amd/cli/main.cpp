@@ -7,8 +7,9 @@
 //   input parsing   src/kseq.h:176-224         FASTA/FASTQ records, multi-line, "\r\n", gz via zlib
 //   orchestration   src/main.cpp:37-321        sections printed to stderr, reads2 gather, output order
 //   formatting      src/misc.cpp:24-49         2-decimal doubles, locale-grouped integers
-// Differences by design: the input is parsed once and kept in memory (the reference parses the file twice,
-// main.cpp:70-127 and 264-313); scoring is batched (flx_score_batch) instead of one Read per record.
+// Differences by design: a plain file is mapped and parsed once (the reference parses it twice, main.cpp:70-127 and
+// 264-313), a gzip file is streamed block by block (gzblocks.h); scoring is batched and streamed (flx_pipeline_*) instead of
+// one Read object per record; ranks (one process per GPU) share the global stage through the library's communicator.
 #include <zlib.h>
 
 #include <algorithm>
@@ -42,9 +43,6 @@
 #include <unistd.h>
 
 #include "../../include/filtlong_hip.h"
-#include "inflate_stream.h"
-
-#define PROGRAM_VERSION "0.3.1"
 
 // ------------------------------------------------------------------------------------------------ formatting
 static std::string double_to_string(double n) {  // src/misc.cpp:24-32
@@ -64,641 +62,9 @@ static std::string int_to_string(long long n) {  // src/misc.cpp:35-40 (thousand
 
 static std::string pad(const std::string &s, size_t width) { return width > s.size() ? s + std::string(width - s.size(), ' ') : s; }
 
-// ------------------------------------------------------------------------------------------------ arguments
-struct Args {
-    std::string input_reads;
-    bool target_bases_set = false; long long target_bases = 0;
-    bool keep_percent_set = false; double keep_percent = 0;
-    bool min_length_set = false; int min_length = 0;
-    bool max_length_set = false; int max_length = 0;
-    bool min_mean_q_set = false; double min_mean_q = 0;
-    bool min_window_q_set = false; double min_window_q = 0;
-    bool assembly_set = false; std::string assembly;
-    std::vector<std::string> short_reads;
-    double length_weight = 1.0, mean_q_weight = 1.0, window_q_weight = 1.0;
-    bool trim = false;
-    bool split_set = false; int split = 0;
-    long long window_size = 250;
-    bool verbose = false;
-    int gpus = 1;  // not a reference flag: --gpus N scores on N GPUs of this node (one process per GPU)
-};
-enum ParsingResult { GOOD, BAD, HELP, VERSION };
-
-struct ParseError : std::runtime_error { using std::runtime_error::runtime_error; };
-
-static double read_double(const std::string &name, const std::string &value) {  // DoublesReader, arguments.cpp:28-39
-    try {
-        if (value.find_first_not_of("0123456789.") != std::string::npos) throw std::invalid_argument("");
-        return std::stod(value);
-    } catch (...) {
-        throw ParseError("Error: argument '" + name + "' received invalid value type '" + value + "'");
-    }
-}
-
-// "<number>[k|kb|m|mb|g|gb]", case-insensitive, fractional numbers allowed ("1.5k" = 1500), result truncated towards zero.
-// Behaviour pinned by the reference's unit-suffix tests (test/test_unit_suffixes.py; arguments.cpp:53-93): anything but digits
-// and dots after the optional sign starts the suffix, so "1e3" is an unknown suffix there and here.
-static long long parse_int_with_suffix(const std::string &value) {
-    const char *text = value.c_str();
-    if (*text == '\0') throw std::invalid_argument("empty");
-    // the numeric part: an optional sign, then digits and dots only (no exponent once a suffix follows)
-    size_t i = (text[0] == '-') ? 1 : 0;
-    const size_t digits_from = i;
-    while (isdigit((unsigned char)text[i]) || text[i] == '.') ++i;
-    if (text[i] == '\0') {  // no suffix: the whole token is the number (std::stod semantics, like the reference)
-        size_t used = 0;
-        const double v = std::stod(value, &used);
-        return static_cast<long long>(v);
-    }
-    if (i == digits_from) throw std::invalid_argument("no number");
-    double scale = 0.0;
-    switch (tolower((unsigned char)text[i])) {
-        case 'k': scale = 1e3; break;
-        case 'm': scale = 1e6; break;
-        case 'g': scale = 1e9; break;
-        default: throw std::invalid_argument("suffix");
-    }
-    const char *rest = text + i + 1;
-    if (!(rest[0] == '\0' || (tolower((unsigned char)rest[0]) == 'b' && rest[1] == '\0'))) throw std::invalid_argument("suffix");
-    const double v = std::stod(value.substr(0, i));
-    return static_cast<long long>(v * scale);
-}
-
-static long long read_ll_suffix(const std::string &name, const std::string &value) {  // arguments.cpp:42-51
-    try { return parse_int_with_suffix(value); }
-    catch (...) { throw ParseError("Error: argument '" + name + "' received invalid value '" + value + "'"); }
-}
-
-static int read_int_suffix(const std::string &name, const std::string &value) {  // arguments.cpp:96-113
-    try {
-        const long long r = parse_int_with_suffix(value);
-        if (r > INT_MAX || r < INT_MIN) throw std::invalid_argument("Value out of range for int");
-        return static_cast<int>(r);
-    } catch (...) { throw ParseError("Error: argument '" + name + "' received invalid value '" + value + "'"); }
-}
-
-static long long read_ll(const std::string &name, const std::string &value) {  // default args.h reader (operator>>)
-    std::istringstream ss(value);
-    long long v;
-    if (!(ss >> v) || !ss.eof()) throw ParseError("Argument '" + name + "' received invalid value type '" + value + "'");
-    return v;
-}
-
-static void print_help(const char *prog) {
-    std::cerr <<
-        "  " << prog << " {OPTIONS} [input_reads]\n\n"
-        "Filtlong: a quality filtering tool for Nanopore and PacBio reads\n"
-        "(MI355X-native scoring hot path; drop-in for the reference command line)\n\n"
-        "usage:\n"
-        "  positional arguments:\n"
-        "    input_reads                         input long reads to be filtered\n\n"
-        "  output thresholds:\n"
-        "    -t[int], --target_bases [int]       keep only the best reads up to this many total bases (unit suffixes: k, kb, m, mb, g, gb)\n"
-        "    -p[float], --keep_percent [float]   keep only this percentage of the best reads (measured by bases)\n"
-        "    -l[int], --min_length [int]         minimum length threshold (unit suffixes: k, kb, m, mb, g, gb)\n"
-        "    -L[int], --max_length [int]         maximum length threshold (unit suffixes: k, kb, m, mb, g, gb)\n"
-        "    -q[float], --min_mean_q [float]     minimum mean quality threshold\n"
-        "    --min_window_q [float]              minimum window quality threshold\n\n"
-        "  external references (if provided, read quality will be determined using these instead of from the Phred scores):\n"
-        "    -a[file], --assembly [file]         reference assembly in FASTA format\n"
-        "    -1[file], --short_1 [file]          reference short reads in FASTQ format\n"
-        "    -2[file], --short_2 [file]          reference short reads in FASTQ format\n\n"
-        "  score weights (control the relative contribution of each score to the final read score):\n"
-        "    --length_weight [float]             weight given to the length score (default: 1)\n"
-        "    --mean_q_weight [float]             weight given to the mean quality score (default: 1)\n"
-        "    --window_q_weight [float]           weight given to the window quality score (default: 1)\n\n"
-        "  read manipulation:\n"
-        "    --trim                              trim non-k-mer-matching bases from start/end of reads\n"
-        "    --split [split]                     split reads at this many (or more) consecutive non-k-mer-matching bases (unit suffixes: k, kb, m, mb, g, gb)\n\n"
-        "  other:\n"
-        "    --window_size [int]                 size of sliding window used when measuring window quality (default: 250)\n"
-        "    --verbose                           verbose output to stderr with info for each read\n"
-        "    --gpus [int]                        score on this many GPUs of the node (one process per GPU, RCCL; default: 1)\n"
-        "    --version                           display the program version and quit\n"
-        "    -h, --help                          display this help menu\n\n"
-        "For more information, go to: https://github.com/rrwick/Filtlong\n";
-}
-
-static bool file_exists(const std::string &f) { std::ifstream in(f); return in.good(); }
-
-static ParsingResult parse_args(int argc, char **argv, Args &a) {
-    bool version = false;
-    bool short1_set = false, short2_set = false;
-    std::string short1, short2;
-    std::vector<std::string> positional;
-    try {
-        for (int i = 1; i < argc; ++i) {
-            std::string tok = argv[i];
-            std::string flag, value;
-            bool have_value = false;
-            if (tok.size() >= 2 && tok[0] == '-' && tok[1] == '-') {
-                flag = tok.substr(2);  // long flags take their value from the next token (LongSeparator(" "), arguments.cpp:128)
-            } else if (tok.size() >= 2 && tok[0] == '-' && !(isdigit((unsigned char)tok[1]) && false)) {
-                flag = std::string(1, tok[1]);
-                if (tok.size() > 2) { value = tok.substr(2); have_value = true; }  // -t100
-                static const char *shorts = "tplLqa12h";
-                if (!strchr(shorts, tok[1])) throw ParseError("Flag could not be matched: " + std::string(1, tok[1]));
-            } else {
-                positional.push_back(tok);
-                continue;
-            }
-            auto need = [&](const char *n) -> std::string {
-                if (have_value) return value;
-                if (i + 1 >= argc) throw ParseError(std::string("Flag '") + n + "' requires an argument but received none");
-                return argv[++i];
-            };
-            if (flag == "h" || flag == "help") { print_help(argv[0]); return HELP; }
-            else if (flag == "version") version = true;
-            else if (flag == "verbose") a.verbose = true;
-            else if (flag == "trim") a.trim = true;
-            else if (flag == "t" || flag == "target_bases") { a.target_bases = read_ll_suffix("int", need("target_bases")); a.target_bases_set = true; }
-            else if (flag == "p" || flag == "keep_percent") { a.keep_percent = read_double("float", need("keep_percent")); a.keep_percent_set = true; }
-            else if (flag == "l" || flag == "min_length") { a.min_length = read_int_suffix("int", need("min_length")); a.min_length_set = true; }
-            else if (flag == "L" || flag == "max_length") { a.max_length = read_int_suffix("int", need("max_length")); a.max_length_set = true; }
-            else if (flag == "q" || flag == "min_mean_q") { a.min_mean_q = read_double("float", need("min_mean_q")); a.min_mean_q_set = true; }
-            else if (flag == "min_window_q") { a.min_window_q = read_double("float", need("min_window_q")); a.min_window_q_set = true; }
-            else if (flag == "a" || flag == "assembly") { a.assembly = need("assembly"); a.assembly_set = true; }
-            else if (flag == "1" || flag == "short_1") { short1 = need("short_1"); short1_set = true; }
-            else if (flag == "2" || flag == "short_2") { short2 = need("short_2"); short2_set = true; }
-            else if (flag == "length_weight") a.length_weight = read_double("float", need("length_weight"));
-            else if (flag == "mean_q_weight") a.mean_q_weight = read_double("float", need("mean_q_weight"));
-            else if (flag == "window_q_weight") a.window_q_weight = read_double("float", need("window_q_weight"));
-            else if (flag == "split") { a.split = read_int_suffix("split", need("split")); a.split_set = true; }
-            else if (flag == "window_size") a.window_size = read_ll("int", need("window_size"));
-            else if (flag == "gpus") a.gpus = (int)read_ll("int", need("gpus"));
-            else throw ParseError("Flag could not be matched: " + flag);
-        }
-        if (positional.size() > 1) throw ParseError("Passed in argument, but no positional arguments were ready to receive it: " + positional[1]);
-    } catch (const ParseError &e) {
-        std::cerr << e.what() << "\n";
-        return BAD;
-    }
-    if (argc == 1) { print_help(argv[0]); return HELP; }
-    if (version) return VERSION;
-    if (!positional.empty()) a.input_reads = positional[0];
-    if (a.input_reads.empty()) { std::cerr << "Error: input reads are required" << "\n"; return BAD; }
-    if (short1_set) a.short_reads.push_back(short1);
-    if (short2_set) a.short_reads.push_back(short2);
-
-    // validation: same order and messages as arguments.cpp:298-393
-    const bool some_reference = !a.short_reads.empty() || a.assembly_set;
-    if (a.trim && !some_reference) { std::cerr << "Error: assembly or read reference is required to use --trim" << "\n"; return BAD; }
-    if (a.split_set && !some_reference) { std::cerr << "Error: assembly or read reference is required to use --split" << "\n"; return BAD; }
-    std::vector<std::string> files;
-    files.push_back(a.input_reads);
-    for (auto &f : a.short_reads) files.push_back(f);
-    if (a.assembly_set) files.push_back(a.assembly);
-    for (auto &f : files)
-        if (!file_exists(f)) { std::cerr << "Error: cannot find file: " << f << "\n"; return BAD; }
-    if (!a.trim && !a.split_set && !a.target_bases_set && !a.keep_percent_set && !a.min_length_set && !a.max_length_set &&
-        !a.min_mean_q_set && !a.min_window_q_set) {
-        std::cerr << "Error: no thresholds set, you must use one of the following options:\n";
-        std::cerr << "target_bases, keep_percent, min_length, max_length, min_mean_q, min_window_q, trim, split\n";
-        return BAD;
-    }
-    if (a.target_bases_set && a.target_bases <= 0) { std::cerr << "Error: the value for --target_bases must be a positive integer\n"; return BAD; }
-    if (a.min_length_set && a.min_length <= 0) { std::cerr << "Error: the value for --min_length must be a positive integer\n"; return BAD; }
-    if (a.max_length_set && a.max_length <= 0) { std::cerr << "Error: the value for --max_length must be a positive integer\n"; return BAD; }
-    if (a.keep_percent_set && (a.keep_percent <= 0.0 || a.keep_percent >= 100.0)) {
-        std::cerr << "Error: the value for --keep_percent must be greater than 0 and less than 100\n"; return BAD; }
-    if (a.min_mean_q_set && a.min_mean_q <= 0.0) { std::cerr << "Error: the value for --min_mean_q must be greater than 0\n"; return BAD; }
-    if (a.min_window_q_set && a.min_window_q <= 0.0) { std::cerr << "Error: the value for --min_window_q must be greater than 0\n"; return BAD; }
-    if (a.length_weight < 0.0 || a.mean_q_weight < 0.0 || a.window_q_weight < 0.0) { std::cerr << "Error: weight values cannot be negative\n"; return BAD; }
-    if (a.split_set && a.split <= 0) { std::cerr << "Error: the value for --split must be a positive integer\n"; return BAD; }
-    if (a.window_size <= 0) { std::cerr << "Error: the value for --window_size must be a positive integer\n"; return BAD; }
-    if (a.gpus < 1 || a.gpus > 64) { std::cerr << "Error: the value for --gpus must be between 1 and 64\n"; return BAD; }
-    return GOOD;
-}
-
-// ------------------------------------------------------------------------------------------------ FASTA/FASTQ
-// In-memory parser with the record grammar of klib's kseq (src/kseq.h:176-224): records start at the next '>' or
-// '@'; the name ends at the first whitespace, the rest of the header line is the comment; sequence lines run until a
-// line whose first character is '>', '+' or '@'; after '+' the quality is read line by line until it is at least as
-// long as the sequence; a trailing '\r' is dropped from every line; empty lines are skipped.
-struct View {  // a piece of the input buffer (or of the side arena for multi-line records); never owns memory
-    const char *p = nullptr;
-    size_t n = 0;
-    size_t size() const { return n; }
-    bool empty() const { return n == 0; }
-    std::string str() const { return std::string(p ? p : "", n); }
-    std::string_view sv() const { return std::string_view(p ? p : "", n); }
-};
-static std::ostream &operator<<(std::ostream &os, const View &v) { return os.write(v.p ? v.p : "", (std::streamsize)v.n); }
-
-struct Record {
-    View name, comment, seq, qual;
-    bool is_fastq = false;
-};
-
-// ---- host threads for the two byte-moving stages (page-in of the input, packing the read plane) ------------------------
-static unsigned host_threads() {
-    const char *e = getenv("FLX_CLI_THREADS");
-    if (e && atoi(e) > 0) return (unsigned)atoi(e);
-    const unsigned hw = std::thread::hardware_concurrency();
-    return std::max(1u, std::min(16u, hw ? hw : 1u));
-}
-
-template <class F>
-static void parallel_for(size_t n_parts, F &&body) {  // body(part) for part in [0, n_parts), on up to host_threads() threads
-    const unsigned t = (unsigned)std::min<size_t>(host_threads(), n_parts);
-    if (t <= 1) { for (size_t i = 0; i < n_parts; ++i) body(i); return; }
-    std::vector<std::thread> th;
-    for (unsigned k = 0; k < t; ++k)
-        th.emplace_back([&, k] { for (size_t i = k; i < n_parts; i += t) body(i); });
-    for (auto &x : th) x.join();
-}
-
-// The whole input, addressable.  Plain files are mapped (no copy; pages are faulted in by several threads); gzip and
-// pipes are inflated / read into memory through zlib, as the reference's kseq does (src/kseq.h:87-110).
-struct Input {
-    const char *p = nullptr;
-    size_t n = 0;
-    void *map = nullptr;
-    size_t map_len = 0;
-    std::string owned;
-    Input() = default;
-    Input(const Input &) = delete;
-    Input &operator=(const Input &) = delete;
-    ~Input() { if (map) munmap(map, map_len); }
-    const char *data() const { return p; }
-    size_t size() const { return n; }
-
-    bool open(const std::string &path) {
-        const int fd = ::open(path.c_str(), O_RDONLY);
-        if (fd < 0) return false;
-        unsigned char magic[2] = {0, 0};
-        struct stat st;
-        const bool regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0;
-        const bool gz = regular && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
-        if (regular && !gz) {
-            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m != MAP_FAILED) {
-                ::close(fd);
-                map = m; map_len = (size_t)st.st_size;
-                p = (const char *)m; n = map_len;
-                madvise(m, map_len, MADV_WILLNEED);
-                const size_t part = 64u << 20;
-                const size_t parts = (n + part - 1) / part;
-                std::vector<unsigned> sink(parts, 0);
-                parallel_for(parts, [&](size_t i) {  // touch one byte per page so the page-table fill runs on all threads
-                    unsigned acc = 0;
-                    const size_t end = std::min(n, (i + 1) * part);
-                    for (size_t at = i * part; at < end; at += 4096) acc += (unsigned char)p[at];
-                    sink[i] = acc;
-                });
-                return true;
-            }
-        }
-        ::close(fd);
-        gzFile fp = gzopen(path.c_str(), "r");  // transparent for uncompressed streams too
-        if (!fp) return false;
-        gzbuffer(fp, 1 << 20);
-        std::vector<char> buf(1 << 22);
-        for (;;) {
-            const int got = gzread(fp, buf.data(), (unsigned)buf.size());
-            if (got < 0) { gzclose(fp); return false; }
-            if (got == 0) break;
-            owned.append(buf.data(), (size_t)got);
-        }
-        gzclose(fp);
-        p = owned.data(); n = owned.size();
-        return true;
-    }
-};
-
-// Record views point into the buffer; only multi-line sequences / qualities are copied (into `arena`).
-struct Parser {
-    const Input &d;
-    std::deque<std::string> &arena;
-    size_t pos = 0;
-    int last_char = 0;
-    Parser(const Input &data, std::deque<std::string> &side) : d(data), arena(side) {}
-    int getc() { return pos < d.size() ? (unsigned char)d.p[pos++] : -1; }
-    // rest of the current line as a view [from, end-of-line), consuming the newline; false at EOF
-    bool rest_of_line(size_t from, View &v) {
-        if (from > d.size()) return false;
-        const void *nlp = pos < d.size() ? memchr(d.data() + pos, '\n', d.size() - pos) : nullptr;
-        const size_t end = nlp ? (size_t)((const char *)nlp - d.data()) : d.size();
-        v.p = d.data() + from;
-        v.n = end - from;
-        pos = nlp ? end + 1 : d.size();
-        return true;
-    }
-    // kseq's ks_getuntil2(KS_SEP_LINE, append): append the rest of the line to the accumulating field `v`
-    // (first line: a view; later lines: copied into the arena); a trailing '\r' is dropped when the field has > 1 chars
-    void append_line(View &v, bool &owned, size_t first_from) {
-        View line;
-        if (v.n == 0 && !owned) {
-            rest_of_line(first_from, v);
-        } else {
-            if (!owned) {
-                arena.emplace_back(v.p, v.n);
-                owned = true;
-            }
-            rest_of_line(first_from, line);
-            arena.back().append(line.p, line.n);
-            v.p = arena.back().data();
-            v.n = arena.back().size();
-        }
-        if (v.n > 1 && v.p[v.n - 1] == '\r') {
-            --v.n;
-            if (owned) arena.back().pop_back();
-        }
-    }
-    // Position of the header character ('@' / '>') of the record next() would return, or size() if there is none:
-    // performs the same skip next() starts with, without consuming the header.
-    size_t peek_header() {
-        if (last_char != 0) return pos - 1;
-        while (pos < d.size() && d.p[pos] != '>' && d.p[pos] != '@') ++pos;
-        return pos;
-    }
-    // returns length >= 0, -1 at EOF, -2 on truncated / mismatching quality   (src/kseq.h:176-224)
-    long long next(Record &r) {
-        int c;
-        if (last_char == 0) {
-            while ((c = getc()) >= 0 && c != '>' && c != '@') {}
-            if (c < 0) return -1;
-            last_char = c;
-        }
-        r = Record();
-        if (pos >= d.size()) return -1;
-        size_t e = pos;
-        while (e < d.size() && !isspace((unsigned char)d.p[e])) ++e;  // the name ends at the first whitespace
-        r.name.p = d.data() + pos;
-        r.name.n = e - pos;
-        c = e < d.size() ? (unsigned char)d.p[e] : -1;
-        pos = e < d.size() ? e + 1 : e;
-        if (c != '\n' && c >= 0) {
-            rest_of_line(pos, r.comment);
-            if (r.comment.n > 1 && r.comment.p[r.comment.n - 1] == '\r') --r.comment.n;
-        }
-        bool seq_owned = false, qual_owned = false;
-        while ((c = getc()) >= 0 && c != '>' && c != '+' && c != '@') {
-            if (c == '\n') continue;
-            append_line(r.seq, seq_owned, pos - 1);  // the line starts at the character just consumed
-        }
-        if (c == '>' || c == '@') last_char = c;
-        r.is_fastq = (c == '+');
-        if (!r.is_fastq) { if (c < 0) last_char = 0; return (long long)r.seq.size(); }
-        while ((c = getc()) >= 0 && c != '\n') {}
-        if (c == -1) return -2;
-        for (;;) {
-            if (pos >= d.size()) break;
-            append_line(r.qual, qual_owned, pos);
-            if (r.qual.size() >= r.seq.size()) break;
-        }
-        last_char = 0;
-        if (r.seq.size() != r.qual.size()) return -2;
-        return (long long)r.seq.size();
-    }
-};
-
-// ---- whole-file parse -------------------------------------------------------------------------------------------------
-struct Parsed {
-    std::vector<Record> recs;
-    std::deque<std::deque<std::string>> arenas;  // owners of the multi-line fields the records point into
-    long long status = -1;                       // -1: clean EOF, -2: the record `bad` is truncated / mismatching
-    Record bad;
-};
-
-static void parse_sequential(const Input &d, Parsed &out) {
-    out.arenas.emplace_back();
-    Parser p(d, out.arenas.back());
-    Record r;
-    for (;;) {
-        const long long l = p.next(r);
-        if (l < 0) { out.status = l; if (l == -2) out.bad = r; return; }
-        out.recs.push_back(r);
-    }
-}
-
-// A position that is certainly the start of a record.  FASTQ input (`fastq`: the file's first record is one): the beginning
-// of a line starting with '@' (or '>') whose line + 2 starts with '+' and whose lines + 1 and + 3 have equal lengths — a
-// quality line can start with '@' or '>' (Phred 31 / 29) too, but then the line after it is a header or a sequence, not '+'.
-// FASTA input: a line starting with '>' (sequence lines never start with it).  Returns d.size() if none is found before `limit`.
-static size_t find_record_start(const Input &d, size_t from, size_t limit, bool fastq) {
-    const char *b = d.p;
-    const size_t n = d.n;
-    auto line_end = [&](size_t at) -> size_t { return at >= n ? n : (size_t)(std::find(b + at, b + n, '\n') - b); };
-    size_t at = from;
-    if (at > 0) at = line_end(at - 1) + 1;  // first line start >= from
-    while (at < limit && at < n) {
-        const size_t e0 = line_end(at);
-        if (b[at] == '>' && !fastq) return at;
-        if ((b[at] == '@' || b[at] == '>') && fastq && e0 < n) {
-            const size_t s1 = e0 + 1, e1 = line_end(s1);
-            const size_t s2 = e1 + 1;
-            if (e1 < n && s2 < n && b[s2] == '+') {
-                const size_t e2 = line_end(s2);
-                const size_t s3 = e2 + 1, e3 = line_end(s3);
-                if (e2 < n && e3 - s3 == e1 - s1 && e1 > s1) return at;
-            }
-        }
-        at = e0 + 1;
-    }
-    return n;
-}
-
-// Chunks of the file parsed concurrently.  Chunk k starts at a certain record start S_k and stops when the next record
-// would start at or after S_{k+1}; the result is accepted only if every chunk stopped EXACTLY at S_{k+1} between two
-// records — then the concatenation is what the sequential parser produces (its state there is just "between records").
-// Anything else (odd formats, an error inside a chunk) returns false and the caller parses sequentially.
-static bool parse_parallel(const Input &d, Parsed &out) {
-    const unsigned t = host_threads();
-    size_t min_bytes = 32u << 20;
-    if (const char *e = getenv("FLX_CLI_PARALLEL_PARSE_MIN")) min_bytes = (size_t)atoll(e);  // tests force it on small files
-    if (t < 2 || d.n < min_bytes || d.n < t) return false;
-    std::vector<size_t> start(t + 1, d.n);
-    start[0] = 0;
-    size_t h0 = 0;  // the kind of the first record decides which lines can start a record
-    while (h0 < d.n && d.p[h0] != '>' && d.p[h0] != '@') ++h0;
-    const bool fastq = h0 < d.n && d.p[h0] == '@';
-    for (unsigned k = 1; k < t; ++k) {
-        start[k] = find_record_start(d, d.n / t * k, d.n / t * (k + 1), fastq);
-        if (start[k] >= d.n || start[k] <= start[k - 1]) return false;
-    }
-    struct Chunk { std::vector<Record> recs; std::deque<std::string> arena; bool ok = false; };
-    std::vector<Chunk> chunks(t);
-    parallel_for(t, [&](size_t k) {
-        Chunk &c = chunks[k];
-        Parser p(d, c.arena);
-        p.pos = start[k];
-        const size_t stop = start[k + 1];
-        Record r;
-        for (;;) {
-            const size_t h = p.peek_header();
-            if (h >= stop) { c.ok = (h == stop); return; }
-            const long long l = p.next(r);
-            if (l < 0) { c.ok = false; return; }  // EOF inside a chunk that should end at a record start, or a bad record
-            c.recs.push_back(r);
-        }
-    });
-    size_t total = 0;
-    for (auto &c : chunks) {
-        if (!c.ok) return false;
-        total += c.recs.size();
-    }
-    out.recs.reserve(total);
-    for (auto &c : chunks) {
-        out.recs.insert(out.recs.end(), c.recs.begin(), c.recs.end());
-        out.arenas.push_back(std::move(c.arena));
-    }
-    out.status = -1;
-    return true;
-}
-
-static bool parse_all(const Input &d, Parsed &out) {  // true: the concurrent parse was accepted
-    if (parse_parallel(d, out)) return true;
-    out = Parsed();
-    parse_sequential(d, out);
-    return false;
-}
-
-// ---- block-wise parse of a compressed input -----------------------------------------------------------------------------
-// A gzip file cannot be mapped, and inflating all of it costs its uncompressed size in memory (the reference never holds
-// more than one record, src/kseq.h:87-110).  BlockReader inflates a block at a time and parses the records that are complete
-// inside it with the same Parser; the unfinished tail moves to the front of the next block.  A record is complete when the
-// parser stopped BEFORE the end of the buffer: it then never saw the end, so more data behind it cannot change the record.
-// Views of a batch are valid until the next call.  A record larger than the block doubles the buffer.
-struct MappedFile {  // read-only mapping of a regular file (the compressed input)
-    const unsigned char *p = nullptr;
-    size_t n = 0;
-    MappedFile() = default;
-    MappedFile(const MappedFile &) = delete;
-    MappedFile &operator=(const MappedFile &) = delete;
-    ~MappedFile() { if (p) munmap((void *)p, n); }
-    bool open(const std::string &path) {
-        const int fd = ::open(path.c_str(), O_RDONLY);
-        if (fd < 0) return false;
-        struct stat st;
-        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) { ::close(fd); return false; }
-        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-        ::close(fd);
-        if (m == MAP_FAILED) return false;
-        p = (const unsigned char *)m;
-        n = (size_t)st.st_size;
-        madvise(m, n, MADV_SEQUENTIAL);
-        return true;
-    }
-    bool gz() const { return n >= 2 && p[0] == 0x1f && p[1] == 0x8b; }
-};
-
-struct BlockReader {
-    static constexpr size_t kHistory = 32768;  // output kept in front of the write position: the window of an access point
-    MappedFile file;
-    InflateStream z;
-    std::vector<char> buf;
-    size_t have = 0;        // valid bytes in buf
-    size_t view_from = 0;   // the parse window is [view_from, have); bytes before it are history
-    size_t carry_from = 0;  // where the next window starts (set by next())
-    uint64_t buf_offset = 0;  // uncompressed offset of buf[0]
-    bool done = false, io_error = false;
-    std::vector<GzPoint> points;  // access points for a concurrent second pass (the first is the beginning of the file)
-    uint64_t span = 0;
-    BlockReader() = default;
-    BlockReader(const BlockReader &) = delete;
-    BlockReader &operator=(const BlockReader &) = delete;
-    static size_t block_bytes() {
-        if (const char *e = getenv("FLX_CLI_BLOCK_BYTES")) return std::max<size_t>(64, (size_t)atoll(e));  // tests force tiny blocks
-        if (const char *e = getenv("FLX_CLI_BLOCK_MB")) return std::max<size_t>(1, (size_t)atoll(e)) << 20;
-        return (size_t)256 << 20;
-    }
-    static uint64_t point_span() {  // uncompressed bytes between access points = the work unit of the output pass
-        if (const char *e = getenv("FLX_CLI_SPAN_BYTES")) return std::max<uint64_t>(1, (uint64_t)atoll(e));
-        return (uint64_t)32 << 20;
-    }
-    bool open(const std::string &path, bool want_points) {
-        if (!file.open(path) || !z.open(file.p, file.n, file.gz())) return false;
-        buf.resize(block_bytes() + kHistory);
-        span = want_points ? point_span() : 0;
-        points.clear();
-        if (want_points) points.emplace_back();
-        return true;
-    }
-    // uncompressed offset of a byte of the current batch
-    uint64_t offset_of(const char *p) const { return buf_offset + (uint64_t)(p - buf.data()); }
-    uint64_t end_offset() const { return buf_offset + have; }
-    bool next(Parsed &out) {  // false: nothing left (or io_error)
-        out = Parsed();
-        if (done) return false;
-        if (carry_from > 0) {  // drop what has been parsed, keep the history in front of the unfinished tail
-            const size_t drop = carry_from > kHistory ? carry_from - kHistory : 0;
-            if (drop > 0) {
-                memmove(buf.data(), buf.data() + drop, have - drop);
-                have -= drop;
-                buf_offset += drop;
-            }
-            view_from = carry_from - drop;
-            carry_from = 0;
-        }
-        for (;;) {
-            if (!z.eof() && have < buf.size()) {
-                have += z.read(buf.data() + have, buf.size() - have, span ? &points : nullptr, span);
-                if (z.error()) { io_error = true; done = true; return false; }
-            }
-            const bool eof = z.eof();
-            view.p = buf.data() + view_from;
-            view.n = have - view_from;
-            out.arenas.emplace_back();
-            Parser ps(view, out.arenas.back());
-            Record r;
-            size_t consumed = view.n;
-            for (;;) {
-                const size_t header = ps.peek_header();
-                const long long len = ps.next(r);
-                if (!eof && ps.pos >= view.n) { consumed = std::min(header, view.n); break; }  // ran into the end of the block: unfinished
-                if (len == -1) break;
-                if (len == -2) { out.status = -2; out.bad = r; done = true; break; }
-                out.recs.push_back(r);
-            }
-            if (out.recs.empty() && !done && !eof && consumed == 0) {  // one record fills the whole block
-                buf.resize((buf.size() - kHistory) * 2 + kHistory);
-                out = Parsed();
-                continue;
-            }
-            carry_from = view_from + consumed;
-            if (eof) done = true;
-            return true;
-        }
-    }
-
-private:
-    Input view;  // non-owning window on buf
-};
-
-// The work units of the output pass over a streamed input: unit j is the text from the first record that starts at or
-// after access point j up to the first record of unit j + 1, so every unit is a whole number of records and can be
-// inflated (from its point) and parsed on its own.
-struct UnitIndex {
-    std::vector<uint64_t> start, first_rec;  // per access point, plus one closing entry (total size, record count)
-    void note_record(const std::vector<GzPoint> &points, uint64_t header_offset, uint64_t rec) {
-        while (start.size() < points.size() && points[start.size()].out <= header_offset) {
-            start.push_back(header_offset);
-            first_rec.push_back(rec);
-        }
-    }
-    void finish(const std::vector<GzPoint> &points, uint64_t total_bytes, uint64_t n_records) {
-        while (start.size() < points.size() + 1) {
-            start.push_back(total_bytes);
-            first_rec.push_back(n_records);
-        }
-    }
-    size_t units() const { return start.empty() ? 0 : start.size() - 1; }
-};
-
-// bytes [from, to) of the uncompressed stream, inflated from an access point at or before `from`
-static bool inflate_range(const MappedFile &file, const GzPoint &pt, uint64_t from, uint64_t to, std::vector<char> &text) {
-    InflateStream z;
-    if (pt.out > from || !z.open_at(file.p, file.n, file.gz(), pt)) return false;
-    std::vector<char> skip(std::min<uint64_t>(from - pt.out, 1u << 20));
-    for (uint64_t left = from - pt.out; left > 0;) {
-        const size_t got = z.read(skip.data(), (size_t)std::min<uint64_t>(left, skip.size()));
-        if (got == 0) return false;
-        left -= got;
-    }
-    text.resize((size_t)(to - from));
-    return z.read(text.data(), text.size()) == text.size() && !z.error();
-}
+#include "args.h"
+#include "fastx.h"
+#include "gzblocks.h"
 
 // FLX_CLI_PARSE_ONLY=seq|par|blk: parse the input, print a digest of every field and exit (no GPU needed).  The CPU tests
 // compare the sequential parser with the concurrent one and with the block-wise reader on generated odd files.
@@ -831,6 +197,79 @@ static int add_sequences(flx_ctx *ctx, flx_kmerset *set, const std::vector<std::
         : flx_kmerset_add_assembly(set, (const uint8_t *)bases.data(), offsets.data(), lengths.data(), seqs.size());
     (void)ctx;
     return rc;
+}
+
+// ---- ordered pieces ----------------------------------------------------------------------------------------------------
+// The output is produced as `n` independent pieces by several threads.  produce(j, piece) fills piece j and says whether it
+// could.  With `offsets` (n + 1 byte offsets, the sink a regular file that is not in append mode) every thread writes its
+// own pieces with pwrite at base + offsets[j] and the file position is moved behind the last one; without, this thread
+// writes the pieces in order as they become ready, and no more than 2 x threads of them exist at a time.
+template <class Produce>
+static bool write_pieces(size_t n, Produce &&produce, FILE *sink, const std::vector<uint64_t> *offsets) {
+    fflush(sink);
+    const int fd = fileno(sink);
+    struct stat st;
+    const int fl = fcntl(fd, F_GETFL);
+    const off_t base = lseek(fd, 0, SEEK_CUR);
+    const bool direct = offsets && !getenv("FLX_CLI_ORDERED_OUTPUT") && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 &&
+                        !(fl & O_APPEND) && base >= 0;
+    std::vector<std::string> piece(n);
+    std::vector<char> state(n, 0);  // 1: ready (or written), 2: failed
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<size_t> next{0};
+    size_t written = 0;
+    const unsigned n_workers = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads(), n));
+    const size_t ahead = 2 * (size_t)n_workers;
+    auto worker = [&] {
+        for (;;) {
+            const size_t j = next.fetch_add(1);
+            if (j >= n) return;
+            if (!direct) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return j < written + ahead; });
+            }
+            std::string &buf = piece[j];
+            if (offsets) buf.reserve((size_t)((*offsets)[j + 1] - (*offsets)[j]));
+            bool ok = produce(j, buf);
+            if (offsets) ok = ok && buf.size() == (*offsets)[j + 1] - (*offsets)[j];
+            if (direct) {
+                for (size_t done = 0; ok && done < buf.size();) {
+                    const ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, base + (off_t)((*offsets)[j] + done));
+                    if (w <= 0) ok = false;
+                    else done += (size_t)w;
+                }
+                std::string().swap(buf);
+            }
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                state[j] = ok ? 1 : 2;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < n_workers; ++t) pool.emplace_back(worker);
+    bool failed = false;
+    for (size_t j = 0; j < n; ++j) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return state[j] != 0; });
+            failed = failed || state[j] == 2;
+        }
+        if (!direct) {
+            if (!failed) fwrite(piece[j].data(), 1, piece[j].size(), sink);
+            std::string().swap(piece[j]);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                written = j + 1;
+            }
+            cv.notify_all();
+        }
+    }
+    for (auto &t : pool) t.join();
+    if (direct && !failed && lseek(fd, base + (off_t)(*offsets)[n], SEEK_SET) < 0) failed = true;
+    return !failed;
 }
 
 int main(int argc, char **argv) {
@@ -1311,7 +750,6 @@ int main(int argc, char **argv) {
             out += '\n';
         }
     };
-    std::string out;
     if (!streamed) {
         // The passed records are cut out of the mapped input by several threads, ~16 MiB of output per piece.  Every piece's
         // place in the output is known beforehand, so when the sink is a regular file each thread writes its pieces itself
@@ -1337,70 +775,11 @@ int main(int argc, char **argv) {
             piece_at.push_back(bytes);
         }
         const size_t n_pieces = piece_first.size() - 1;
-        fflush(sink);
-        const int fd = fileno(sink);
-        struct stat st;
-        const int fl = fcntl(fd, F_GETFL);
-        const off_t base = lseek(fd, 0, SEEK_CUR);
-        const bool direct = !getenv("FLX_CLI_ORDERED_OUTPUT") && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 &&
-                            !(fl & O_APPEND) && base >= 0;
-        std::vector<std::string> piece(n_pieces);
-        std::vector<char> state(n_pieces, 0);  // 1: ready (or written), 2: write failed
-        std::mutex mu;
-        std::condition_variable cv;
-        std::atomic<size_t> next_piece{0};
-        size_t written = 0;
-        const unsigned n_workers = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads(), n_pieces));
-        const size_t ahead = 2 * (size_t)n_workers;
-        auto worker = [&] {
-            for (;;) {
-                const size_t j = next_piece.fetch_add(1);
-                if (j >= n_pieces) return;
-                if (!direct) {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return j < written + ahead; });
-                }
-                std::string &buf = piece[j];
-                buf.reserve((size_t)(piece_at[j + 1] - piece_at[j]));
-                for (uint64_t i = piece_first[j]; i < piece_first[j + 1]; ++i) emit(buf, i, kept.recs[reads2[i].rec]);
-                bool ok = buf.size() == piece_at[j + 1] - piece_at[j];
-                if (direct) {
-                    for (size_t done = 0; ok && done < buf.size();) {
-                        const ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, base + (off_t)(piece_at[j] + done));
-                        if (w <= 0) ok = false;
-                        else done += (size_t)w;
-                    }
-                    std::string().swap(buf);
-                }
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    state[j] = ok ? 1 : 2;
-                }
-                cv.notify_all();
-            }
-        };
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < n_workers; ++t) pool.emplace_back(worker);
-        bool failed = false;
-        for (size_t j = 0; j < n_pieces; ++j) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return state[j] != 0; });
-                failed = failed || state[j] == 2;
-            }
-            if (!direct) {
-                if (!failed) fwrite(piece[j].data(), 1, piece[j].size(), sink);
-                std::string().swap(piece[j]);
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    written = j + 1;
-                }
-                cv.notify_all();
-            }
-        }
-        for (auto &t : pool) t.join();
-        if (direct && !failed && lseek(fd, base + (off_t)piece_at[n_pieces], SEEK_SET) < 0) failed = true;
-        if (failed) { std::cerr << "Error: could not write the output\n"; return 1; }
+        const bool ok = write_pieces(n_pieces, [&](size_t j, std::string &buf) {
+            for (uint64_t i = piece_first[j]; i < piece_first[j + 1]; ++i) emit(buf, i, kept.recs[reads2[i].rec]);
+            return true;
+        }, sink, &piece_at);
+        if (!ok) { std::cerr << "Error: could not write the output\n"; return 1; }
     } else {
         // Second pass over the compressed input (src/main.cpp:263-313 re-reads the file too), but not front to back on one
         // thread: pass 1 left access points in the deflate stream, the pieces between them (whole records, ~32 MiB of text)
@@ -1414,71 +793,29 @@ int main(int argc, char **argv) {
                 r2_at[j] = cur;
             }
         }
-        std::vector<std::string> piece(n_units);
-        std::vector<char> state(n_units, 0);  // 1: ready, 2: failed
-        std::mutex mu;
-        std::condition_variable cv;
-        std::atomic<size_t> next_unit{0};
-        size_t written = 0;
-        const unsigned n_workers = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads(), n_units));
-        const size_t ahead = 2 * (size_t)n_workers;  // bounds the text in flight
-        auto worker = [&] {
+        const bool ok = write_pieces(n_units, [&](size_t j, std::string &buf) {
+            bool any = false;
+            for (uint64_t i = r2_at[j]; i < r2_at[j + 1] && !any; ++i) any = r2_pass[i] != 0;
+            if (!any) return true;
             std::vector<char> text;
-            for (;;) {
-                const size_t j = next_unit.fetch_add(1);
-                if (j >= n_units) return;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return j < written + ahead; });
-                }
-                bool ok = true, any = false;
-                for (uint64_t i = r2_at[j]; i < r2_at[j + 1] && !any; ++i) any = r2_pass[i] != 0;
-                if (any) {
-                    Parsed got;
-                    ok = inflate_range(blocks.file, blocks.points[j], units.start[j], units.start[j + 1], text);
-                    if (ok) {
-                        Input view;
-                        view.p = text.data();
-                        view.n = text.size();
-                        parse_sequential(view, got);
-                        ok = got.recs.size() == units.first_rec[j + 1] - units.first_rec[j];
-                    }
-                    uint64_t cur = r2_at[j];
-                    for (size_t k = 0; ok && k < got.recs.size(); ++k) {
-                        const uint64_t rec = units.first_rec[j] + k;
-                        const Record &r = got.recs[k];
-                        if (r.name.sv() != names[rec] || (int32_t)r.seq.size() != lengths[rec]) { ok = false; break; }
-                        for (; cur < r2_at[j + 1] && reads2[cur].rec == rec; ++cur) emit(piece[j], cur, r);
-                    }
-                }
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    state[j] = ok ? 1 : 2;
-                }
-                cv.notify_all();
+            Parsed got;
+            if (!inflate_range(blocks.file, blocks.points[j], units.start[j], units.start[j + 1], text)) return false;
+            Input view;
+            view.p = text.data();
+            view.n = text.size();
+            parse_sequential(view, got);
+            if (got.recs.size() != units.first_rec[j + 1] - units.first_rec[j]) return false;
+            uint64_t cur = r2_at[j];
+            for (size_t k = 0; k < got.recs.size(); ++k) {
+                const uint64_t rec = units.first_rec[j] + k;
+                const Record &r = got.recs[k];
+                if (r.name.sv() != names[rec] || (int32_t)r.seq.size() != lengths[rec]) return false;
+                for (; cur < r2_at[j + 1] && reads2[cur].rec == rec; ++cur) emit(buf, cur, r);
             }
-        };
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < n_workers; ++t) pool.emplace_back(worker);
-        bool failed = false;
-        for (size_t j = 0; j < n_units; ++j) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return state[j] != 0; });
-                failed = failed || state[j] == 2;
-            }
-            if (!failed) fwrite(piece[j].data(), 1, piece[j].size(), sink);
-            std::string().swap(piece[j]);
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                written = j + 1;
-            }
-            cv.notify_all();
-        }
-        for (auto &t : pool) t.join();
-        if (failed) { std::cerr << "Error: " << args.input_reads << " could not be read a second time (did it change?)\n"; return 1; }
+            return true;
+        }, sink, nullptr);
+        if (!ok) { std::cerr << "Error: " << args.input_reads << " could not be read a second time (did it change?)\n"; return 1; }
     }
-    fwrite(out.data(), 1, out.size(), sink);
     fflush(sink);
     if (world > 1) {
         fclose(sink);
