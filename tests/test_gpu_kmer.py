@@ -218,6 +218,38 @@ def test_long_reads_vs_oracle(be, synth):
                 assert wc["mean_q"] == oc["mean_q"] and wc["window_q"] == oc["window_q"] and wc["passed"] == oc["passed"]
 
 
+def test_every_byte_value_in_reads(be, synth):
+    """The device's base encoder is branch free (three SWAR byte comparisons per dword, case folded by clearing bit 5):
+    exactly 'C' 'c' 'G' 'g' 'T' 't' may code 1/2/3 and every other byte value — 'A', 'N', IUPAC letters, digits, bytes
+    that differ from a base only in bit 7 or bit 4, 0x00, 0xff — codes 0 like the reference's switch (src/kmers.cpp:176-196)."""
+    from filtlong_amd import synth as S
+    rng = np.random.RandomState(11)
+    ref = np.frombuffer(b"".join(synth["contigs"]), dtype=np.uint8)
+    reads = []
+    lookalikes = np.array([0xC3, 0xE3, 0x53, 0x03, 0xC7, 0xE7, 0x57, 0x07, 0xD4, 0xF4, 0x44, 0x14, 0x41, 0x61, 0x4E, 0x6E, 0, 255],
+                          dtype=np.uint8)   # C/G/T with bit 7 set, bit 4 flipped, bits 6-5 cleared; A, a, N, n
+    for i, L in enumerate([300, 1000, 4096, 5000, 20000]):
+        s0 = int(rng.randint(0, len(ref) - L))
+        r = ref[s0:s0 + L].copy()
+        pos = rng.randint(0, L, max(4, L // 40))
+        r[pos] = rng.randint(0, 256, len(pos)).astype(np.uint8) if i % 2 == 0 else lookalikes[rng.randint(0, len(lookalikes), len(pos))]
+        lower = rng.randint(0, L - 64)
+        r[lower:lower + 64] = np.frombuffer(bytes(r[lower:lower + 64]).lower(), dtype=np.uint8)
+        reads.append(("b%d" % i, r.tobytes(), S.qual_read(100 + i, L).tobytes()))
+    # one read made of every byte value in turn, and one of the look-alikes only: no 16-mer of theirs may be found by accident
+    reads.append(("allbytes", bytes(range(256)) * 8, S.qual_read(200, 2048).tobytes()))
+    reads.append(("lookalikes", bytes(lookalikes.tolist()) * 100, S.qual_read(201, 1800).tobytes()))
+    orc = _oracle.KmerSet(); orc.add_assembly(synth["contigs"])
+    for pkw in (dict(), dict(trim=True, split=50)):
+        got = be.score(reads, pkw, synth["asm"])
+        p = _oracle.make_params(**pkw)
+        for (name, s, q), o in zip(reads, got):
+            w = _oracle.score_read(s, q, p, orc, cap=65536)
+            assert w["mean_q"] == o["mean_q"] and w["window_q"] == o["window_q"], (name, pkw, w["mean_q"], o["mean_q"])
+            assert (w["first"], w["last"], w["passed"]) == (o["first"], o["last"], o["passed"]), (name, pkw)
+            assert w["child_ranges"] == o["child_ranges"], (name, pkw)
+
+
 def test_prefilter_and_fold_variants_give_identical_results(be, synth, monkeypatch):
     """The L2 prefilter (kmerset finalize) and the word-level child passes are pure accelerations: without the prefilter
     (FLX_KMER_PREFILTER=0, the path large sets take) and with the bit-level fold (FLX_KMER_FOLD=bits) every output field
