@@ -77,8 +77,15 @@ __device__ __host__ inline double final_score_with(PowFn powfn, int length, doub
     return gm * scale;
 }
 
+// The device score only ORDERS reads (the boundary audit re-scores the band around the cut with the host libm), so the two
+// exponents of the default weights need no pow: x^1 is x and x^(1/2) the correctly rounded square root, both within an ulp
+// of what glibc's pow returns — far inside the audit band.  The exponent is the same for every read: a uniform branch.
 struct DevPow {
-    __device__ double operator()(double x, double y) const { return pow(x, y); }
+    __device__ double operator()(double x, double y) const {
+        if (y == 1.0) return x;
+        if (y == 0.5) return sqrt(x);
+        return pow(x, y);
+    }
 };
 
 __global__ void k_final_score(uint64_t n, const double *mean_q, const double *window_q, const int32_t *length,
