@@ -176,32 +176,20 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
         t["coff"].data_ptr(), t["crng"].data_ptr(), t["cmean"].data_ptr(), t["cwin"].data_ptr(), t["cpass"].data_ptr())
     s.child_capacity = cap
     target = int(b.bases * target_frac)
-    idx_n = torch.arange(n, dtype=torch.int64, device=dev)
+    # reads2 arrays (src/main.cpp:138-147): every read, or its children in its place
+    cap2 = n + (cap if trim_split else 0)
+    r2 = {k: torch.zeros(cap2, dtype=dt, device=dev) for k, dt in (("mean", torch.float64), ("win", torch.float64),
+                                                                   ("len", torch.int32), ("pass", torch.uint8))}
 
     def step():
         ctx.score_kmer_dev(ks, b.d_plane.data_ptr(), b.plane_bytes, b.d_off.data_ptr(), b.d_len.data_ptr(),
                            b.d_ord.data_ptr(), n, params, s)
         nc = int(s.n_children)
-        if nc == 0:
-            m2, w2, l2, p2 = t["mean"], t["win"], b.d_len, t["pass"].clone()
-        else:
-            # reads2 (src/main.cpp:138-147): file order, every parent with children replaced in place by its children
-            cnt = t["coff"][1:] - t["coff"][:-1]
-            size = torch.where(cnt > 0, cnt, torch.ones_like(cnt))
-            parent = torch.repeat_interleave(idx_n, size)
-            start2 = torch.cumsum(size, 0) - size
-            is_child = cnt[parent] > 0
-            ci = torch.where(is_child, t["coff"][:-1][parent] + (torch.arange(parent.numel(), device=dev) - start2[parent]),
-                             torch.zeros_like(parent))
-            crng = t["crng"].view(-1, 2)
-            m2 = torch.where(is_child, t["cmean"][ci], t["mean"][parent])
-            w2 = torch.where(is_child, t["cwin"][ci], t["win"][parent])
-            l2 = torch.where(is_child, crng[ci, 1] - crng[ci, 0], b.d_len[parent]).to(torch.int32)
-            p2 = torch.where(is_child, t["cpass"][ci], t["pass"][parent])
-        torch.cuda.synchronize()
-        rep = ctx.rank_and_cut_dev(m2.numel(), m2.data_ptr(), w2.data_ptr(), l2.data_ptr(), p2.data_ptr(),
+        n2 = ctx.reads2_gather_dev(n, b.d_len.data_ptr(), s, cap2, r2["mean"].data_ptr(), r2["win"].data_ptr(),
+                                   r2["len"].data_ptr(), r2["pass"].data_ptr())
+        rep = ctx.rank_and_cut_dev(n2, r2["mean"].data_ptr(), r2["win"].data_ptr(), r2["len"].data_ptr(), r2["pass"].data_ptr(),
                                    target_bases=target, total_bases=b.bases)
-        return rep, nc, m2.numel()
+        return rep, nc, n2
 
     for _ in range(warmup):
         step()
@@ -216,6 +204,7 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
     cover_ms, cn = ctx.timing_get("flx_score_kmer_cover")
     fold_ms, _ = ctx.timing_get("flx_score_kmer_fold")
     rank_ms, _ = ctx.timing_get("flx_rank")
+    gather_ms, _ = ctx.timing_get("flx_reads2")
     ctx.timing_enable(False)
     cover = cover_ms / max(cn, 1)
     lookups = b.bases - 15 * n
@@ -235,7 +224,7 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
         "value": round(b.bases / el / 1e6, 1), "unit": "Mbases/s", "ms_per_step": round(el * 1e3, 2),
         "bases": b.bases, "set_size": len(ks), "set_build_s_device": round(build_s, 2), "children": nc, "reads2": n2,
         "stage_ms_per_step": {"cover_kernel": round(cover, 2), "fold_kernels": round(fold_ms / steps, 2),
-                              "rank_kernels": round(rank_ms / steps, 2)},
+                              "reads2_gather_kernels": round(gather_ms / steps, 3), "rank_kernels": round(rank_ms / steps, 2)},
         "lookups_per_s_G": round(lookups / (cover * 1e-3) / 1e9, 2),
         "roofline": {
             "bound": "hbm", "kernel": "k_kmer_cover",
@@ -277,12 +266,23 @@ def main():
                     help="N > 1: rccl = the library's own communicator (flx_rank_and_cut_comm_dev: one all-gather of the mean "
                          "qualities, histograms all-reduced on the device, no host round trips); sharded / replicated = the same "
                          "exchange driven from torch.distributed (host callback / full records)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
-                                                       "one-GPU functional test of the N > 1 path)")
+    ap.add_argument("--backend", default="auto", help="torch.distributed backend that launches the ranks and carries the "
+                                                       "communicator id: auto = nccl (RCCL) with one GPU per rank, gloo when "
+                                                       "ranks share a GPU (one-GPU functional tests of the N > 1 path)")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, collectives) even "
                                                               "with one rank: exercises the RCCL calls on a 1-GPU box")
     ap.add_argument("--dump-flags", default="", help="write this rank's final pass flags to <path>.rank<r>.npy (tests)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python3 bench.py --gpus N` as the driver types it: start the N ranks ourselves — one process per GPU under
+        # torch.distributed.run on a free local port; rank 0 of that job prints the JSON line on our stdout
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
 
     import torch
     import torch.distributed as dist
@@ -292,12 +292,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched through torch.distributed.run" % args.gpus)
-    device_index = local_rank % max(torch.cuda.device_count(), 1)  # == local_rank except in the one-GPU gloo test
+    if world > 1 and args.gpus != world:
+        sys.exit("bench.py --gpus %d launched with WORLD_SIZE=%d" % (args.gpus, world))
+    n_dev = max(torch.cuda.device_count(), 1)
+    device_index = local_rank % n_dev  # == local_rank unless several ranks share a GPU (the one-GPU functional tests)
     torch.cuda.set_device(device_index)
     multi = world > 1 or args.force_dist
+    if args.backend == "auto":  # RCCL wants one device per rank; ranks that share a GPU rendezvous over gloo
+        args.backend = "nccl" if n_dev >= world else "gloo"
     if args.backend != "nccl" and args.global_stage == "rccl" and not os.environ.get("FLX_RCCL_LIB"):
         args.global_stage = "sharded"  # the library's communicator is RCCL only (FLX_RCCL_LIB: the tests' loopback stand-in)
     if multi:
@@ -464,7 +466,8 @@ def main():
                                 "reads sharded by count; 1 all-gather of mean qualities + all-reduced selection histograms "
                                 "(torch.distributed, host callback)" if args.global_stage == "sharded" else
                                 "reads sharded by count; 1 all-gather of per-read records, global stage replicated"),
-                "device": info["name"],
+                "device": info["name"], "gpus_visible": n_dev, "launch_backend": args.backend if multi else None,
+                "rccl_ranks": ctx.L.flx_comm_world(ctx.h) if multi and args.global_stage == "rccl" else None,
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

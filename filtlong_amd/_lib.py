@@ -19,7 +19,8 @@ STATUS_NAMES = {0: "FLX_OK", 1: "FLX_ERR_INVALID", 2: "FLX_ERR_HIP", 3: "FLX_ERR
 ABI_SYMBOLS = [
     "flx_abi_version", "flx_version", "flx_ctx_create", "flx_ctx_destroy", "flx_last_error", "flx_ctx_set_stream",
     "flx_ctx_synchronize", "flx_ctx_device_info", "flx_timing_enable", "flx_timing_reset", "flx_timing_get",
-    "flx_plane_layout", "flx_length_order", "flx_score_batch", "flx_score_batch_dev", "flx_rank_and_cut",
+    "flx_plane_layout", "flx_length_order", "flx_score_batch", "flx_score_batch_dev", "flx_reads2_gather", "flx_reads2_gather_dev",
+    "flx_rank_and_cut",
     "flx_rank_and_cut_dev", "flx_rank_and_cut_sharded_dev", "flx_rank_and_cut_comm_dev", "flx_rank_and_cut_comm", "flx_comm_unique_id",
     "flx_pipeline_create", "flx_pipeline_reserve", "flx_pipeline_next_buffer", "flx_pipeline_submit", "flx_pipeline_finish", "flx_pipeline_destroy",
     "flx_comm_init", "flx_comm_destroy", "flx_comm_rank", "flx_comm_world", "flx_comm_sum_u64", "flx_kmerset_create", "flx_kmerset_destroy", "flx_kmerset_add_assembly",
@@ -120,6 +121,8 @@ def load():
     L.flx_length_order.argtypes = [vp, u64, vp]
     L.flx_score_batch.argtypes = [vp, vp, vp, u64, vp, vp, vp, u64, C.POINTER(Params), C.POINTER(Scores)]
     L.flx_score_batch_dev.argtypes = [vp, vp, vp, u64, vp, vp, vp, u64, C.POINTER(Params), C.POINTER(Scores)]
+    L.flx_reads2_gather_dev.argtypes = [vp, u64, vp, C.POINTER(Scores), u64, vp, vp, vp, vp, vp, vp, C.POINTER(u64)]
+    L.flx_reads2_gather.argtypes = [vp, u64, vp, C.POINTER(Scores), u64, vp, vp, vp, vp, vp, vp, C.POINTER(u64)]
     rank_args = [vp, u64, vp, vp, vp, vp, dbl, dbl, dbl, i32, i64, i32, dbl, i64, vp, C.POINTER(CutReport)]
     L.flx_rank_and_cut.argtypes = rank_args
     L.flx_rank_and_cut_dev.argtypes = rank_args

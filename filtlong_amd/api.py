@@ -216,6 +216,38 @@ class Context:
         self._check(self.L.flx_score_batch_dev(self.h, kmers.h if kmers is not None else None, d_plane, plane_bytes,
                                                d_offsets, d_lengths, d_order, n, C.byref(params), C.byref(s)))
 
+    # ---- reads2 gather (src/main.cpp:138-147) ------------------------------------------------------
+    def reads2_gather(self, lengths, scores):
+        """flx_reads2_gather on the dictionary score_reads returns: file order, parents replaced in place by their children.
+        Returns a dict of numpy arrays mean_q / window_q / length / passed / parent / child in reads2 order."""
+        n = len(lengths)
+        ln = np.ascontiguousarray(lengths, dtype=np.int32)
+        nc = len(scores["child_mean_q"])
+        keep = [np.ascontiguousarray(scores[k]) for k in ("mean_q", "window_q", "passed", "child_offsets", "child_ranges",
+                                                          "child_mean_q", "child_window_q", "child_passed")]
+        s = Scores()
+        s.mean_q, s.window_q, s.passed, s.child_offsets = (keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data,
+                                                           keep[3].ctypes.data)
+        s.child_ranges, s.child_mean_q, s.child_window_q, s.child_passed = (keep[4].ctypes.data, keep[5].ctypes.data,
+                                                                          keep[6].ctypes.data, keep[7].ctypes.data)
+        s.child_capacity = s.n_children = nc
+        cap = n + nc
+        out = {"mean_q": np.zeros(cap, np.float64), "window_q": np.zeros(cap, np.float64), "length": np.zeros(cap, np.int32),
+               "passed": np.zeros(cap, np.uint8), "parent": np.zeros(cap, np.uint32), "child": np.zeros(cap, np.int64)}
+        n2 = C.c_uint64()
+        self._check(self.L.flx_reads2_gather(self.h, n, ln.ctypes.data, C.byref(s), cap, out["mean_q"].ctypes.data,
+                                             out["window_q"].ctypes.data, out["length"].ctypes.data, out["passed"].ctypes.data,
+                                             out["parent"].ctypes.data, out["child"].ctypes.data, C.byref(n2)))
+        return {k: v[:n2.value] for k, v in out.items()}
+
+    def reads2_gather_dev(self, n, d_lengths, scores, capacity, d_mean2, d_window2, d_length2, d_passed2, d_parent2=None,
+                          d_child2=None):
+        """flx_reads2_gather_dev: `scores` is a _lib.Scores with device pointers (as filled by score_kmer_dev); returns n2."""
+        n2 = C.c_uint64()
+        self._check(self.L.flx_reads2_gather_dev(self.h, n, d_lengths, C.byref(scores), capacity, d_mean2, d_window2,
+                                                 d_length2, d_passed2, d_parent2, d_child2, C.byref(n2)))
+        return int(n2.value)
+
     # ---- seam 3: rank + cut --------------------------------------------------------------------
     def rank_and_cut(self, mean_q, window_q, length, passed, length_weight=1.0, mean_q_weight=1.0,
                      window_q_weight=1.0, target_bases=None, keep_percent=None, total_bases=None,

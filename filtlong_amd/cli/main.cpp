@@ -581,7 +581,6 @@ int main(int argc, char **argv) {
     uint64_t n_scored = 0;
     if (flx_pipeline_finish(pipe, &res, &n_scored) != FLX_OK || n_scored != n) return fail_flx(ctx, "scoring");
     const double *mean_q = res.mean_q, *window_q = res.window_q, *c_mean = res.child_mean_q, *c_window = res.child_window_q;
-    const uint8_t *passed = res.passed, *c_passed = res.child_passed;
     const int32_t *c_ranges = res.child_ranges;
     const uint64_t *child_off = res.child_offsets;
     if (g_timing) fprintf(stderr, "[timing] %llu chunk(s) of <= %llu MiB\n", (unsigned long long)n_chunks, (unsigned long long)(chunk_bytes >> 20));
@@ -593,17 +592,25 @@ int main(int argc, char **argv) {
     std::vector<double> r2_mean, r2_window;
     std::vector<int32_t> r2_len;
     std::vector<uint8_t> r2_pass;
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint64_t a = child_off[i], b = child_off[i + 1];
-        const std::string name(names[i]);
-        if (a == b) {
-            reads2.push_back({lo_rec + i, 0, lengths[i], false, name});
-            r2_mean.push_back(mean_q[i]); r2_window.push_back(window_q[i]); r2_len.push_back(lengths[i]); r2_pass.push_back(passed[i]);
-        } else {
-            for (uint64_t k = a; k < b; ++k) {
-                const int s0 = c_ranges[2 * k], e0 = c_ranges[2 * k + 1];
-                reads2.push_back({lo_rec + i, s0, e0, true, name + "_" + std::to_string(s0 + 1) + "-" + std::to_string(e0)});  // read.cpp:135-136
-                r2_mean.push_back(c_mean[k]); r2_window.push_back(c_window[k]); r2_len.push_back(e0 - s0); r2_pass.push_back(c_passed[k]);
+    {
+        // the gather itself is the library's (flx_reads2_gather): values in reads2 order + where every entry came from
+        const uint64_t cap2 = n + res.n_children;
+        r2_mean.resize(cap2); r2_window.resize(cap2); r2_len.resize(cap2); r2_pass.resize(cap2);
+        std::vector<uint32_t> parent2(cap2);
+        std::vector<int64_t> child2(cap2);
+        uint64_t n2_gathered = 0;
+        if (flx_reads2_gather(ctx, n, lengths.data(), &res, cap2, r2_mean.data(), r2_window.data(), r2_len.data(), r2_pass.data(),
+                              parent2.data(), child2.data(), &n2_gathered) != FLX_OK)
+            return fail_flx(ctx, "reads2 gather");
+        r2_mean.resize(n2_gathered); r2_window.resize(n2_gathered); r2_len.resize(n2_gathered); r2_pass.resize(n2_gathered);
+        reads2.reserve(n2_gathered);
+        for (uint64_t j = 0; j < n2_gathered; ++j) {
+            const uint64_t i = parent2[j];
+            if (child2[j] < 0) {
+                reads2.push_back({lo_rec + i, 0, lengths[i], false, std::string(names[i])});
+            } else {
+                const int s0 = c_ranges[2 * child2[j]], e0 = c_ranges[2 * child2[j] + 1];
+                reads2.push_back({lo_rec + i, s0, e0, true, std::string(names[i]) + "_" + std::to_string(s0 + 1) + "-" + std::to_string(e0)});  // read.cpp:135-136
             }
         }
     }

@@ -2,12 +2,14 @@
 //
 // One process per GPU; every process holds one flx_ctx with one RCCL communicator.  The reference has no counterpart (it
 // is a single process, src/main.cpp:37-321); what is exchanged is what main.cpp:169-261 needs from ALL reads2 entries:
+//   * one small sum first: every rank's reads2 count + the bases of the reads passing the hard cut-offs (main.cpp:222-226);
 //   * ONE all-gather of the mean qualities (the statistics of main.cpp:170-196 are order-dependent folds over all of
-//     them; 8 bytes per entry; ncclAllGather when every rank holds the same count, else ncclBroadcast per root inside one
-//     group = all-gather with unequal counts);
+//     them; 8 bytes per entry; always ncclAllGather — unequal shards (children, a remainder) are padded to the largest
+//     count and packed by one kernel);
 //   * the 8 selection histograms (257 x u64) are ncclAllReduce'd on the device, on the context's stream, between the
 //     histogram kernel and the kernel that picks the next key byte — no host synchronisation per pass;
-//   * three small host-side sums (passed bases, band sizes, boundary-audit candidates);
+//   * ONE small host-side sum after the selection: band sizes + the boundary-audit candidates themselves (up to 32 per rank
+//     ride along; a larger band — a big group of near-equal scores — takes a second exchange);
 //   * only when the reference's own std::sort order over all reads has to decide (NaN scores, equal scores straddling
 //     the cut): all-gather of window / length / passed as well and the single-GPU stage replicated on every rank.
 //
@@ -28,7 +30,6 @@ struct RcclApi {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
-    decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -53,7 +54,6 @@ int load_rccl(flx_ctx *ctx) {
     FLX_SYM(CommInitRank, "ncclCommInitRank")
     FLX_SYM(CommDestroy, "ncclCommDestroy")
     FLX_SYM(AllReduce, "ncclAllReduce")
-    FLX_SYM(Broadcast, "ncclBroadcast")
     FLX_SYM(AllGather, "ncclAllGather")
     FLX_SYM(GroupStart, "ncclGroupStart")
     FLX_SYM(GroupEnd, "ncclGroupEnd")
@@ -136,11 +136,10 @@ int flx_comm_allreduce_u64_dev(flx_ctx *ctx, uint64_t *d_buf, uint64_t count) {
     return FLX_OK;
 }
 
-int flx_comm_allreduce_u64_host(flx_ctx *ctx, uint64_t *buf, uint64_t count) {
+static int comm_stage(flx_ctx *ctx, size_t bytes) {  // the small device staging buffer of host-visible sums (grow-only)
     flx_comm *c = ctx->comm;
-    if (!c) return flx_fail(ctx, FLX_ERR_STATE, "no communicator");
-    const size_t bytes = count * 8;
     if (bytes > c->stage_bytes) {
+        FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (c->stage) (void)hipFree(c->stage);
         c->stage = nullptr;
         c->stage_bytes = 0;
@@ -148,6 +147,14 @@ int flx_comm_allreduce_u64_host(flx_ctx *ctx, uint64_t *buf, uint64_t count) {
         FLX_HIP(ctx, hipMalloc(&c->stage, want));
         c->stage_bytes = want;
     }
+    return FLX_OK;
+}
+
+int flx_comm_allreduce_u64_host(flx_ctx *ctx, uint64_t *buf, uint64_t count) {
+    flx_comm *c = ctx->comm;
+    if (!c) return flx_fail(ctx, FLX_ERR_STATE, "no communicator");
+    const size_t bytes = count * 8;
+    FLX_CHECK(comm_stage(ctx, bytes));
     FLX_HIP(ctx, hipMemcpyAsync(c->stage, buf, bytes, hipMemcpyHostToDevice, ctx->stream));
     FLX_NCCL(ctx, g_rccl.AllReduce(c->stage, c->stage, count, ncclUint64, ncclSum, c->comm, ctx->stream));
     FLX_HIP(ctx, hipMemcpyAsync(buf, c->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -163,32 +170,58 @@ extern "C" int flx_comm_sum_u64(flx_ctx *ctx, uint64_t *buf, uint64_t count) {
 }
 
 // all-gather with per-rank counts: rank r's `elems[r]` elements of `esize` bytes land at offset sum(elems[0..r)) of recv.
-// Equal counts (a batch sharded evenly, the benchmark's case): ncclAllGather, RCCL's own multi-ring schedule over the
-// xGMI links.  Unequal counts (children, a remainder): one ncclBroadcast per root inside a group.
-static int allgather_v(flx_ctx *ctx, const void *d_send, void *d_recv, const std::vector<uint64_t> &elems, size_t esize) {
+// Always ONE ncclAllGather (RCCL's own multi-ring schedule over the xGMI links).  Equal counts (a batch sharded evenly,
+// the benchmark's case): straight into recv.  Unequal counts (children, a remainder): every rank contributes the LARGEST
+// count (the tail of a shorter shard is padding, never read), the slots land in `d_padded` and one kernel packs them.
+struct SegTable {
+    uint64_t begin[65];  // begin[r] = first packed element of rank r; begin[world] = total
+    int world;
+};
+
+__global__ void __launch_bounds__(256) k_pack_segments(const uint8_t *padded, uint8_t *packed, SegTable t, uint64_t slot_elems,
+                                                       uint32_t esize) {
+    const uint64_t total = t.begin[t.world];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        int r = 0;
+        while (i >= t.begin[r + 1]) ++r;
+        const uint64_t src = (uint64_t)r * slot_elems + (i - t.begin[r]);
+        if (esize == 8) ((uint64_t *)packed)[i] = ((const uint64_t *)padded)[src];
+        else if (esize == 4) ((uint32_t *)packed)[i] = ((const uint32_t *)padded)[src];
+        else packed[i] = padded[src];
+    }
+}
+
+static int allgather_v(flx_ctx *ctx, const void *d_send, void *d_recv, void *d_padded, void *d_send_pad,
+                       const std::vector<uint64_t> &elems, size_t esize) {
     flx_comm *c = ctx->comm;
-    bool equal = elems[0] > 0;
-    for (int r = 1; r < c->world; ++r) equal = equal && elems[r] == elems[0];
+    if (c->world > 64) return flx_fail(ctx, FLX_ERR_INVALID, "at most 64 ranks");
+    bool equal = true;
+    uint64_t slot = 0, total = 0;
+    for (int r = 0; r < c->world; ++r) {
+        equal = equal && elems[r] == elems[0];
+        slot = std::max<uint64_t>(slot, elems[r]);
+        total += elems[r];
+    }
+    if (total == 0) return FLX_OK;
     if (equal) {
-        FLX_NCCL(ctx, g_rccl.AllGather(d_send, d_recv, (size_t)elems[0] * esize, ncclUint8, c->comm, ctx->stream));
+        FLX_NCCL(ctx, g_rccl.AllGather(d_send, d_recv, (size_t)slot * esize, ncclUint8, c->comm, ctx->stream));
         return FLX_OK;
     }
-    FLX_NCCL(ctx, g_rccl.GroupStart());
-    uint64_t at = 0;
-    for (int r = 0; r < c->world; ++r) {
-        const size_t bytes = (size_t)elems[r] * esize;
-        if (bytes) {
-            char *dst = (char *)d_recv + at * esize;
-            const void *src = r == c->rank ? d_send : (const void *)dst;
-            ncclResult_t rr = g_rccl.Broadcast(src, dst, bytes, ncclUint8, r, c->comm, ctx->stream);
-            if (rr != ncclSuccess) {
-                (void)g_rccl.GroupEnd();
-                return flx_fail(ctx, FLX_ERR_STATE, "ncclBroadcast failed: %s", g_rccl.GetErrorString(rr));
-            }
-        }
-        at += elems[r];
+    // a shorter shard sends from a staging slot of full size (reading past the end of the caller's array is not ours to do)
+    const void *send = d_send;
+    if (elems[c->rank] < slot) {
+        if (elems[c->rank])
+            FLX_HIP(ctx, hipMemcpyAsync(d_send_pad, d_send, (size_t)elems[c->rank] * esize, hipMemcpyDeviceToDevice, ctx->stream));
+        send = d_send_pad;
     }
-    FLX_NCCL(ctx, g_rccl.GroupEnd());
+    FLX_NCCL(ctx, g_rccl.AllGather(send, d_padded, (size_t)slot * esize, ncclUint8, c->comm, ctx->stream));
+    SegTable t;
+    t.world = c->world;
+    t.begin[0] = 0;
+    for (int r = 0; r < c->world; ++r) t.begin[r + 1] = t.begin[r] + elems[r];
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((total + 255) / 256, 4096));
+    hipLaunchKernelGGL(k_pack_segments, dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t *)d_padded, (uint8_t *)d_recv, t, slot,
+                       (uint32_t)esize);
     return FLX_OK;
 }
 
@@ -207,20 +240,38 @@ extern "C" int flx_rank_and_cut_comm_dev(flx_ctx *ctx, uint64_t n_local, const v
     FLX_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
 
-    // shard sizes (reads2 entries per rank: children make them unequal)
-    std::vector<uint64_t> counts((size_t)c->world, 0);
-    counts[c->rank] = n_local;
-    FLX_CHECK(flx_comm_allreduce_u64_host(ctx, counts.data(), counts.size()));
-    uint64_t n_total = 0, first = 0;
+    // shard sizes (reads2 entries per rank: children make them unequal) and the bases of the reads that pass the hard
+    // cut-offs (main.cpp:222-226), all ranks, in ONE host-visible sum
+    std::vector<uint64_t> counts((size_t)c->world + 1, 0);
+    {
+        const size_t bytes = counts.size() * 8;
+        FLX_CHECK(comm_stage(ctx, bytes));
+        uint64_t *d_stage = (uint64_t *)c->stage;
+        counts[c->rank] = n_local;
+        FLX_HIP(ctx, hipMemcpyAsync(d_stage, counts.data(), bytes, hipMemcpyHostToDevice, st));
+        if (n_local) FLX_CHECK(flx_passed_bases_async(ctx, n_local, (const int32_t *)d_length, (const uint8_t *)d_passed, d_stage + c->world));
+        flx_time_begin(ctx, "flx_comm_counts");
+        ncclResult_t r = g_rccl.AllReduce(d_stage, d_stage, counts.size(), ncclUint64, ncclSum, c->comm, st);
+        flx_time_end(ctx);
+        if (r != ncclSuccess) return flx_fail(ctx, FLX_ERR_STATE, "ncclAllReduce failed: %s", g_rccl.GetErrorString(r));
+        FLX_HIP(ctx, hipMemcpyAsync(counts.data(), d_stage, bytes, hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+    }
+    const uint64_t passed_bases = counts[c->world];
+    counts.resize((size_t)c->world);
+    uint64_t n_total = 0, first = 0, slot = 0;
     for (int r = 0; r < c->world; ++r) {
         if (r == c->rank) first = n_total;
         n_total += counts[r];
+        slot = std::max<uint64_t>(slot, counts[r]);
     }
     if (n_total > 0xffffffffull) return flx_fail(ctx, FLX_ERR_INVALID, "at most 2^32-1 reads");
 
     // gather buffer: [mean f64 | window f64 | length i32 | passed u8] x n_total (only the first part is filled unless the
-    // replicated fallback is needed)
-    const size_t need = n_total * 21 + 64;
+    // replicated fallback is needed) + the padded slots of an all-gather with unequal counts + one send slot
+    const size_t rec_bytes = (n_total * 21 + 255) & ~(size_t)255;
+    const size_t pad_bytes = ((size_t)c->world * slot * 8 + 255) & ~(size_t)255;
+    const size_t need = rec_bytes + pad_bytes + slot * 8 + 64;
     if (need > c->gather_bytes) {
         FLX_HIP(ctx, hipStreamSynchronize(st));
         if (c->gather) (void)hipFree(c->gather);
@@ -233,22 +284,24 @@ extern "C" int flx_rank_and_cut_comm_dev(flx_ctx *ctx, uint64_t n_local, const v
     double *g_win = g_mean + n_total;
     int32_t *g_len = (int32_t *)(g_win + n_total);
     uint8_t *g_pass = (uint8_t *)(g_len + n_total);
+    void *g_padded = (char *)c->gather + rec_bytes;
+    void *g_sendpad = (char *)g_padded + pad_bytes;
 
     flx_time_begin(ctx, "flx_comm_allgather_means");
-    int rc = allgather_v(ctx, d_mean_q, g_mean, counts, 8);
+    int rc = allgather_v(ctx, d_mean_q, g_mean, g_padded, g_sendpad, counts, 8);
     flx_time_end(ctx);
     FLX_CHECK(rc);
 
     rc = flx_rank_and_cut_sharded_comm(ctx, n_total, g_mean, first, n_local, (const double *)d_window_q, (const int32_t *)d_length,
                                        (uint8_t *)d_passed, lw, mw, ww, target_bases_set, target_bases, keep_percent_set,
-                                       keep_percent, total_bases, d_final_score, c->rank, c->world, rep);
+                                       keep_percent, total_bases, d_final_score, c->rank, c->world, passed_bases, rep);
     if (rc != FLX_NEED_REPLICATED) return rc;
 
     // the reference's own std::sort order over ALL reads decides: every record to every rank, single-GPU stage replicated
     flx_time_begin(ctx, "flx_comm_allgather_records");
-    rc = allgather_v(ctx, d_window_q, g_win, counts, 8);
-    if (rc == FLX_OK) rc = allgather_v(ctx, d_length, g_len, counts, 4);
-    if (rc == FLX_OK) rc = allgather_v(ctx, d_passed, g_pass, counts, 1);
+    rc = allgather_v(ctx, d_window_q, g_win, g_padded, g_sendpad, counts, 8);
+    if (rc == FLX_OK) rc = allgather_v(ctx, d_length, g_len, g_padded, g_sendpad, counts, 4);
+    if (rc == FLX_OK) rc = allgather_v(ctx, d_passed, g_pass, g_padded, g_sendpad, counts, 1);
     flx_time_end(ctx);
     FLX_CHECK(rc);
     flx_dbuf d_fs;

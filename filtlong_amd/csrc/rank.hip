@@ -384,6 +384,8 @@ struct Shard {
     bool use_comm = false;
     uint64_t first = 0;
     int rank = 0, world = 1;
+    bool have_passed_bases = false;  // comm.hip sums them together with the shard sizes
+    uint64_t passed_bases = 0;
     bool sharded() const { return reduce != nullptr || use_comm; }
     // sum of a HOST buffer over all ranks
     int sum(flx_ctx *ctx, uint64_t *buf, uint64_t count) const {
@@ -543,25 +545,11 @@ static int cut_by_select(flx_ctx *ctx, uint64_t n, const double *mean, const dou
     FLX_HIP(ctx, hipMemcpyAsync(h_acc, d_acc, 16, hipMemcpyDeviceToHost, st));
     FLX_HIP(ctx, hipStreamSynchronize(st));
     const unsigned local_n = (unsigned)(h_acc[0] & 0xffffffffull);
-    // band sizes of every rank (own slot filled, the rest zero) + the weight in front of the band, in one sum
-    std::vector<uint64_t> counts((size_t)sh.world + 1, 0);
-    counts[sh.rank] = local_n;
-    counts[sh.world] = h_acc[1];
-    FLX_CHECK(sh.sum(ctx, counts.data(), counts.size()));
-    uint64_t band_total = 0, my_at = 0;
-    for (int r = 0; r < sh.world; ++r) {
-        if (r == sh.rank) my_at = band_total;
-        band_total += counts[r];
-    }
-    const long long weight_before = (long long)counts[sh.world];
-    if (band_total > cap) {  // huge tie group (e.g. millions of duplicate reads): let the sort path handle it
-        tsel.end();
-        return sh.sharded() ? FLX_NEED_REPLICATED : FLX_SELECT_BAND_TOO_LARGE;
-    }
-    const unsigned band_n = (unsigned)band_total;
     // the band's records in ONE gather kernel + ONE copy; exact scores with the host libm (what the reference computes)
-    std::vector<BandRec> recs(local_n);
-    if (local_n) {
+    // (a rank whose own band already exceeds the capacity gathers nothing but still takes part in the sum below: every rank
+    // must issue the same exchanges, and the summed sizes then send all of them to the sort path together)
+    std::vector<BandRec> recs(local_n <= cap ? local_n : 0);
+    if (local_n && local_n <= cap) {
         hipLaunchKernelGGL(k_band_gather, dim3((local_n + 255) / 256), dim3(256), 0, st, local_n, band_idx, keys, mean, window,
                            length, passed, d_recs);
         FLX_HIP(ctx, hipMemcpyAsync(recs.data(), d_recs, (size_t)local_n * sizeof(BandRec), hipMemcpyDeviceToHost, st));
@@ -569,18 +557,48 @@ static int cut_by_select(flx_ctx *ctx, uint64_t n, const double *mean, const dou
         std::sort(recs.begin(), recs.end(), [](const BandRec &x, const BandRec &y) { return x.idx < y.idx; });
     }
     // five words per candidate: global reads2 index, key, exact score bits, length, pre-cut flag
-    std::vector<uint64_t> wire((size_t)band_n * 5, 0);
-    for (unsigned i = 0; i < local_n; ++i) {
-        const BandRec &b = recs[i];
+    auto put = [&](uint64_t *w, const BandRec &b) {
         const double sc = host_final_score(b.len, b.mean, b.window, s);
-        uint64_t *w = &wire[(my_at + i) * 5];
         w[0] = sh.first + b.idx;
         w[1] = b.key;
         memcpy(&w[2], &sc, 8);
         w[3] = (uint64_t)(uint32_t)b.len;
         w[4] = b.was_passed;
+    };
+    // ONE sum carries the band sizes of every rank (own slot filled, the rest zero), the weight in front of the band and,
+    // in fixed slots of kInline candidates per rank, the candidates themselves — the band is a 1e-11 neighbourhood of the
+    // crossing score, normally a handful of reads.  Only a rank with more than kInline members forces a second exchange.
+    const unsigned kInline = 32;
+    const size_t head = (size_t)sh.world + 1;
+    std::vector<uint64_t> counts(head + (sh.sharded() ? (size_t)sh.world * kInline * 5 : 0), 0);
+    counts[sh.rank] = local_n;
+    counts[sh.world] = h_acc[1];
+    if (sh.sharded() && local_n <= kInline)
+        for (unsigned i = 0; i < local_n; ++i) put(&counts[head + ((size_t)sh.rank * kInline + i) * 5], recs[i]);
+    FLX_CHECK(sh.sum(ctx, counts.data(), counts.size()));
+    uint64_t band_total = 0, my_at = 0;
+    bool all_inline = sh.sharded();
+    for (int r = 0; r < sh.world; ++r) {
+        if (r == sh.rank) my_at = band_total;
+        band_total += counts[r];
+        if (counts[r] > kInline) all_inline = false;
     }
-    FLX_CHECK(sh.sum(ctx, wire.data(), wire.size()));
+    const long long weight_before = (long long)counts[sh.world];
+    if (band_total > cap) {  // huge tie group (e.g. millions of duplicate reads): let the sort path handle it
+        tsel.end();
+        return sh.sharded() ? FLX_NEED_REPLICATED : FLX_SELECT_BAND_TOO_LARGE;
+    }
+    const unsigned band_n = (unsigned)band_total;
+    std::vector<uint64_t> wire((size_t)band_n * 5, 0);
+    if (all_inline) {
+        uint64_t at = 0;
+        for (int r = 0; r < sh.world; ++r)
+            for (uint64_t i = 0; i < counts[r]; ++i, ++at)
+                memcpy(&wire[at * 5], &counts[head + ((size_t)r * kInline + i) * 5], 40);
+    } else {
+        for (unsigned i = 0; i < local_n; ++i) put(&wire[(my_at + i) * 5], recs[i]);
+        FLX_CHECK(sh.sum(ctx, wire.data(), wire.size()));
+    }
     std::vector<Cand> cand(band_n);
     for (unsigned i = 0; i < band_n; ++i) {
         const uint64_t *w = &wire[(size_t)i * 5];
@@ -781,6 +799,14 @@ static int cut_by_sort(flx_ctx *ctx, uint64_t n, const double *mean, const doubl
 }
 
 
+int flx_passed_bases_async(flx_ctx *ctx, uint64_t n, const int32_t *d_length, const uint8_t *d_passed, uint64_t *d_out) {
+    if (n == 0) return FLX_OK;
+    TimeScope t(ctx, "flx_rank_passed_bases");
+    hipLaunchKernelGGL(k_passed_bases, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1024)), dim3(256), 0, ctx->stream, n,
+                       d_length, d_passed, (unsigned long long *)d_out);
+    return FLX_OK;
+}
+
 // Global stage on one rank's view: statistics over ALL reads2 entries (mean_all[0, n_total)), everything else on the
 // local entries [sh.first, sh.first + n).  Single rank: n == n_total, sh.first == 0, no exchange.
 static int rank_and_cut_impl(flx_ctx *ctx, uint64_t n_total, const double *mean_all, uint64_t n, const double *window,
@@ -819,17 +845,16 @@ static int rank_and_cut_impl(flx_ctx *ctx, uint64_t n_total, const double *mean_
         void *scr;
         FLX_CHECK(flx_scratch(ctx, 64, &scr));
         unsigned long long *d_acc = (unsigned long long *)scr;
-        FLX_HIP(ctx, hipMemsetAsync(d_acc, 0, 8, st));
-        {
-            TimeScope t(ctx, "flx_rank_passed_bases");
-            hipLaunchKernelGGL(k_passed_bases, dim3(1024), dim3(256), 0, st, n, length, passed, d_acc);
+        unsigned long long passed_bases = sh.passed_bases;
+        if (!sh.have_passed_bases) {
+            FLX_HIP(ctx, hipMemsetAsync(d_acc, 0, 8, st));
+            FLX_CHECK(flx_passed_bases_async(ctx, n, length, passed, (uint64_t *)d_acc));
+            FLX_HIP(ctx, hipMemcpyAsync(&passed_bases, d_acc, 8, hipMemcpyDeviceToHost, st));
+            FLX_HIP(ctx, hipStreamSynchronize(st));
+            uint64_t pb = passed_bases;
+            FLX_CHECK(sh.sum(ctx, &pb, 1));
+            passed_bases = pb;
         }
-        unsigned long long passed_bases = 0;
-        FLX_HIP(ctx, hipMemcpyAsync(&passed_bases, d_acc, 8, hipMemcpyDeviceToHost, st));
-        FLX_HIP(ctx, hipStreamSynchronize(st));
-        uint64_t pb = passed_bases;
-        FLX_CHECK(sh.sum(ctx, &pb, 1));
-        passed_bases = pb;
         target = compute_target(target_bases_set, target_bases, keep_percent_set, keep_percent, total_bases);
         rep->target_bases = target;
         if (target >= total_bases) rep->outcome = FLX_CUT_NOT_ENOUGH;
@@ -910,10 +935,11 @@ int flx_rank_and_cut_sharded_comm(flx_ctx *ctx, uint64_t n_total, const double *
                                   const double *d_window, const int32_t *d_length, uint8_t *d_passed, double lw, double mw,
                                   double ww, int target_bases_set, int64_t target_bases, int keep_percent_set,
                                   double keep_percent, int64_t total_bases, void *d_final_score, int rank, int world,
-                                  flx_cut_report *rep) {
+                                  uint64_t passed_bases_all_ranks, flx_cut_report *rep) {
     memset(rep, 0, sizeof *rep);
     Shard sh;
     sh.use_comm = true; sh.first = first; sh.rank = rank; sh.world = world;
+    sh.have_passed_bases = true; sh.passed_bases = passed_bases_all_ranks;
     return rank_and_cut_impl(ctx, n_total, d_mean_all, n_local, d_window, d_length, d_passed, lw, mw, ww, target_bases_set,
                              target_bases, keep_percent_set, keep_percent, total_bases, d_final_score, rep, sh);
 }

@@ -31,4 +31,6 @@ int flx_rank_and_cut_sharded_comm(flx_ctx *ctx, uint64_t n_total, const double *
                                   const double *d_window, const int32_t *d_length, uint8_t *d_passed, double lw, double mw,
                                   double ww, int target_bases_set, int64_t target_bases, int keep_percent_set,
                                   double keep_percent, int64_t total_bases, void *d_final_score, int rank, int world,
-                                  flx_cut_report *rep);
+                                  uint64_t passed_bases_all_ranks, flx_cut_report *rep);
+// *d_out += sum of length[i] over passed[i] (main.cpp:222-226), in stream order
+int flx_passed_bases_async(flx_ctx *ctx, uint64_t n, const int32_t *d_length, const uint8_t *d_passed, uint64_t *d_out);

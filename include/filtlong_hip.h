@@ -143,6 +143,26 @@ int flx_score_batch_dev(flx_ctx *ctx, const flx_kmerset *set, const void *d_plan
                         const flx_params *params, flx_scores *out_dev);
 
 /* ------------------------------------------------------------------------------------------
+ * between seam 2 and seam 3 — the reads2 gather     (replaces src/main.cpp:138-147)
+ *
+ * reads2 = file order with every trimmed / split parent replaced IN PLACE by its children.  Gathers what the global
+ * stage reads (mean quality, window quality, length, pass flag) from the per-read and per-child outputs of
+ * flx_score_batch* into reads2 order: entry j is either read parent2[j] itself (child2[j] == -1) or its child number
+ * child2[j] (index into the child arrays; length = end - start of its range, src/read.cpp:131-137).  Without children
+ * (Phred mode, or no --trim / --split: scores->child_offsets NULL or n_children 0) reads2 is the reads themselves.
+ * `capacity` = room in the output arrays (n_reads + n_children always suffices); *n2 = number of entries
+ * (FLX_ERR_CAPACITY: *n2 is the capacity needed).  parent2 (uint32) and child2 (int64) may be NULL.
+ * _dev: every pointer (also those inside `scores`) is a device pointer; one scan + one scatter kernel on the
+ * context's stream.
+ * ---------------------------------------------------------------------------------------- */
+int flx_reads2_gather_dev(flx_ctx *ctx, uint64_t n_reads, const void *d_lengths, const flx_scores *scores_dev,
+                          uint64_t capacity, void *d_mean_q2, void *d_window_q2, void *d_length2, void *d_passed2,
+                          void *d_parent2, void *d_child2, uint64_t *n2);
+int flx_reads2_gather(flx_ctx *ctx, uint64_t n_reads, const int32_t *lengths, const flx_scores *scores, uint64_t capacity,
+                      double *mean_q2, double *window_q2, int32_t *length2, uint8_t *passed2, uint32_t *parent2,
+                      int64_t *child2, uint64_t *n2);
+
+/* ------------------------------------------------------------------------------------------
  * seam 3 — global rank + cut     (replaces src/main.cpp:169-261 + Read::set_final_score,
  *                                 src/read.cpp:249-267)
  *

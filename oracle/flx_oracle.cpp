@@ -388,6 +388,38 @@ extern "C" double flo_final_score(double length_score, double mean_q, double win
 }
 
 // ---------------------------------------------------------------------------
+// a19b  reads2 gather             (src/main.cpp:138-147)
+//   for (auto read : reads) { if (read->m_child_reads.size() == 0) reads2.push_back(read);
+//                             else for (auto child : read->m_child_reads) reads2.push_back(child); }
+//   a child's length is end - start of its range (src/read.cpp:131-137)
+// ---------------------------------------------------------------------------
+extern "C" uint64_t flo_reads2_gather(uint64_t n, const int32_t *length, const double *mean_q, const double *window_q,
+                                      const uint8_t *passed, const uint64_t *child_offsets, const int32_t *child_ranges,
+                                      const double *child_mean_q, const double *child_window_q,
+                                      const uint8_t *child_passed, double *mean_q2, double *window_q2, int32_t *length2,
+                                      uint8_t *passed2, uint32_t *parent2, int64_t *child2) {
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t a = child_offsets ? child_offsets[i] : 0, b = child_offsets ? child_offsets[i + 1] : 0;
+        if (a == b) {
+            mean_q2[at] = mean_q[i]; window_q2[at] = window_q[i]; length2[at] = length[i]; passed2[at] = passed[i];
+            if (parent2) parent2[at] = (uint32_t)i;
+            if (child2) child2[at] = -1;
+            ++at;
+        } else {
+            for (uint64_t k = a; k < b; ++k) {
+                mean_q2[at] = child_mean_q[k]; window_q2[at] = child_window_q[k];
+                length2[at] = child_ranges[2 * k + 1] - child_ranges[2 * k]; passed2[at] = child_passed[k];
+                if (parent2) parent2[at] = (uint32_t)i;
+                if (child2) child2[at] = (int64_t)k;
+                ++at;
+            }
+        }
+    }
+    return at;
+}
+
+// ---------------------------------------------------------------------------
 // a20-a25  global stage           (src/main.cpp:169-261)
 //   arrays are in reads2 order (file order, children in place of their parents,
 //   main.cpp:138-147).  mean_q / window_q are overwritten with the normalised

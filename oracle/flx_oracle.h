@@ -76,6 +76,15 @@ int flo_score_read(const flo_kmerset *set, const char *seq, const char *qual, in
                    flo_read_result *out, int32_t *bad_ranges, int32_t *child_ranges, flo_read_result *children,
                    int cap);
 
+/* a19b: reads2 = file order with every parent replaced in place by its children (src/main.cpp:138-147).
+ * child_offsets[n+1] is the CSR of the children (children of read i: child_offsets[i] .. child_offsets[i+1]-1, each with
+ * its (start,end) range).  Outputs hold n - #parents-with-children + #children entries; returns that count. */
+uint64_t flo_reads2_gather(uint64_t n, const int32_t *length, const double *mean_q, const double *window_q,
+                           const uint8_t *passed, const uint64_t *child_offsets, const int32_t *child_ranges,
+                           const double *child_mean_q, const double *child_window_q, const uint8_t *child_passed,
+                           double *mean_q2, double *window_q2, int32_t *length2, uint8_t *passed2, uint32_t *parent2,
+                           int64_t *child2);
+
 double flo_final_score(double length_score, double mean_q, double window_q, double lw, double mw, double ww);
 
 int flo_rank_and_cut(uint64_t n, double *mean_q, double *window_q, const int32_t *length, uint8_t *passed, double lw,

@@ -198,6 +198,27 @@ def score_read(seq, qual, params, kmerset=None, cap=4096):
     }
 
 
+def reads2_gather(lengths, sc):
+    """flo_reads2_gather on a score dictionary (keys as filtlong_amd.api.Context.score_reads returns them)."""
+    n = len(lengths)
+    ln = np.ascontiguousarray(lengths, dtype=np.int32)
+    dt = {"mean_q": np.float64, "window_q": np.float64, "passed": np.uint8, "child_offsets": np.uint64,
+          "child_ranges": np.int32, "child_mean_q": np.float64, "child_window_q": np.float64, "child_passed": np.uint8}
+    a = {k: np.ascontiguousarray(sc[k], dtype=t) for k, t in dt.items()}
+    cap = n + len(a["child_mean_q"])
+    out = {"mean_q": np.zeros(cap, np.float64), "window_q": np.zeros(cap, np.float64), "length": np.zeros(cap, np.int32),
+           "passed": np.zeros(cap, np.uint8), "parent": np.zeros(cap, np.uint32), "child": np.zeros(cap, np.int64)}
+    f = lib().flo_reads2_gather
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_uint64] + [C.c_void_p] * 15
+    n2 = f(n, ln.ctypes.data, a["mean_q"].ctypes.data, a["window_q"].ctypes.data, a["passed"].ctypes.data,
+           a["child_offsets"].ctypes.data, a["child_ranges"].ctypes.data, a["child_mean_q"].ctypes.data,
+           a["child_window_q"].ctypes.data, a["child_passed"].ctypes.data, out["mean_q"].ctypes.data,
+           out["window_q"].ctypes.data, out["length"].ctypes.data, out["passed"].ctypes.data, out["parent"].ctypes.data,
+           out["child"].ctypes.data)
+    return {k: v[:n2] for k, v in out.items()}
+
+
 def rank_and_cut(mean_q, window_q, length, passed, lw=1.0, mw=1.0, ww=1.0, target_bases=None, keep_percent=None,
                  total_bases=None):
     n = len(mean_q)

@@ -36,6 +36,9 @@ class OracleBackend:
             res.append(o)
         return res
 
+    def reads2(self, lengths, sc):
+        return _oracle.reads2_gather(lengths, sc)
+
     def rank(self, mean_q, window_q, length, passed, **kw):
         r = _oracle.rank_and_cut(mean_q, window_q, length, passed, **kw)
         return r["passed"], r["target_bases"], r["kept_bases"], r["outcome"]
@@ -85,6 +88,9 @@ class HipBackend:
             })
         return res
 
+    def reads2(self, lengths, sc):
+        return self.ctx.reads2_gather(lengths, sc)
+
     def rank(self, mean_q, window_q, length, passed, lw=1.0, mw=1.0, ww=1.0, **kw):
         r = self.ctx.rank_and_cut(mean_q, window_q, length, passed, length_weight=lw, mean_q_weight=mw,
                                   window_q_weight=ww, **kw)
@@ -96,22 +102,33 @@ def run_filter(backend, reads, ks, pkw=None, target_bases=None, keep_percent=Non
     """Returns (ordered output names, after_count, after_bases, target, kept, outcome) like the reference CLI."""
     pkw = pkw or {}
     scored = backend.score(reads, pkw, ks)
-    # reads2 gather, main.cpp:138-147; child names read.cpp:135-136
-    names, mean_q, window_q, length, passed = [], [], [], [], []
-    for (name, seq, qual), r in zip(reads, scored):
-        if not r["children"]:
-            names.append(name); mean_q.append(r["mean_q"]); window_q.append(r["window_q"])
-            length.append(len(seq)); passed.append(r["passed"])
+    # reads2 gather, main.cpp:138-147, through the backend's seam (oracle: flo_reads2_gather, HIP: flx_reads2_gather);
+    # child names read.cpp:135-136
+    lengths = np.array([len(seq) for _, seq, _ in reads], dtype=np.int32)
+    kids = [c for r in scored for c in r["children"]]
+    rngs = [x for r in scored for x in r["child_ranges"]]
+    sc = {"mean_q": np.array([r["mean_q"] for r in scored], dtype=np.float64),
+          "window_q": np.array([r["window_q"] for r in scored], dtype=np.float64),
+          "passed": np.array([r["passed"] for r in scored], dtype=np.uint8),
+          "child_offsets": np.concatenate([[0], np.cumsum([len(r["children"]) for r in scored])]).astype(np.uint64),
+          "child_ranges": np.array(rngs, dtype=np.int32).reshape(-1, 2),
+          "child_mean_q": np.array([c["mean_q"] for c in kids], dtype=np.float64),
+          "child_window_q": np.array([c["window_q"] for c in kids], dtype=np.float64),
+          "child_passed": np.array([c["passed"] for c in kids], dtype=np.uint8)}
+    r2 = backend.reads2(lengths, sc)
+    names = []
+    for par, ch in zip(r2["parent"], r2["child"]):
+        if ch < 0:
+            names.append(reads[par][0])
         else:
-            for (s, e), c in zip(r["child_ranges"], r["children"]):
-                names.append("%s_%d-%d" % (name, s + 1, e)); mean_q.append(c["mean_q"])
-                window_q.append(c["window_q"]); length.append(e - s); passed.append(c["passed"])
+            names.append("%s_%d-%d" % (reads[par][0], rngs[ch][0] + 1, rngs[ch][1]))
+    mean_q, window_q, length, passed = r2["mean_q"], r2["window_q"], r2["length"], r2["passed"]
     total_bases = sum(len(seq) for _, seq, _ in reads)  # original reads, main.cpp:89
     out_passed, target, kept, outcome = backend.rank(
         np.array(mean_q), np.array(window_q), np.array(length, dtype=np.int32), np.array(passed, dtype=np.uint8),
         lw=lw, mw=mw, ww=ww, target_bases=target_bases, keep_percent=keep_percent, total_bases=total_bases)
     out_names = [n for n, p in zip(names, out_passed) if p]
-    return out_names, len(names), int(sum(length)), int(target), int(kept), int(outcome)
+    return out_names, len(names), int(np.asarray(length, dtype=np.int64).sum()), int(target), int(kept), int(outcome)
 
 
 def golden_args_to_kwargs(args):

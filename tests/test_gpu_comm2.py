@@ -10,6 +10,8 @@ import os
 import subprocess
 import sys
 
+import zlib
+
 import numpy as np
 import pytest
 
@@ -73,7 +75,7 @@ CASES = [
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_multi_rank_stage_matches_single_gpu(tmp_path, shim, case):
     name, kind, n, world, fracs, kw = case
-    rng = np.random.RandomState(abs(hash(name)) % 2 ** 31)
+    rng = np.random.RandomState(zlib.crc32(name.encode()) % 2 ** 31)
     mean, window, length, passed = make_case(rng, n, kind)
     total = int(length.astype(np.int64).sum())
     kw = dict(kw)

@@ -197,7 +197,7 @@ def test_kmer_mode_properties(short_reads, size):
 
     # sampled exactness against the oracle (same generator on the host)
     rng = np.random.RandomState(3)
-    sample = np.unique(np.concatenate([rng.randint(0, n, 50), order[:3], order[-3:]]))
+    sample = np.unique(np.concatenate([rng.randint(0, n, 1000 if size == "full" else 300), order[:3], order[-3:]]))
     p = _oracle.make_params(**pkw)
     for i in sample:
         L = int(lengths[i])
@@ -210,5 +210,37 @@ def test_kmer_mode_properties(short_reads, size):
         for k, ch in enumerate(w["children"]):
             assert w["child_ranges"][k] == (int(crng[a + k, 0]), int(crng[a + k, 1])), (int(i), k)
             assert ch["mean_q"] == cmean[a + k] and ch["window_q"] == cwin[a + k] and ch["passed"] == cpass[a + k], (int(i), k)
+
+    # The global stage at this size (src/main.cpp:138-147 then 169-261): the device's reads2 gather equals the oracle's loop
+    # entry for entry, and on those reads2 arrays the ORACLE (its std::sort over all ~1.2x10^7 entries) gives the same
+    # statistics, kept bases and pass set as flx_rank_and_cut_dev.
+    cap2 = n + nchild
+    r2 = {k: torch.zeros(cap2, dtype=dt, device=dev) for k, dt in (
+        ("mean", torch.float64), ("win", torch.float64), ("len", torch.int32), ("pass", torch.uint8), ("parent", torch.int32),
+        ("child", torch.int64), ("fs", torch.float64))}
+    n2 = ctx.reads2_gather_dev(n, d_len.data_ptr(), s, cap2, r2["mean"].data_ptr(), r2["win"].data_ptr(), r2["len"].data_ptr(),
+                               r2["pass"].data_ptr(), r2["parent"].data_ptr(), r2["child"].data_ptr())
+    assert n2 == n - int((np.diff(coff) > 0).sum()) + nchild
+    sc = {"mean_q": mean, "window_q": win, "passed": t["pass"].cpu().numpy(), "child_offsets": coff.view(np.uint64),
+          "child_ranges": crng, "child_mean_q": cmean, "child_window_q": cwin, "child_passed": cpass}
+    w2 = _oracle.reads2_gather(lengths, sc)
+    assert len(w2["mean_q"]) == n2
+    g2 = {k: r2[k].cpu().numpy()[:n2] for k in r2}
+    assert (g2["mean"].view(np.uint64) == w2["mean_q"].view(np.uint64)).all()
+    assert (g2["win"].view(np.uint64) == w2["window_q"].view(np.uint64)).all()
+    assert (g2["len"] == w2["length"]).all() and (g2["pass"] == w2["passed"]).all()
+    assert (g2["parent"].view(np.uint32) == w2["parent"]).all() and (g2["child"] == w2["child"]).all()
+    total = int(lengths.astype(np.int64).sum())  # original reads, src/main.cpp:89
+    rep = ctx.rank_and_cut_dev(n2, r2["mean"].data_ptr(), r2["win"].data_ptr(), r2["len"].data_ptr(), r2["pass"].data_ptr(),
+                               target_bases=total // 2, total_bases=total, d_final_score=r2["fs"].data_ptr())
+    want = _oracle.rank_and_cut(w2["mean_q"], w2["window_q"], w2["length"], w2["passed"], target_bases=total // 2,
+                                total_bases=total)
+    assert rep.mean_quality == want["mean_quality"] and rep.stdev_quality == want["stdev_quality"]
+    assert rep.min_z == want["min_z"] and rep.max_z == want["max_z"]
+    assert rep.outcome == want["outcome"] and rep.target_bases == want["target_bases"] == total // 2
+    assert rep.kept_bases == want["kept_bases"]
+    final = r2["pass"].cpu().numpy()[:n2]
+    assert (final == want["passed"]).all()
+    assert np.allclose(r2["fs"].cpu().numpy()[:n2], want["final_score"], rtol=1e-12, atol=0, equal_nan=True)
     ks.close()
     ctx.close()

@@ -272,3 +272,49 @@ def test_prefilter_and_fold_variants_give_identical_results(be, synth, monkeypat
     assert len(base) == len(alt)
     for (name, _s, _q), a, b in zip(reads, base, alt):
         assert bits(a) == bits(b), name
+
+
+def test_reads2_gather_matches_oracle(ctx, be, synth):
+    """flx_reads2_gather / _dev (src/main.cpp:138-147) against the oracle's loop: parents replaced in place by their children,
+    a child's length = end - start; without children the reads themselves; capacity errors report the size needed."""
+    import ctypes as C
+    from filtlong_amd import _lib
+    reads = _cases.kmer_reads(synth["contigs"])
+    for pkw, ks in ((dict(trim=True, split=100), synth["asm"]), (dict(split=40), synth["short"]), (dict(), synth["asm"]),
+                    (dict(trim=True), None)):
+        p = api.make_params(**pkw)
+        strings = [(seq if ks is not None else qual) for _, seq, qual in reads]
+        plane, offsets, lengths = api.pack_reads(strings)
+        sc = ctx.score_reads(plane, offsets, lengths, p, kmers=ks, order=api.length_order(lengths))
+        got = ctx.reads2_gather(lengths, sc)
+        want = _oracle.reads2_gather(lengths, sc)
+        nc = len(sc["child_mean_q"])
+        assert (nc > 0) == (ks is not None and bool(pkw))
+        for k in ("mean_q", "window_q"):
+            assert (got[k].view(np.uint64) == want[k].view(np.uint64)).all(), (pkw, k)
+        for k in ("length", "passed", "parent", "child"):
+            assert (got[k] == want[k]).all(), (pkw, k)
+        n_parents = int((np.diff(sc["child_offsets"].astype(np.int64)) > 0).sum())
+        assert len(got["mean_q"]) == len(reads) - n_parents + nc
+        if nc:
+            # capacity too small: FLX_ERR_CAPACITY and the size needed
+            s = _lib.Scores()
+            keep = {k: np.ascontiguousarray(sc[k]) for k in sc}
+            s.mean_q, s.window_q, s.passed, s.child_offsets = (keep["mean_q"].ctypes.data, keep["window_q"].ctypes.data,
+                                                               keep["passed"].ctypes.data, keep["child_offsets"].ctypes.data)
+            s.child_ranges, s.child_mean_q, s.child_window_q, s.child_passed = (
+                keep["child_ranges"].ctypes.data, keep["child_mean_q"].ctypes.data, keep["child_window_q"].ctypes.data,
+                keep["child_passed"].ctypes.data)
+            s.n_children = s.child_capacity = nc
+            small = len(got["mean_q"]) - 1
+            o = [np.zeros(small, t) for t in (np.float64, np.float64, np.int32, np.uint8)]
+            n2 = C.c_uint64()
+            rc = ctx.L.flx_reads2_gather(ctx.h, len(reads), lengths.ctypes.data, C.byref(s), small, o[0].ctypes.data,
+                                         o[1].ctypes.data, o[2].ctypes.data, o[3].ctypes.data, None, None, C.byref(n2))
+            assert rc == 5 and n2.value == small + 1
+    # no reads at all
+    empty = {k: np.zeros(0, t) for k, t in (("mean_q", np.float64), ("window_q", np.float64), ("passed", np.uint8),
+                                            ("child_ranges", np.int32), ("child_mean_q", np.float64),
+                                            ("child_window_q", np.float64), ("child_passed", np.uint8))}
+    empty["child_offsets"] = np.zeros(1, np.uint64)
+    assert len(ctx.reads2_gather(np.zeros(0, np.int32), empty)["mean_q"]) == 0

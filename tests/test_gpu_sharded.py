@@ -205,3 +205,35 @@ def test_bench_rccl_stage_single_rank(tmp_path):
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         outs.append(np.load(path + ".rank0.npy"))
     assert (outs[0] == outs[1]).all() and 0 < int(outs[0].sum()) < len(outs[0])
+
+
+@pytest.mark.parametrize("shim", [True, False], ids=["library-communicator", "torch-sharded"])
+def test_bench_starts_its_own_ranks(tmp_path, shim):
+    """`python3 bench.py --gpus 2 ...` exactly as the driver types it (no torch.distributed.run in front, no WORLD_SIZE in
+    the environment): bench.py starts the two ranks itself, rank 0 prints ONE JSON line with n_gpus 2, and the flags of both
+    ranks equal the single-process run over the same 2 x 20 000 reads.  Two ranks on one GPU: the launch backend falls to
+    gloo by itself; with FLX_RCCL_LIB the library's own communicator runs over the loopback stand-in (tests/shim)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "FLX_RANK_SORT")}
+    if shim:
+        shim_dir = os.path.join(ROOT, "tests", "shim")
+        subprocess.check_call(["make", "-s", "-C", shim_dir])
+        env["FLX_RCCL_LIB"] = os.path.join(shim_dir, "libloopback_rccl.so")
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--reads", "40000",
+                        "--no-cpu-baseline", "--no-extras", "--dump-flags", one], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads",
+                        "20000", "--dump-flags", two], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["config"]["reads_total"] == 40000 and j["scaling"] == "weak"
+    assert j["config"]["launch_backend"] == "gloo" and "comm" in j["stage_ms_per_step"]
+    if shim:
+        assert j["config"]["rccl_ranks"] == 2 and "library-owned RCCL communicator" in j["config"]["parallelism"]
+    want = np.load(one + ".rank0.npy")
+    got = np.concatenate([np.load(two + ".rank%d.npy" % k) for k in range(2)])
+    assert want.shape == got.shape and (want == got).all() and 0 < int(want.sum()) < len(want)
