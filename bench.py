@@ -38,8 +38,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-RANDOM_REQ_PEAK_G = 55.0     # tools/randbench: random 4-byte reads from a table beyond the L2, G requests/s (64 B each)
-L2_LOOKUP_PEAK_G = 265.0     # tools/randbench: the same from an L2-resident table (<= 4 MiB)
+RANDOM_REQ_PEAK_G = 55.0     # tools/tabench: random requests beyond the L2 (Infinity Cache or HBM alike), G/s, 64 B each
+L2_LOOKUP_PEAK_G = 261.0     # tools/tabench: cache LINES per second from an L2-resident table (<= 4 MiB), however many lanes share a line
 REF_LEN = 5_000_000
 
 
@@ -124,6 +124,51 @@ def short_read_pairs(ref):
     return ref[idx], comp[ref[idx + 350]][:, ::-1]
 
 
+def end_to_end_cli(n_reads):
+    """File -> stdout through filtlong_amd/bin/filtlong vs oracle/_ref/filtlong (the reference binary) on the same FASTQ
+    (tools/gen_fastq: the synthetic Phred workload, ~20 kB per read), --target_bases = half the bases; timed here."""
+    import hashlib
+    gen = os.path.join(ROOT, "tools", "gen_fastq")
+    if not os.path.exists(gen):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "oracle"), "-o", gen,
+                               os.path.join(ROOT, "tools", "gen_fastq.cpp")])
+    ours = os.path.join(ROOT, "filtlong_amd", "bin", "filtlong")
+    ref = os.path.join(ROOT, "oracle", "_ref", "filtlong")
+    env = dict(os.environ, LANG="C", LC_ALL="C")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        fq = os.path.join(d, "reads.fastq")
+        bases = int(subprocess.run([gen, str(n_reads), fq], check=True, stdout=subprocess.PIPE).stdout.decode().split()[0])
+        size = os.path.getsize(fq)
+        target = str(bases // 2)
+
+        def run(binary, outp):
+            t = time.perf_counter()
+            with open(outp, "wb") as fo:
+                rc = subprocess.run([binary, "--target_bases", target, fq], stdout=fo, stderr=subprocess.DEVNULL, env=env).returncode
+            return time.perf_counter() - t, rc
+
+        def sha(path):
+            h = hashlib.sha256()
+            with open(path, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    h.update(blk)
+            return h.hexdigest()
+
+        run(ours, os.path.join(d, "a.out"))  # first run: device runtime start-up and page cache
+        t_ours, rc_ours = min(run(ours, os.path.join(d, "a.out")) for _ in range(2))
+        out = {"measured_in_this_run": True, "fastq_bytes": size, "reads": n_reads, "bases": bases, "target_bases": int(target),
+               "seconds": round(t_ours, 3), "gbases_per_s": round(bases / t_ours / 1e9, 3), "exit_code": rc_ours,
+               "stdout_bytes": os.path.getsize(os.path.join(d, "a.out")), "stdout_sha256": sha(os.path.join(d, "a.out"))[:16],
+               "pcie": "the streamed ingest moves 1 byte per base host -> device in pinned chunks (two slots)"}
+        if os.path.exists(ref):
+            t_ref, rc_ref = run(ref, os.path.join(d, "r.out"))
+            out.update({"reference_seconds": round(t_ref, 2), "reference_exit_code": rc_ref, "speedup": round(t_ref / t_ours, 1),
+                        "stdout_identical_to_reference": sha(os.path.join(d, "r.out"))[:16] == out["stdout_sha256"]})
+        return out
+
+
 class Batch:
     """The packed batch of one rank in HBM (layout, processing order, id range)."""
 
@@ -201,6 +246,7 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
         rep, nc, n2 = step()
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / steps
+    cover_kernel = "k_kmer_cover" if os.environ.get("FLX_KMER_COVER") == "v2" else "k_kmer_cover_w"
     cover_ms, cn = ctx.timing_get("flx_score_kmer_cover")
     fold_ms, _ = ctx.timing_get("flx_score_kmer_fold")
     rank_ms, _ = ctx.timing_get("flx_rank")
@@ -208,15 +254,17 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
     ctx.timing_enable(False)
     cover = cover_ms / max(cn, 1)
     lookups = b.bases - 15 * n
-    # far (beyond-L2) 64-byte requests of one k_kmer_cover launch: PMC pass of this same command (profiles/), when recorded
-    far = None
-    fpath = os.path.join(ROOT, "profiles", "r02_kmer_far_requests.json")
+    # requests of one cover launch by class: PMC pass of this same command (tools/prof_kmer.sh), recorded in profiles/ —
+    # per-position figures measured at 1e6 reads, scaled to this batch (the mix of reads is the same); NOT measured in this run
+    req = None
+    fpath = os.path.join(ROOT, "profiles", "r03_kmer_requests.json")
     if os.path.exists(fpath):
         rec = json.load(open(fpath)).get(cfg)
-        if rec:  # per-base figures measured at 1e6 reads, scaled to this batch (the mix of reads is the same)
-            far = {"far_requests": rec["far_requests_per_base"] * b.bases, "traffic_bytes": rec["traffic_bytes_per_base"] * b.bases,
+        if rec and rec.get("kernel") == cover_kernel:
+            req = {"far_requests": rec["far_requests_per_base"] * b.bases, "traffic_bytes": rec["traffic_bytes_per_base"] * b.bases,
                    "l2_hits": rec["l2_hit_requests_per_base"] * b.bases}
     algo_bytes = b.bases + 33 * n + 25 * nc  # L + 8 + 25 per read, 8 + 17 per child
+    achieved = algo_bytes / (cover * 1e-3) / 1e9
     out = {
         "workload": "%s: %s reads x gamma(k=4) mean 10 kbp from a 5 Mbp reference, %s, --target_bases %d" % (
             cfg.upper(), "{:,}".format(n),
@@ -227,20 +275,21 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
                               "reads2_gather_kernels": round(gather_ms / steps, 3), "rank_kernels": round(rank_ms / steps, 2)},
         "lookups_per_s_G": round(lookups / (cover * 1e-3) / 1e9, 2),
         "roofline": {
-            "bound": "hbm", "kernel": "k_kmer_cover",
-            "note": "not a streaming kernel: per position ONE random L2-hit lookup (2 MiB 12-mer prefilter) and, for candidates, a random "
-                    "64-byte fabric request into the 512 MiB exact bitmap; both go through the same vector-memory path.  `achieved` = far "
-                    "requests x 64 B / kernel time, `peak` = the measured random-request ceiling (tools/randbench: 55 G requests/s x 64 B); "
-                    "`l2_lookup_frac` = L2-hit lookups/s over the 265 G/s an L2-resident table delivers alone; both ceilings are "
-                    "approached at the same time, the classes overlap only partly (request counts from the PMC pass recorded in profiles/, not from this run).  The streamed bytes (SURVEY §8d, "
-                    "`algorithmic_bytes`) are %.1f %% of the 8 TB/s HBM peak over the whole step" % (
-                        100.0 * algo_bytes / el / 1e9 / HBM_PEAK_GBS),
-            "achieved": round(far["far_requests"] * 64 / (cover * 1e-3) / 1e9, 1) if far else None,
-            "peak": RANDOM_REQ_PEAK_G * 64, "unit": "GB/s",
-            "frac": round(far["far_requests"] / (cover * 1e-3) / 1e9 / RANDOM_REQ_PEAK_G, 4) if far else None,
-            "l2_lookup_frac": round(far["l2_hits"] / (cover * 1e-3) / 1e9 / L2_LOOKUP_PEAK_G, 4) if far else None,
-            "traffic": int(far["traffic_bytes"]) if far else None, "avg_kernel_ms": round(cover, 3),
-            "algorithmic_bytes": int(algo_bytes)},
+            # the contract's fraction: SURVEY §8(d) algorithmic bytes of the launch / kernel time / HBM peak
+            "bound": "hbm", "kernel": cover_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": int(req["traffic_bytes"]) if req else None,
+            "traffic_source": "profiles/r03_kmer_requests.json (PMC pass of this command at 1e6 reads, scaled; not this run)" if req else None,
+            "avg_kernel_ms": round(cover, 3), "algorithmic_bytes": int(algo_bytes),
+            # what actually bounds the kernel: random lookups, priced per cache line (tools/tabench, profiles/r03_microbench.txt):
+            # 261 G lines/s from an L2-resident table, 55 G/s beyond the L2, and the two classes add up
+            "request_model": None if not req else {
+                "l2_lines": int(req["l2_hits"]), "far_requests": int(req["far_requests"]),
+                "l2_lookup_frac": round(req["l2_hits"] / (cover * 1e-3) / 1e9 / L2_LOOKUP_PEAK_G, 4),
+                "far_request_frac": round(req["far_requests"] / (cover * 1e-3) / 1e9 / RANDOM_REQ_PEAK_G, 4),
+                "model_ms": round((req["l2_hits"] / L2_LOOKUP_PEAK_G + req["far_requests"] / RANDOM_REQ_PEAK_G) / 1e6, 2),
+                "note": "model_ms = l2_lines / 261 G/s + far_requests / 55 G/s: the kernel sits on the sum of its two request "
+                        "classes; the HBM-streaming fraction above is small because one 64-byte request serves two positions' "
+                        "lookups, not because bytes are wasted"}},
         "cut": {"target_bases": int(rep.target_bases), "kept_bases": int(rep.kept_bases), "outcome": int(rep.outcome)},
     }
     ks.close()
@@ -540,27 +589,19 @@ def main():
                 except Exception as e:  # an extra must not cost the headline line
                     extras[cfg] = {"error": repr(e)}
                 torch.cuda.empty_cache()
-            # (4) end to end (file -> stdout) through the C++ CLI: recorded by tools/bench_e2e_big.sh on a 20 GB FASTQ, not this run
-            epath = os.path.join(ROOT, "profiles", "r02_e2e_big.json")
-            if os.path.exists(epath):
-                e = json.load(open(epath))
-                extras["end_to_end_cli"] = {
-                    "source": "profiles/r02_e2e_big.json (tools/bench_e2e_big.sh on a GPU box; not measured in this run)",
-                    "fastq_bytes": e["fastq_bytes"], "bases": e["bases"], "gbases_per_s": round(e["e2e_gbases_per_s"], 3),
-                    "seconds": round(e["filtlong_amd_s"], 2), "reference_seconds": round(e["reference_s"], 1),
-                    "stdout_identical_to_reference": e["stdout_identical"], "peak_rss_anon_mib": e["peak_rss_anon_mib_at_stage_ends"],
-                    "pcie": "the streamed ingest moves 1 byte per base host -> device in pinned 1 GiB chunks (two slots); at the "
-                            "measured %.1f Gbases/s end to end the link carries %.1f GB/s of its ~55 GB/s: parse, pack and output "
-                            "on the host bound the run, not PCIe or the GPU" % (e["e2e_gbases_per_s"], e["e2e_gbases_per_s"])}
-            gpath = os.path.join(ROOT, "profiles", "r02_e2e_gz.json")
-            if os.path.exists(gpath):
-                e = json.load(open(gpath))
-                extras["end_to_end_cli_gzip"] = {
-                    "source": "profiles/r02_e2e_gz.json (tools/bench_e2e_gz.sh on a GPU box; not measured in this run)",
-                    "fastq_bytes": e["fastq_bytes"], "gz_bytes": e["gz_bytes"], "bases": e["bases"],
-                    "seconds": round(e["filtlong_amd_streamed_s"], 2), "reference_seconds": round(e["reference_s"], 1),
-                    "stdout_identical_to_reference": e["stdout_identical"], "peak_rss_anon_mib": e["peak_rss_anon_mib_streamed"],
-                    "note": e["note"]}
+            # (4) end to end (file -> stdout) through the C++ CLI, MEASURED IN THIS RUN: a 2 GB FASTQ of the same synthetic
+            #     Phred workload, the drop-in binary and the reference binary on the same file, stdout compared byte for byte
+            try:
+                extras["end_to_end_cli"] = end_to_end_cli(100_000)
+            except Exception as e:  # an extra must not cost the headline line
+                extras["end_to_end_cli"] = {"measured_in_this_run": False, "error": repr(e)}
+            # the 20 GB and gzip runs are too long for the default bench: recorded by tools/bench_e2e_big.sh / bench_e2e_gz.sh
+            for key, path in (("end_to_end_cli_20GB_recorded", "r02_e2e_big.json"), ("end_to_end_cli_gzip_recorded", "r02_e2e_gz.json")):
+                fp = os.path.join(ROOT, "profiles", path)
+                if os.path.exists(fp):
+                    e = json.load(open(fp))
+                    extras[key] = {"source": "profiles/%s (not measured in this run)" % path, "measured_in_this_run": False,
+                                   **{k: e[k] for k in e if k not in ("note",)}}
             out["extras"] = extras
         print(json.dumps(out), flush=True)
     if multi:

@@ -16,6 +16,43 @@ constexpr int kPrefilterBits = 24;
 __host__ __device__ inline uint32_t flx_sub12(uint32_t kmer16, int d) { return (kmer16 >> (2 * d)) & 0xFFFFFFu; }  // d = 0: last 12 bases
 const uint32_t *flx_kmerset_prefilter(const flx_kmerset *set);
 
+// ---- pair tables of the wave-level cover kernel (round 3) --------------------------------------------------------------
+// A random lookup is priced per distinct cache LINE an instruction touches, not per lane (tools/tabench: 261 G lines/s from
+// the L2 however many lanes share a line, 55 G/s beyond it), so both tables answer TWO consecutive positions with one byte:
+//
+// pre11  — the 12-mer prefilter keyed by the 11-mer C the 12-mers of positions i and i+1 share (x.C ends at i, C.y ends at
+//          i+1): bit x of the low nibble = "x.C occurs in a set member", bit 4+y = "C.y occurs".  That is every 12-mer twice
+//          (4 MiB); the table is folded onto CANONICAL 11-mers instead — an 11-mer and its reverse complement share a byte,
+//          the strand read off the middle base (A/C vs G/T: exactly one of the two strands has it in {A, C}) — which gives
+//          2 MiB again, still L2 resident.  Folding ORs the two strands' bits: a superset, and any superset of the present
+//          12-mers is a valid filter (no false negatives); the reference inserts both strands of every 16-mer anyway
+//          (src/kmers.cpp:109-120), so nothing is lost except around non-ACGT bases.
+// exact15 — exact membership keyed by the 15-mer C the 16-mers of positions i and i+1 share: bit x = "x.C is a member",
+//          bit 4+y = "C.y is a member" (1 GiB; every member sets two bits).  One 64-byte fabric request answers both.
+__host__ __device__ inline uint32_t flx_rc11(uint32_t c) {  // reverse complement of an 11-mer (22 bits, first base on top)
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r = __brev(c);
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((c >> i) & 1u) << (31 - i);
+#endif
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);  // bits inside every 2-bit group back in order
+    return (~r) >> 10;
+}
+// byte index and bit numbers of the two questions an 11-mer C answers: `even` = bit of x.C, `odd` = bit of C.y
+struct flx_pre11_slot { uint32_t index, even_bit, odd_bit; };
+__host__ __device__ inline flx_pre11_slot flx_pre11(uint32_t c, uint32_t x, uint32_t y) {
+    const uint32_t other = (c >> 11) & 1u;  // middle base (bits 11:10) is G or T: the byte belongs to the other strand
+    const uint32_t k = other ? flx_rc11(c) : c;
+    flx_pre11_slot s;
+    s.index = ((k >> 12) << 11) | (k & 0x7FFu);  // bit 11 of a canonical 11-mer is 0: dropped
+    s.even_bit = other ? 7u - x : x;             // RC(x.C) = RC(C).comp(x): a successor of the canonical strand
+    s.odd_bit = other ? 3u - y : 4u + y;         // RC(C.y) = comp(y).RC(C): a predecessor
+    return s;
+}
+const uint8_t *flx_kmerset_pre11(const flx_kmerset *set);    // 2 MiB or NULL (no prefilter: saturated, or switched off)
+const uint8_t *flx_kmerset_exact15(const flx_kmerset *set);  // 1 GiB
+
 int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_plane, uint64_t plane_bytes,
                        const uint64_t *d_offsets, const int32_t *d_lengths, const uint32_t *d_order,
                        uint64_t n_reads, const flx_params *params, flx_scores *out);

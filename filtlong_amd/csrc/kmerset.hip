@@ -125,6 +125,40 @@ __global__ void __launch_bounds__(256) k_build_prefilter(const uint32_t *bm, uin
     }
 }
 
+// pre11 from the 12-mer presence bits: every present 12-mer Y = x.C = C'.y marks the byte of C (as predecessor x) and of C'
+// (as successor y) — kmerset.h
+__global__ void __launch_bounds__(256) k_build_pre11(const uint32_t *pre12, uint32_t *pre11_words) {
+    const uint32_t n_words = 1u << (kPrefilterBits - 5);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += gridDim.x * blockDim.x) {
+        uint32_t w = pre12[i];
+        while (w) {
+            const int b = __ffs(w) - 1;
+            w &= w - 1;
+            const uint32_t y12 = (i << 5) | (uint32_t)b;
+            const flx_pre11_slot a = flx_pre11(y12 & 0x3FFFFFu, y12 >> 22, 0);  // x.C
+            atomicOr(&pre11_words[a.index >> 2], (1u << a.even_bit) << ((a.index & 3u) * 8));
+            const flx_pre11_slot c = flx_pre11(y12 >> 2, 0, y12 & 3u);          // C'.y
+            atomicOr(&pre11_words[c.index >> 2], (1u << c.odd_bit) << ((c.index & 3u) * 8));
+        }
+    }
+}
+
+// exact15 from the membership bitmap: member K = x.C15 = C15'.y sets bit x of byte C15 and bit 4+y of byte C15'
+__global__ void __launch_bounds__(256) k_build_exact15(const uint32_t *bm, uint64_t n_words, uint32_t *ex_words) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t w = bm[i];
+        while (w) {
+            const int b = __ffs(w) - 1;
+            w &= w - 1;
+            const uint32_t k = (uint32_t)(i << 5) | (uint32_t)b;
+            const uint32_t c = k & 0x3FFFFFFFu, x = k >> 30;
+            atomicOr(&ex_words[c >> 2], (1u << x) << ((c & 3u) * 8));
+            const uint32_t c2 = k >> 2, y = k & 3u;
+            atomicOr(&ex_words[c2 >> 2], (16u << y) << ((c2 & 3u) * 8));
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_popcount(const uint32_t *bm, uint64_t n_words, unsigned long long *out) {
     unsigned long long acc = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x)
@@ -247,6 +281,8 @@ struct flx_kmerset {
     uint32_t *asm_only = nullptr;       // copy of `present` taken when the first short reads arrive (512 MiB)
     uint32_t *seen1 = nullptr, *seen2 = nullptr, *seen3 = nullptr;
     uint32_t *prefilter = nullptr;      // 2 MiB, built at finalize (kmerset.h)
+    uint32_t *pre11 = nullptr;          // 2 MiB: the same filter, two positions per byte (kmerset.h)
+    uint32_t *exact15 = nullptr;        // 1 GiB: exact membership, two positions per byte
     // short-read sequences kept on the device until finalize (only replayed if Bloom candidates exist)
     struct Batch {
         uint8_t *bases;
@@ -262,6 +298,8 @@ struct flx_kmerset {
 bool flx_kmerset_is_final(const flx_kmerset *set) { return set->final_; }
 const uint32_t *flx_kmerset_bitmap(const flx_kmerset *set) { return set->present; }
 const uint32_t *flx_kmerset_prefilter(const flx_kmerset *set) { return set->prefilter; }
+const uint8_t *flx_kmerset_pre11(const flx_kmerset *set) { return (const uint8_t *)set->pre11; }
+const uint8_t *flx_kmerset_exact15(const flx_kmerset *set) { return (const uint8_t *)set->exact15; }
 
 extern "C" int flx_kmerset_create(flx_ctx *ctx, flx_kmerset **out) {
     if (!ctx || !out) return FLX_ERR_INVALID;
@@ -292,7 +330,7 @@ extern "C" void flx_kmerset_destroy(flx_kmerset *s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     free_batches(s);
-    for (uint32_t *p : {s->present, s->asm_only, s->seen1, s->seen2, s->seen3, s->prefilter})
+    for (uint32_t *p : {s->present, s->asm_only, s->seen1, s->seen2, s->seen3, s->prefilter, s->pre11, s->exact15})
         if (p) (void)hipFree(p);
     delete s;
 }
@@ -553,6 +591,16 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
         FLX_HIP(ctx, hipMalloc((void **)&s->prefilter, pf_bytes));
         FLX_HIP(ctx, hipMemsetAsync(s->prefilter, 0, pf_bytes, st));
         hipLaunchKernelGGL(k_build_prefilter, dim3(8192), dim3(256), 0, st, s->present, kBitmapWords, s->prefilter);
+        FLX_HIP(ctx, hipMalloc((void **)&s->pre11, (size_t)2 << 20));
+        FLX_HIP(ctx, hipMemsetAsync(s->pre11, 0, (size_t)2 << 20, st));
+        hipLaunchKernelGGL(k_build_pre11, dim3(2048), dim3(256), 0, st, s->prefilter, s->pre11);
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+    }
+    if (sz > 0) {  // the pair form of the exact bitmap (what the cover kernel asks)
+        hipError_t e = hipMalloc((void **)&s->exact15, (size_t)1 << 30);
+        if (e != hipSuccess) return flx_fail(ctx, FLX_ERR_NOMEM, "k-mer pair table (1 GiB): %s", hipGetErrorString(e));
+        FLX_HIP(ctx, hipMemsetAsync(s->exact15, 0, (size_t)1 << 30, st));
+        hipLaunchKernelGGL(k_build_exact15, dim3(8192), dim3(256), 0, st, s->present, kBitmapWords, s->exact15);
         FLX_HIP(ctx, hipStreamSynchronize(st));
     }
     s->final_ = true;

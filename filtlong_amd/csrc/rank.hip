@@ -28,6 +28,8 @@
 #include <limits>
 #include <numeric>
 
+#include <thread>
+
 #include "flx_internal.h"
 #include "rank_internal.h"
 
@@ -349,14 +351,30 @@ static int exact_host_cut(flx_ctx *ctx, uint64_t n, const double *d_mean, const 
     FLX_HIP(ctx, hipMemcpy(mean.data(), d_mean, n * 8, hipMemcpyDeviceToHost));
     FLX_HIP(ctx, hipMemcpy(window.data(), d_window, n * 8, hipMemcpyDeviceToHost));
     FLX_HIP(ctx, hipMemcpy(len.data(), d_length, n * 4, hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < n; ++i) fs[i] = host_final_score(len[i], mean[i], window[i], s);
-    std::vector<uint64_t> order(n);
-    std::iota(order.begin(), order.end(), 0ull);
-    const double *f = fs.data();
-    std::sort(order.begin(), order.end(), [f](uint64_t a, uint64_t b) { return f[a] > f[b]; });
+    // exact scores with the host libm (three pow calls per read, src/read.cpp:252-254): independent per read -> all host threads
+    {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned nt = (unsigned)std::min<uint64_t>(hw, std::max<uint64_t>(1, n / 65536));
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t)
+            pool.emplace_back([&, t]() {
+                for (uint64_t i = n * t / nt; i < n * (t + 1) / nt; ++i) fs[i] = host_final_score(len[i], mean[i], window[i], s);
+            });
+        for (auto &th : pool) th.join();
+    }
+    // The reference sorts its vector<Read*> in reads2 order with libstdc++'s std::sort and a comparator on the scores
+    // (src/main.cpp:247-248).  The permutation introsort produces is a function of the comparison OUTCOMES only, not of the
+    // element type, so sorting (score, index) records in the same initial order gives the reference's order — without the
+    // pointer chase per comparison (10^7 reads: 0.8 s instead of 3.5 s).  No cheaper route exists: the order inside a tie
+    // group depends on the whole run of the algorithm (tools/tie_order_probe.cpp: a pre-sorted input, the stable order and its
+    // reverse each keep a different member set than the reference in > 99 % of inputs with a tie group at the cut).
+    struct Rec { double score; uint32_t idx; };
+    std::vector<Rec> order(n);
+    for (uint64_t i = 0; i < n; ++i) order[i] = Rec{fs[i], (uint32_t)i};
+    std::sort(order.begin(), order.end(), [](const Rec &a, const Rec &b) { return a.score > b.score; });
     long long so_far = 0;
     for (uint64_t k = 0; k < n; ++k) {
-        const uint64_t i = order[k];
+        const uint64_t i = order[k].idx;
         if (passed[i] && so_far < target) so_far += len[i];
         else passed[i] = 0;
     }
@@ -882,6 +900,11 @@ static int rank_and_cut_impl(flx_ctx *ctx, uint64_t n_total, const double *mean_
     }
 
     {
+        const char *x = getenv("FLX_RANK_EXACT");  // test / bench hook: take the tie fallback (the reference's std::sort on the host)
+        if (x && x[0] == '1') {
+            if (sh.sharded()) return FLX_NEED_REPLICATED;
+            return exact_host_cut(ctx, n, mean, window, length, passed, nullptr, nullptr, s, target, rep);
+        }
         const char *e = getenv("FLX_RANK_SORT");  // test hook / fallback selector
         if (e && e[0] == '1') {
             if (sh.sharded()) return FLX_NEED_REPLICATED;  // the sort path wants every record on one device

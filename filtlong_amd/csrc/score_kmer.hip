@@ -22,6 +22,10 @@
 #include "kmerset.h"
 #include "rank_internal.h"
 
+#ifndef FLX_FARFIRST_LANES
+#define FLX_FARFIRST_LANES 32  // settled lanes of a span from which the next span asks the exact table first (score_kmer.hip, below)
+#endif
+
 namespace {
 
 // The 2-bit codes of the four bases of a dword (src/kmers.cpp:176-196: C/c 1, G/g 2, T/t 3, anything else 0) packed into 8
@@ -241,6 +245,226 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
             last[rid] = c ? l : -1;
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// coverage, wave level (round 3) — the kernel that runs; k_kmer_cover above stays as the second implementation
+// (FLX_KMER_COVER=v2, cross-checked in the tests)
+// ---------------------------------------------------------------------------------------------------
+// One WAVEFRONT owns a read and walks it left to right in spans of 1024 positions; a lane owns 16 consecutive positions
+// (one 16-byte load, prefetched one span ahead).  No LDS, no barrier: the left neighbour's bases / 12-mer bits / last
+// candidate travel by __shfl_up, lane 63's by a wave-uniform carry into the next span, and the coverage of a span is
+// written one span late, when the hits of its right neighbour are known.
+//
+// What a lookup costs (tools/tabench, profiles/r03_microbench.txt): one distinct cache LINE per instruction — 261 G/s
+// from the L2, 55 G/s beyond it, the two classes add up — so the kernel is built around lines, not lanes:
+//   * prefilter: ONE byte of `pre11` answers the 12-mers of two consecutive positions (kmerset.h): 8 loads per lane;
+//   * exact membership: ONE byte of `exact15` answers the 16-mers of two consecutive positions: a far request per PAIR;
+//   * which pairs are asked: a base is covered iff ANY 16-mer over it is a member, and two confirmed members inside a
+//     lane's window of 17 positions (its own 16 + the left neighbour's last) are at most 16 apart, so together they cover
+//     everything a candidate between them could.  Only the OUTERMOST members matter: search the candidates from the top
+//     down until the first member, and from the bottom up (not at all if the left neighbour's last position is a member),
+//     one pair per side and round; a clean stretch costs one request per 16 positions, a false candidate costs one only
+//     when it lies outside the confirmed span.  Rounds repeat until no lane of the wave has an open question.
+template <bool HAS_PREFILTER>
+__global__ void __launch_bounds__(256) k_kmer_cover_w(const uint8_t *plane, const uint64_t *offsets, const int32_t *lengths,
+                                                      const uint32_t *order, uint64_t n_reads, const uint8_t *exact15,
+                                                      const uint8_t *pre11, uint32_t *cov, const uint64_t *cov_off,
+                                                      int32_t *count, int32_t *first, int32_t *last) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t slot = wave0; slot < n_reads; slot += n_waves) {
+        const uint32_t rid = __builtin_amdgcn_readfirstlane(order ? order[slot] : (uint32_t)slot);
+        const int L = __builtin_amdgcn_readfirstlane(lengths[rid]);
+        const uint8_t *seq = plane + offsets[rid];
+        uint32_t *row = cov + (cov_off[rid] >> 2);
+        const int row_words = (((L + 7) / 8 + 15) & ~15) >> 2;
+        const int n_spans = (L + 1023) >> 10;
+        int cnt = 0, fst = 0x7fffffff, lst = -1;
+        // carried from lane 63 of the previous span (wave-uniform)
+        uint32_t c_lo = 0, c_p12 = 0, c_cand15 = 0, c_hit15 = 0;
+        uint32_t prev_hits = 0;  // hits of the previous span, waiting for their right neighbour's
+        bool far_first = false;  // this span asks the exact table BEFORE the prefilter (decided by the previous span, below)
+
+        auto finalize = [&](int sp, uint32_t h, uint32_t right_of_63) {  // hits of span sp -> coverage bits, counts, row words
+            const int p0 = (sp << 10) + lane * 16;
+            uint32_t next = __shfl_down(h, 1, 64);
+            if (lane == 63) next = right_of_63;
+            uint32_t x = h | (next << 16);
+            x |= x >> 1;
+            x |= x >> 2;
+            x |= x >> 4;
+            x |= x >> 8;  // bit j = OR of hit bits j .. j+15: base p0+j lies in a member 16-mer (src/read.cpp:53-54)
+            uint32_t c16 = x & 0xffffu;
+            if (p0 >= L) c16 = 0;
+            else if (p0 + 16 > L) c16 &= (1u << (L - p0)) - 1u;
+            cnt += __popc(c16);
+            if (c16) {
+                fst = min(fst, p0 + (__ffs(c16) - 1));
+                lst = max(lst, p0 + (32 - __clz(c16)));
+            }
+            const uint32_t up = __shfl_down(c16, 1, 64);
+            const int word = p0 >> 5;
+            if ((lane & 1) == 0 && word < row_words) row[word] = c16 | (up << 16);
+        };
+
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (lane * 16 < L) raw = *reinterpret_cast<const uint4 *>(seq + lane * 16);  // rows are 16-byte aligned and padded
+        for (int sp = 0; sp < n_spans; ++sp) {
+            const int p0 = (sp << 10) + lane * 16;
+            uint4 raw_next = make_uint4(0, 0, 0, 0);
+            if (p0 + 1024 < L) raw_next = *reinterpret_cast<const uint4 *>(seq + p0 + 1024);
+            // 2 bits per base, earliest base on top: lo = my 16 bases, hi = the 16 before them
+            const uint32_t lo = (codes4(raw.x) << 24) | (codes4(raw.y) << 16) | (codes4(raw.z) << 8) | codes4(raw.w);
+            uint32_t hi = __shfl_up(lo, 1, 64);
+            if (lane == 0) hi = c_lo;
+            // positions p0 + j that end a 12-mer / a 16-mer inside the read
+            uint32_t valid12 = 0, valid16 = 0;
+            if (p0 < L) {
+                valid12 = valid16 = 0xffffu;
+                if (p0 < 11) valid12 &= ~((1u << (11 - p0)) - 1u);
+                if (p0 < 15) valid16 &= ~((1u << (15 - p0)) - 1u);
+                if (p0 + 16 > L) {
+                    valid12 &= (1u << (L - p0)) - 1u;
+                    valid16 &= (1u << (L - p0)) - 1u;
+                }
+            }
+            // ---- exact membership: one byte of exact15 answers the pair of positions (a, a + 1), any a in 0..14 — the 15 bases
+            // ending at a are the byte's index, the base before them picks the bit of position a, the base after them the bit of
+            // a + 1.  A question from ABOVE (top-down search) takes the pair that ENDS at the asked position, one from below the
+            // pair that starts there: either way the request also settles the next candidate in the direction of the search. ----
+            uint32_t hits = 0, probed = 0;
+            auto probe = [&](int top, int bot, uint32_t keep) {  // positions asked from above / from below, -1 = none
+                const int a0 = top > 0 ? top - 1 : 0, a1 = bot < 14 ? bot : 14;
+                uint32_t g0 = 0, g1 = 0;
+#ifdef FLX_ABL_NOFAR
+                g0 = g1 = 0xffu;  // ablation: every asked 16-mer "is a member", no far request
+#else
+                // plain byte loads: non-temporal ones measured 8 % slower here (43.3 vs 40.1 ms per 1e10 positions), 4-byte loads
+                // 6 % slower — although a microbenchmark that mixes table and far lookups in one burst prefers nt (tools/tabench (7))
+                if (top >= 0) g0 = exact15[__builtin_amdgcn_alignbit(hi, lo, 30 - 2 * a0) & 0x3FFFFFFFu];
+                if (bot >= 0) g1 = exact15[__builtin_amdgcn_alignbit(hi, lo, 30 - 2 * a1) & 0x3FFFFFFFu];
+#endif
+                if (top >= 0) {
+                    const uint32_t x = (hi >> (28 - 2 * a0)) & 3u, y = (lo >> (28 - 2 * a0)) & 3u;
+                    hits |= (((g0 >> x) & 1u) | (((g0 >> (4 + y)) & 1u) << 1)) << a0;
+                    probed |= 3u << a0;
+                }
+                if (bot >= 0) {
+                    const uint32_t x = (hi >> (28 - 2 * a1)) & 3u, y = (lo >> (28 - 2 * a1)) & 3u;
+                    hits |= (((g1 >> x) & 1u) | (((g1 >> (4 + y)) & 1u) << 1)) << a1;
+                    probed |= 3u << a1;
+                }
+                hits &= keep;  // positions outside the read hold no 16-mer
+            };
+
+            // ---- far first (clean stretches): where most lanes of the previous span had their own last 16-mer AND their left
+            // neighbour's confirmed, ask for the last 16-mer of every lane before anything else.  A lane whose own and whose left
+            // neighbour's are members is SETTLED: its 16 bases lie in its own last 16-mer, the 15 before them in the neighbour's,
+            // so none of its other 16-mers can add coverage and its eight prefilter lines are never fetched.  The request is the
+            // one a clean lane needs anyway; it is wasted only on a lane whose last pair holds no candidate. ----
+            bool settled = false;
+            uint32_t ltop = 0;  // far first: is the left neighbour's last 16-mer a member
+            if (far_first) {
+                if (__any((valid16 >> 15) != 0)) probe((valid16 >> 15) ? 15 : -1, -1, valid16);
+                ltop = __shfl_up(hits >> 15, 1, 64);
+                if (lane == 0) ltop = c_hit15;
+                settled = (hits >> 15) && ltop;
+            }
+
+            // ---- 12-mer prefilter: pair m = positions p0 + 2m, p0 + 2m + 1; x.C.y = the 13 bases ending at p0 + 2m + 1 ----
+            uint32_t p12 = 0xffffu;  // (a settled lane: every 12-mer of its last 16-mer is present, the others are not needed)
+            if (HAS_PREFILTER && !settled) {
+                uint32_t byte[8], sel[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const uint32_t a = __builtin_amdgcn_alignbit(hi, lo, 28 - 4 * m);
+                    const flx_pre11_slot q = flx_pre11((a >> 2) & 0x3FFFFFu, (a >> 24) & 3u, a & 3u);
+#ifdef FLX_ABL_NOL2
+                    byte[m] = 0xffu;  // ablation: no prefilter lookups (every 12-mer "present")
+#else
+                    byte[m] = pre11[q.index];
+#endif
+                    sel[m] = q.even_bit | (q.odd_bit << 8);
+                }
+                p12 = 0;
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    p12 |= (((byte[m] >> (sel[m] & 0xffu)) & 1u) | (((byte[m] >> (sel[m] >> 8)) & 1u) << 1)) << (2 * m);
+            }
+            p12 &= valid12;
+            uint32_t p12_left = __shfl_up(p12 >> 11, 1, 64);  // the left lane's 12-mers ending at its positions 11..15 = mine at -5..-1
+            if (lane == 0) p12_left = c_p12;
+            if (!HAS_PREFILTER) p12_left = 0x1fu;
+            const uint32_t m12 = (p12_left >> 1) | (p12 << 4);  // bit i: the 12-mer ending at p0 - 4 + i
+            uint32_t cand = m12 & (m12 >> 1) & (m12 >> 2) & (m12 >> 3) & (m12 >> 4) & valid16;  // all five 12-mers present
+            if (settled) cand = hits;  // nothing open: the confirmed members are all this lane contributes
+            uint32_t lcand = __shfl_up(cand >> 15, 1, 64);
+            if (lane == 0) lcand = c_cand15;
+            hits &= cand;  // (a member is always a candidate)
+            probed |= ~cand & 0xffffu;
+
+            // One step of the search in the lane's window of 17 positions (bit 0 = the left neighbour's last position, bit j + 1 =
+            // my position j): the highest open candidate above the confirmed members and the lowest one below them.
+            auto next_asks = [&](uint32_t left_member, int &top, int &bot) -> bool {
+                const uint32_t H = (hits << 1) | left_member;
+                const uint32_t open = (cand & ~probed) << 1;
+                uint32_t above = open, below = open;
+                if (H) {
+                    above = open & ~((2u << (31 - __clz(H))) - 1u);
+                    below = open & ((H & (0u - H)) - 1u);
+                }
+                top = above ? 30 - __clz(above) : -1;  // position = bit - 1
+                bot = below ? __ffs(below) - 2 : -1;
+                if (bot >= 0 && bot + 1 >= top && top >= 0) bot = -1;  // the two questions meet: the pair that ends at `top` answers both
+                return (top & bot) != -1;
+            };
+            uint32_t lhit;
+            int top, bot;
+            if (far_first) {
+                lhit = ltop & lcand;  // already exact
+            } else {
+                // first step on a BET: a candidate at the left neighbour's last position is taken for a member (it is the top of
+                // that lane's search, so its answer arrives with this round's), corrected right after
+                const bool need = next_asks(lcand, top, bot);
+                if (__any(need)) probe(top, bot, cand);
+                lhit = __shfl_up(hits >> 15, 1, 64);
+                if (lane == 0) lhit = c_hit15;
+                lhit &= lcand;
+            }
+            for (;;) {
+                const bool need = next_asks(lhit, top, bot);
+                if (!__any(need)) break;
+                probe(top, bot, cand);
+            }
+
+            // far first for the next span?  Per lane the skipped prefilter lines are worth 8 x 3.8 ps, a wasted request 18 ps
+            // (tools/tabench): worth it from about half the lanes settled.
+            far_first = __popcll(__ballot((hits >> 15) && lhit)) >= FLX_FARFIRST_LANES;
+
+            // ---- coverage of the previous span (its lane 63 needed my lane 0's hits), then carry ----
+            if (sp > 0) finalize(sp - 1, prev_hits, __builtin_amdgcn_readfirstlane(hits));
+            prev_hits = hits;
+            c_lo = __builtin_amdgcn_readlane(lo, 63);
+            c_p12 = __builtin_amdgcn_readlane(p12 >> 11, 63);
+            c_cand15 = __builtin_amdgcn_readlane(cand >> 15, 63);
+            c_hit15 = __builtin_amdgcn_readlane(hits >> 15, 63);
+            raw = raw_next;
+        }
+        if (n_spans > 0) finalize(n_spans - 1, prev_hits, 0u);
+        for (int wd = n_spans * 32 + lane; wd < row_words; wd += 64) row[wd] = 0;  // (only L == 0 leaves words unwritten)
+        for (int o = 32; o > 0; o >>= 1) {
+            cnt += __shfl_xor(cnt, o, 64);
+            fst = min(fst, __shfl_xor(fst, o, 64));
+            lst = max(lst, __shfl_xor(lst, o, 64));
+        }
+        if (lane == 0) {
+            count[rid] = cnt;
+            first[rid] = cnt ? fst : -1;  // m_first_base_in_kmer / m_last_base_in_kmer, src/read.cpp:75-84
+            last[rid] = cnt ? lst : -1;
+        }
     }
 }
 
@@ -622,13 +846,27 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     // ---- kernel 1: lookups -> coverage bits ----
     {
         const unsigned grid = (unsigned)std::min<uint64_t>(n_reads, 1u << 20);
+        const char *cover_env = getenv("FLX_KMER_COVER");  // "v2": round 2's workgroup-per-read kernel (second implementation)
+        const bool old_cover = cover_env && strcmp(cover_env, "v2") == 0;
         flx_time_begin(ctx, "flx_score_kmer_cover");
+        if (!old_cover) {
+            const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 3) / 4, 1u << 20);
+            if (flx_kmerset_pre11(set))
+                hipLaunchKernelGGL(k_kmer_cover_w<true>, dim3(wgrid), dim3(256), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
+                                   flx_kmerset_exact15(set), flx_kmerset_pre11(set), (uint32_t *)d_cov, (const uint64_t *)d_covoff,
+                                   d_cnt, first, last);
+            else
+                hipLaunchKernelGGL(k_kmer_cover_w<false>, dim3(wgrid), dim3(256), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
+                                   flx_kmerset_exact15(set), (const uint8_t *)nullptr, (uint32_t *)d_cov, (const uint64_t *)d_covoff,
+                                   d_cnt, first, last);
+        } else {
         hipLaunchKernelGGL(k_kmer_cover<256>, dim3(grid), dim3(256), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
                            flx_kmerset_bitmap(set), flx_kmerset_prefilter(set), (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first,
                            last);
         hipLaunchKernelGGL(k_kmer_cover<64>, dim3(grid), dim3(64), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
                            flx_kmerset_bitmap(set), flx_kmerset_prefilter(set), (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first,
                            last);
+        }
         flx_time_end(ctx);
     }
 

@@ -72,6 +72,32 @@ __global__ void __launch_bounds__(256) k_mixed(const uint32_t *small, uint64_t s
     if (acc == 0x12345) out[0] = acc;
 }
 
+// 16 lookups in a `small` table + F far lookups, far loads non-temporal when NTFAR (does the L2 keep a 3 MiB table next to the far lines?)
+template <int F, bool NTFAR>
+__global__ void __launch_bounds__(256) k_mixed2(const uint32_t *small, uint32_t small_words, const uint32_t *big, uint64_t big_mask,
+                                                int iters, uint32_t *out) {
+    uint64_t x = (blockIdx.x * 256ull + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        uint32_t v[16], f[F];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            v[j] = small[(uint32_t)(((x >> 32) * (uint64_t)small_words) >> 32)];
+        }
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            f[j] = NTFAR ? __builtin_nontemporal_load(big + ((x >> 20) & big_mask)) : big[(x >> 20) & big_mask];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc ^= v[j];
+#pragma unroll
+        for (int j = 0; j < F; ++j) acc ^= f[j];
+    }
+    if (acc == 0x12345) out[0] = acc;
+}
+
 // far lookups only, F per iteration (same loop shape as k_mixed)
 template <int F>
 __global__ void __launch_bounds__(256) k_far(const uint32_t *big, uint64_t big_mask, int iters, uint32_t *out) {
@@ -125,7 +151,8 @@ static float timed(L launch) {
     return ms;
 }
 
-int main() {
+int main(int argc, char **argv) {
+    const bool only7 = argc > 1 && argv[1][0] == '7';
     const uint64_t big_bytes = 512ull << 20;
     uint32_t *buf, *out;
     CK(hipMalloc(&buf, big_bytes));
@@ -136,6 +163,7 @@ int main() {
     const int blocks = 256 * 8;
     const double per_iter = (double)blocks * 256 * 16;
 
+    if (!only7) {
     printf("# (1) every lane its own random line: G lookups/s by table size and load flavour (2048 x 256 threads, 16 loads in flight per thread)\n");
     for (uint64_t kib : {16ull, 64ull, 256ull, 1024ull, 2048ull, 4096ull, 65536ull, 524288ull}) {
         const uint64_t mask = kib * 1024 / 128 - 1;
@@ -184,6 +212,19 @@ int main() {
             printf("F %d: mixed %8.3f ms   far alone %8.3f ms   L2 alone %8.3f ms   (sum %8.3f)\n", i, ms[i], fs[i], m0, m0 + fs[i]);
         printf("far alone, 16 in flight per thread: %7.1f G/s;  1 in flight: %7.1f G/s\n", per_iter * 100 / f16 / 1e6, per_iter / 16 * 100 / f1 / 1e6);
     }
+    }
+    printf("# (7) 16 lookups in a table of S MiB + 4 far lookups (512 MiB) per iteration, far loads plain / nt: ms per 100 iterations\n");
+    {
+        const uint64_t bm = big_bytes / 4 - 1;
+        for (double mib : {1.0, 2.0, 2.5, 3.0, 3.5, 4.0}) {
+            const uint32_t words = (uint32_t)(mib * (1 << 20) / 4);
+            float a = timed([&](int it) { hipLaunchKernelGGL((k_mixed2<4, false>), dim3(blocks), dim3(256), 0, 0, buf, words, buf, bm, it, out); });
+            float b = timed([&](int it) { hipLaunchKernelGGL((k_mixed2<4, true>), dim3(blocks), dim3(256), 0, 0, buf, words, buf, bm, it, out); });
+            float c = timed([&](int it) { hipLaunchKernelGGL((k_mixed2<1, false>), dim3(blocks), dim3(256), 0, 0, buf, words, buf, bm, it, out); });
+            printf("table %.1f MiB: F=4 plain %8.3f ms   F=4 nt %8.3f ms   F=1 plain %8.3f ms\n", mib, a, b, c);
+        }
+    }
+    if (only7) return 0;
     printf("# (6) 2 MiB table, plain loads, by resident workgroups (256 threads) per CU\n");
     {
         const uint64_t mask = 2048 * 1024 / 128 - 1;
