@@ -23,7 +23,7 @@
 #include "rank_internal.h"
 
 #ifndef FLX_FARFIRST_LANES
-#define FLX_FARFIRST_LANES 32  // settled lanes of a span from which the next span asks the exact table first (score_kmer.hip, below)
+#define FLX_FARFIRST_LANES 16  // settled lanes of a span from which the next span asks the exact table first (score_kmer.hip, below)
 #endif
 
 namespace {

@@ -555,27 +555,37 @@ int launch_a(flx_ctx *ctx, PhredArgs &a, bool priv) {
 
 }  // namespace
 
-// The instantiations (window sizes 48..319, A = ws / 16 = 3..19) are spread over four translation units of this same file
-// (-DFLX_REGS_PART=0..3, see the Makefile) so that they compile in parallel.
+// The instantiations (window sizes 1..511, A = ws / 16 = 0..31) are spread over six translation units of this same file
+// (-DFLX_REGS_PART=0..5, see the Makefile) so that they compile in parallel.  Rings beyond 36 pieces (A >= 32) are no
+// longer kept in registers by hipcc (the array goes to scratch memory): from ws = 512 on the LDS-ring / stream kernels of
+// score_phred.hip take over.
 #define FLX_REGS_CASE(AA) \
     case AA:              \
         *launched = true; \
         return launch_a<AA>(ctx, a, priv);
 #if FLX_REGS_PART == 0
 int flx_launch_score_phred_regs_part0(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
-    switch (a.ws / 16) { FLX_REGS_CASE(3) FLX_REGS_CASE(4) FLX_REGS_CASE(5) FLX_REGS_CASE(6) FLX_REGS_CASE(7) default: return FLX_OK; }
+    switch (a.ws / 16) { FLX_REGS_CASE(0) FLX_REGS_CASE(1) FLX_REGS_CASE(2) FLX_REGS_CASE(3) FLX_REGS_CASE(4) FLX_REGS_CASE(5) FLX_REGS_CASE(6) FLX_REGS_CASE(7) default: return FLX_OK; }
 }
 #elif FLX_REGS_PART == 1
 int flx_launch_score_phred_regs_part1(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
-    switch (a.ws / 16) { FLX_REGS_CASE(8) FLX_REGS_CASE(9) FLX_REGS_CASE(10) FLX_REGS_CASE(11) default: return FLX_OK; }
+    switch (a.ws / 16) { FLX_REGS_CASE(8) FLX_REGS_CASE(9) FLX_REGS_CASE(10) FLX_REGS_CASE(11) FLX_REGS_CASE(12) default: return FLX_OK; }
 }
 #elif FLX_REGS_PART == 2
 int flx_launch_score_phred_regs_part2(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
-    switch (a.ws / 16) { FLX_REGS_CASE(12) FLX_REGS_CASE(13) FLX_REGS_CASE(14) FLX_REGS_CASE(15) default: return FLX_OK; }
+    switch (a.ws / 16) { FLX_REGS_CASE(13) FLX_REGS_CASE(14) FLX_REGS_CASE(15) FLX_REGS_CASE(16) FLX_REGS_CASE(17) default: return FLX_OK; }
+}
+#elif FLX_REGS_PART == 3
+int flx_launch_score_phred_regs_part3(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
+    switch (a.ws / 16) { FLX_REGS_CASE(18) FLX_REGS_CASE(19) FLX_REGS_CASE(20) FLX_REGS_CASE(21) FLX_REGS_CASE(22) default: return FLX_OK; }
+}
+#elif FLX_REGS_PART == 4
+int flx_launch_score_phred_regs_part4(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
+    switch (a.ws / 16) { FLX_REGS_CASE(23) FLX_REGS_CASE(24) FLX_REGS_CASE(25) FLX_REGS_CASE(26) FLX_REGS_CASE(27) default: return FLX_OK; }
 }
 #else
-int flx_launch_score_phred_regs_part3(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
-    switch (a.ws / 16) { FLX_REGS_CASE(16) FLX_REGS_CASE(17) FLX_REGS_CASE(18) FLX_REGS_CASE(19) default: return FLX_OK; }
+int flx_launch_score_phred_regs_part5(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
+    switch (a.ws / 16) { FLX_REGS_CASE(28) FLX_REGS_CASE(29) FLX_REGS_CASE(30) FLX_REGS_CASE(31) default: return FLX_OK; }
 }
 #endif
 #undef FLX_REGS_CASE
@@ -584,6 +594,8 @@ int flx_launch_score_phred_regs_part3(flx_ctx *ctx, PhredArgs &a, bool priv, boo
 int flx_launch_score_phred_regs_part1(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
 int flx_launch_score_phred_regs_part2(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
 int flx_launch_score_phred_regs_part3(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
+int flx_launch_score_phred_regs_part4(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
+int flx_launch_score_phred_regs_part5(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
 
 namespace {
 // Which table layout?  Plain tables are ~6 % faster when a wavefront's quality values stay within ~32 consecutive table
@@ -624,7 +636,7 @@ int flx_launch_score_phred_stream(flx_ctx *ctx, PhredArgs a) {
 int flx_launch_score_phred_regs(flx_ctx *ctx, PhredArgs a, bool *launched) {
     *launched = false;
     const int A = a.ws / 16;
-    if (A < 3 || A > 19) return FLX_OK;
+    if (A > 31) return FLX_OK;
     const char *env = getenv("FLX_PHRED_TABLES");  // "plain" | "private" | unset = decide from a sample of the data
     bool priv = env && strcmp(env, "private") == 0;
     // scratch: [0,4) ticket, [4,8) redo count, [64, 1088) sample histogram, [2048, 2048 + 4 n) redo list
@@ -658,12 +670,12 @@ int flx_launch_score_phred_regs(flx_ctx *ctx, PhredArgs a, bool *launched) {
         }
         priv = !high && 496.0 * conflicts > 3.0;  // bytes >= 128 would all go through the redo path: stay plain
     }
-    switch (A / 4) {
-        case 0: case 1: FLX_CHECK(flx_launch_score_phred_regs_part0(ctx, a, priv, launched)); break;
-        case 2: FLX_CHECK(flx_launch_score_phred_regs_part1(ctx, a, priv, launched)); break;
-        case 3: FLX_CHECK(flx_launch_score_phred_regs_part2(ctx, a, priv, launched)); break;
-        default: FLX_CHECK(flx_launch_score_phred_regs_part3(ctx, a, priv, launched)); break;
-    }
+    if (A <= 7) FLX_CHECK(flx_launch_score_phred_regs_part0(ctx, a, priv, launched));
+    else if (A <= 12) FLX_CHECK(flx_launch_score_phred_regs_part1(ctx, a, priv, launched));
+    else if (A <= 17) FLX_CHECK(flx_launch_score_phred_regs_part2(ctx, a, priv, launched));
+    else if (A <= 22) FLX_CHECK(flx_launch_score_phred_regs_part3(ctx, a, priv, launched));
+    else if (A <= 27) FLX_CHECK(flx_launch_score_phred_regs_part4(ctx, a, priv, launched));
+    else FLX_CHECK(flx_launch_score_phred_regs_part5(ctx, a, priv, launched));
     if (*launched && priv) {
         flx_time_begin(ctx, "flx_score_phred_redo");
         hipLaunchKernelGGL(flx_score_phred_redo, dim3(256), dim3(256), 0, ctx->stream, a);

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+for v in ff0 ff4 ff8 ff12 ff16; do
+L=filtlong_amd/lib/exp/libfiltlong_hip_$v.so
+for c in c3 c4; do
+FLX_LIB_PATH=$L timeout 300 python bench.py --config $c --reads 1000000 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('$c ${v}', d['value'], d['ms_per_step'], d['stage_ms_per_step']['cover_kernel'], d['cut']['kept_bases'])"
+done
+done
