@@ -17,7 +17,7 @@ STATUS_NAMES = {0: "FLX_OK", 1: "FLX_ERR_INVALID", 2: "FLX_ERR_HIP", 3: "FLX_ERR
 
 # every symbol include/filtlong_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "flx_abi_version", "flx_version", "flx_ctx_create", "flx_ctx_destroy", "flx_last_error", "flx_ctx_set_stream",
+    "flx_abi_version", "flx_version", "flx_device_count", "flx_ctx_create", "flx_ctx_destroy", "flx_last_error", "flx_ctx_set_stream",
     "flx_ctx_synchronize", "flx_ctx_device_info", "flx_timing_enable", "flx_timing_reset", "flx_timing_get",
     "flx_plane_layout", "flx_length_order", "flx_score_batch", "flx_score_batch_dev", "flx_reads2_gather", "flx_reads2_gather_dev",
     "flx_rank_and_cut",

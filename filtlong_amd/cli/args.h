@@ -214,6 +214,10 @@ static ParsingResult parse_args(int argc, char **argv, Args &a) {
     if (a.min_window_q_set && a.min_window_q <= 0.0) { std::cerr << "Error: the value for --min_window_q must be greater than 0\n"; return BAD; }
     if (a.length_weight < 0.0 || a.mean_q_weight < 0.0 || a.window_q_weight < 0.0) { std::cerr << "Error: weight values cannot be negative\n"; return BAD; }
     if (a.split_set && a.split <= 0) { std::cerr << "Error: the value for --split must be a positive integer\n"; return BAD; }
+    // The reference reads the option as a long long and stores it in an `int` field before validating it
+    // (src/arguments.cpp:295,389; src/arguments.h:90): 4294967546 scores with a window of 250, 2147483648 is "not positive".
+    // The drop-in narrows the same way, then validates.
+    a.window_size = (long long)(int32_t)(uint32_t)(unsigned long long)a.window_size;
     if (a.window_size <= 0) { std::cerr << "Error: the value for --window_size must be a positive integer\n"; return BAD; }
     if (a.gpus < 1 || a.gpus > 64) { std::cerr << "Error: the value for --gpus must be between 1 and 64\n"; return BAD; }
     return GOOD;

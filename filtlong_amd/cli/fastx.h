@@ -135,7 +135,7 @@ struct Parser {
     }
     // kseq's ks_getuntil2(KS_SEP_LINE, append): append the rest of the line to the accumulating field `v`
     // (first line: a view; later lines: copied into the arena); a trailing '\r' is dropped when the field has > 1 chars
-    void append_line(View &v, bool &owned, size_t first_from) {
+    void append_line(View &v, bool &owned, size_t first_from, bool first_consumed) {
         View line;
         if (v.n == 0 && !owned) {
             rest_of_line(first_from, v);
@@ -149,6 +149,10 @@ struct Parser {
             v.p = arena.back().data();
             v.n = arena.back().size();
         }
+        // kseq strips the '\r' at the end of ks_getuntil2 — which returns before that (-1) when the stream is at its end right
+        // behind the line's first character, the one kseq_read consumed itself with ks_getc (src/kseq.h:141,188-190): a last
+        // line that is a bare '\r' without a newline keeps it
+        if (first_consumed && first_from + 1 >= d.size()) return;
         if (v.n > 1 && v.p[v.n - 1] == '\r') {
             --v.n;
             if (owned) arena.back().pop_back();
@@ -184,7 +188,7 @@ struct Parser {
         bool seq_owned = false, qual_owned = false;
         while ((c = getc()) >= 0 && c != '>' && c != '+' && c != '@') {
             if (c == '\n') continue;
-            append_line(r.seq, seq_owned, pos - 1);  // the line starts at the character just consumed
+            append_line(r.seq, seq_owned, pos - 1, true);  // the line starts at the character just consumed
         }
         if (c == '>' || c == '@') last_char = c;
         r.is_fastq = (c == '+');
@@ -193,7 +197,7 @@ struct Parser {
         if (c == -1) return -2;
         for (;;) {
             if (pos >= d.size()) break;
-            append_line(r.qual, qual_owned, pos);
+            append_line(r.qual, qual_owned, pos, false);
             if (r.qual.size() >= r.seq.size()) break;
         }
         last_char = 0;

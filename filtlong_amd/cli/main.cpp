@@ -37,6 +37,8 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <poll.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -272,6 +274,89 @@ static bool write_pieces(size_t n, Produce &&produce, FILE *sink, const std::vec
     return !failed;
 }
 
+// ---- rank 0 of `--gpus N`: the forked ranks, their pipes, the private directory of the output parts -------------------------
+// A watchdog thread reaps the children while rank 0 works: a child that dies early (no such device, RCCL missing, ...) would
+// otherwise leave rank 0 blocked inside a collective for ever — the job then ends at once with a message, and whichever way
+// main() is left no child and no file stays behind.
+struct Job {
+    std::vector<pid_t> children;
+    std::vector<int> id_pipes;
+    std::string dir;
+    std::thread watchdog;
+    std::mutex mu;
+    std::atomic<bool> stop{false};
+    std::vector<int> exited;  // exit status per child, -1 while it runs
+    Job() = default;
+    Job &operator=(Job &&o) {  // (a forked child drops its copy; no thread exists at that point)
+        children = std::move(o.children); id_pipes = std::move(o.id_pipes); dir = std::move(o.dir);
+        exited.clear();
+        return *this;
+    }
+    void remove_dir() {
+        if (dir.empty()) return;
+        for (size_t r = 0; r <= children.size(); ++r) unlink((dir + "/out.part" + std::to_string(r)).c_str());
+        rmdir(dir.c_str());
+        dir.clear();
+    }
+    void kill_all() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < children.size(); ++i)
+            if (exited.empty() || exited[i] < 0) kill(children[i], SIGKILL);
+    }
+    bool poll_once(bool block) {  // returns false when a child ended badly
+        bool ok = true;
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < children.size(); ++i) {
+            if (exited[i] >= 0) { ok = ok && exited[i] == 0; continue; }
+            int st = 0;
+            const pid_t r = waitpid(children[i], &st, block ? 0 : WNOHANG);
+            if (r == children[i]) exited[i] = (WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0));
+            else if (r < 0) exited[i] = 255;
+            if (exited[i] > 0) ok = false;
+        }
+        return ok;
+    }
+    void start_watchdog() {
+        exited.assign(children.size(), -1);
+        watchdog = std::thread([this]() {
+            while (!stop.load()) {
+                if (!poll_once(false)) {
+                    int which = 0, status = 0;
+                    { std::lock_guard<std::mutex> lk(mu); for (size_t i = 0; i < exited.size(); ++i) if (exited[i] > 0) { which = (int)i + 1; status = exited[i]; } }
+                    const std::string msg = "\nError: rank " + std::to_string(which) + " ended early (status " + std::to_string(status) +
+                                            "): no GPU for it, or the RCCL library could not be loaded?\n";
+                    (void)!write(2, msg.data(), msg.size());
+                    kill_all();
+                    poll_once(true);
+                    remove_dir();
+                    _exit(1);
+                }
+                usleep(20000);
+            }
+        });
+    }
+    bool finish() {  // normal end: every child must have left with status 0
+        if (children.empty()) return true;
+        stop.store(true);
+        if (watchdog.joinable()) watchdog.join();
+        const bool ok = poll_once(true);
+        remove_dir();
+        children.clear();
+        return ok;
+    }
+};
+static Job g_job;
+struct JobGuard {
+    ~JobGuard() {  // an early return of rank 0
+        if (g_job.children.empty()) return;
+        g_job.stop.store(true);
+        if (g_job.watchdog.joinable()) g_job.watchdog.join();
+        g_job.kill_all();
+        g_job.poll_once(true);
+        g_job.remove_dir();
+    }
+};
+
 int main(int argc, char **argv) {
     Args args;
     const ParsingResult pr = parse_args(argc, argv, args);
@@ -285,32 +370,64 @@ int main(int argc, char **argv) {
     // any GPU state exists.  Reads are sharded by count in contiguous blocks of file order; every rank parses the (mapped)
     // input's record index, scores its own block and takes part in the global stage through the library's RCCL
     // communicator; rank 0 owns stderr and stdout.
-    std::vector<pid_t> children;
+    // Launcher mode is an explicit opt-in — RANK + WORLD_SIZE + FLX_COMM_ID_FILE (a path unique to the job) all set: a bare
+    // WORLD_SIZE inherited from a SLURM / torchrun shell must not turn a plain run into a rank that waits for peers.
     std::string id_file;
-    if (const char *ws = getenv("WORLD_SIZE")) {
-        g_world = std::max(1, atoi(ws));
-        g_rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
+    int id_pipe = -1;  // --gpus: the read end of this rank's pipe from rank 0
+    if (getenv("WORLD_SIZE") && getenv("RANK") && getenv("FLX_COMM_ID_FILE")) {
+        g_world = std::max(1, atoi(getenv("WORLD_SIZE")));
+        g_rank = atoi(getenv("RANK"));
+        id_file = getenv("FLX_COMM_ID_FILE");
+        g_part_prefix = id_file + ".out";
     } else if (args.gpus > 1) {
+        if (!getenv("FLX_DEVICE")) {  // (FLX_DEVICE pins every rank to one device: the one-GPU tests of this path)
+            // the HIP runtime does not survive a fork, so the device count comes from a probe child
+            const pid_t probe = fork();
+            if (probe == 0) _exit(std::max(0, std::min(flx_device_count(), 255)));
+            int st = 0;
+            if (probe < 0 || waitpid(probe, &st, 0) < 0 || !WIFEXITED(st)) { std::cerr << "Error: cannot probe the GPUs\n"; return 1; }
+            if (WEXITSTATUS(st) < args.gpus) {
+                std::cerr << "Error: --gpus " << args.gpus << " but only " << WEXITSTATUS(st) << " GPU(s) visible\n";
+                return 1;
+            }
+        }
         g_world = args.gpus;
-        id_file = "/tmp/flx_comm_" + std::to_string((long long)getpid()) + ".id";
-        setenv("FLX_COMM_ID_FILE", id_file.c_str(), 1);
+        // a private directory for the ranks' output parts (mkdtemp: mode 0700, unpredictable name)
+        const char *td = getenv("TMPDIR");
+        std::string tmpl = std::string(td && *td ? td : "/tmp") + "/flx_XXXXXX";
+        if (!mkdtemp(&tmpl[0])) { std::cerr << "Error: cannot create a temporary directory under " << (td && *td ? td : "/tmp") << "\n"; return 1; }
+        g_job.dir = tmpl;
+        g_part_prefix = tmpl + "/out";
+        // the communicator id reaches every rank through a pipe made before the fork
+        std::vector<int> wr;
         for (int r = 1; r < g_world; ++r) {
+            int fds[2];
+            if (pipe(fds) != 0) { std::cerr << "Error: pipe failed\n"; return 1; }
             const pid_t pid = fork();
             if (pid < 0) { std::cerr << "Error: fork failed\n"; return 1; }
-            if (pid == 0) { g_rank = r; children.clear(); break; }
-            children.push_back(pid);
+            if (pid == 0) {
+                g_rank = r;
+                g_job = Job();  // a child owns neither children nor the directory
+                for (int w : wr) close(w);
+                close(fds[1]);
+                id_pipe = fds[0];
+                break;
+            }
+            close(fds[0]);
+            wr.push_back(fds[1]);
+            g_job.children.push_back(pid);
+        }
+        if (g_rank == 0) {
+            g_job.id_pipes = wr;
+            g_job.start_watchdog();
         }
     }
+    JobGuard job_guard;  // rank 0 of --gpus: whatever way main() is left, no child and no part file stays behind
     if (g_rank < 0 || g_rank >= g_world) { std::cerr << "Error: RANK " << g_rank << " outside WORLD_SIZE " << g_world << "\n"; return 1; }
     if (g_world > 1 && args.verbose) { std::cerr << "Error: --verbose is not available with more than one GPU\n"; return 1; }
     if (g_rank > 0) {  // rank 0 speaks for the job
         if (!freopen("/dev/null", "w", stderr)) return 1;
         if (!freopen("/dev/null", "w", stdout)) return 1;
-    }
-    if (g_world > 1) {
-        const char *f = getenv("FLX_COMM_ID_FILE");
-        id_file = f ? f : std::string("/tmp/flx_comm_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + ".id";
-        g_part_prefix = id_file + ".out";
     }
 
     std::cerr << "\n";
@@ -327,20 +444,46 @@ int main(int argc, char **argv) {
         }
     }
     if (g_world > 1) {
-        // the communicator's 128-byte id travels through a file: rank 0 writes it (temp name + rename), the others wait for it
+        // the communicator's 128-byte id: --gpus hands it to every child through its pipe; under a launcher it travels through
+        // FLX_COMM_ID_FILE (rank 0: exclusive create of a temp name, never through a symlink, then rename; the others accept
+        // only a file written after they started — a stale one from a crashed earlier job is older)
         unsigned char id[FLX_COMM_ID_BYTES];
         if (g_rank == 0) {
             if (flx_comm_unique_id(ctx, id) != FLX_OK) return fail_flx(ctx, "communicator");
-            const std::string tmp = id_file + ".tmp";
-            FILE *f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) { std::cerr << "Error: cannot write " << tmp << "\n"; return 1; }
-            fclose(f);
-            if (rename(tmp.c_str(), id_file.c_str()) != 0) { std::cerr << "Error: cannot create " << id_file << "\n"; return 1; }
+            if (!g_job.children.empty()) {
+                for (int w : g_job.id_pipes) {
+                    if (write(w, id, sizeof id) != (ssize_t)sizeof id) { std::cerr << "Error: cannot hand the communicator id to a rank\n"; return 1; }
+                    close(w);
+                }
+                g_job.id_pipes.clear();
+            } else {
+                const std::string tmp = id_file + ".tmp";
+                unlink(tmp.c_str());
+                const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+                if (fd < 0 || write(fd, id, sizeof id) != (ssize_t)sizeof id) { std::cerr << "Error: cannot write " << tmp << "\n"; return 1; }
+                close(fd);
+                if (rename(tmp.c_str(), id_file.c_str()) != 0) { std::cerr << "Error: cannot create " << id_file << "\n"; return 1; }
+            }
+        } else if (id_pipe >= 0) {
+            size_t got = 0;
+            struct pollfd pfd = {id_pipe, POLLIN, 0};
+            while (got < sizeof id && poll(&pfd, 1, 120000) > 0) {  // rank 0 gone: EOF, at once
+                const ssize_t k = read(id_pipe, id + got, sizeof id - got);
+                if (k <= 0) break;
+                got += (size_t)k;
+            }
+            close(id_pipe);
+            if (got != sizeof id) return 1;
         } else {
+            const time_t started = time(nullptr);
             bool ok = false;
             for (int tries = 0; tries < 6000 && !ok; ++tries) {  // up to 60 s
-                FILE *f = fopen(id_file.c_str(), "rb");
-                if (f) { ok = fread(id, 1, sizeof id, f) == sizeof id; fclose(f); }
+                struct stat sb;
+                const int fd = open(id_file.c_str(), O_RDONLY | O_NOFOLLOW);
+                if (fd >= 0) {
+                    if (fstat(fd, &sb) == 0 && sb.st_mtime + 2 >= started) ok = read(fd, id, sizeof id) == (ssize_t)sizeof id;
+                    close(fd);
+                }
                 if (!ok) usleep(10000);
             }
             if (!ok) return 1;
@@ -348,7 +491,7 @@ int main(int argc, char **argv) {
         if (flx_comm_init(ctx, id, g_rank, g_world) != FLX_OK) return fail_flx(ctx, "communicator");
         uint64_t ready = 1;  // everybody has read the id
         if (flx_comm_sum_u64(ctx, &ready, 1) != FLX_OK) return fail_flx(ctx, "communicator");
-        if (g_rank == 0) unlink(id_file.c_str());
+        if (g_rank == 0 && !id_file.empty()) unlink(id_file.c_str());
     }
 
     stage("context");
@@ -418,7 +561,7 @@ int main(int argc, char **argv) {
 
     flx_params prm;
     memset(&prm, 0, sizeof prm);
-    prm.window_size = (int32_t)args.window_size;
+    prm.window_size = args.window_size;  // (already narrowed to the reference's int by parse_args)
     prm.min_length_set = args.min_length_set; prm.min_length = args.min_length;
     prm.max_length_set = args.max_length_set; prm.max_length = args.max_length;
     prm.min_mean_q_set = args.min_mean_q_set; prm.min_mean_q = args.min_mean_q;
@@ -452,6 +595,10 @@ int main(int argc, char **argv) {
         const uint64_t base = lengths.size();
         int32_t longest = 0;
         for (uint64_t i = 0; i < cnt; ++i) {
+            if (recs[lo + i].seq.size() > (size_t)INT32_MAX) {  // the reference holds a read's length in an int as well (src/main.cpp:108)
+                std::cerr << "\nError: read " << recs[lo + i].name.sv() << " is longer than 2^31-1 bases\n";
+                return 1;
+            }
             lengths.push_back((int32_t)recs[lo + i].seq.size());
             longest = std::max(longest, lengths.back());
         }
@@ -848,12 +995,7 @@ int main(int argc, char **argv) {
     pipe = nullptr;
     if (kmers) flx_kmerset_destroy(kmers);
     flx_ctx_destroy(ctx);
-    int status = 0;
-    for (pid_t c : children) {
-        int st = 0;
-        if (waitpid(c, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) status = 1;
-    }
-    if (status) { std::cerr << "Error: a rank failed\n"; return 1; }
+    if (!g_job.finish()) { std::cerr << "Error: a rank failed\n"; return 1; }
     if (rank == 0) std::cerr << "\n";
     return 0;
 }

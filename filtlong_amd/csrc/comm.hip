@@ -17,6 +17,8 @@
 // already have loaded — else /opt/rocm/lib/librccl.so.1), so single-GPU users never touch it and the library does not
 // force a second RCCL into a process that brings its own.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include "flx_internal.h"
@@ -71,6 +73,27 @@ int load_rccl(flx_ctx *ctx) {
                             __LINE__);                                                                          \
     } while (0)
 
+// This RCCL build prints a banner ("RCCL version : ... Librccl path : ...") on STDOUT when a communicator is created — and
+// stdout is the data channel of the host this library serves (the reference writes the surviving reads there,
+// src/main.cpp:263-313).  File descriptor 1 points at /dev/null while RCCL initialises.
+struct StdoutSilencer {
+    int saved = -1;
+    StdoutSilencer() {
+        fflush(stdout);
+        const int nul = open("/dev/null", O_WRONLY);
+        if (nul < 0) return;
+        saved = dup(1);
+        if (saved >= 0) dup2(nul, 1);
+        close(nul);
+    }
+    ~StdoutSilencer() {
+        if (saved < 0) return;
+        fflush(stdout);
+        dup2(saved, 1);
+        close(saved);
+    }
+};
+
 }  // namespace
 
 struct flx_comm {
@@ -86,7 +109,10 @@ extern "C" int flx_comm_unique_id(flx_ctx *ctx, void *id_out) {
     if (!ctx || !id_out) return FLX_ERR_INVALID;
     FLX_CHECK(load_rccl(ctx));
     ncclUniqueId id;
-    FLX_NCCL(ctx, g_rccl.GetUniqueId(&id));
+    {
+        StdoutSilencer quiet;
+        FLX_NCCL(ctx, g_rccl.GetUniqueId(&id));
+    }
     static_assert(sizeof id == FLX_COMM_ID_BYTES, "ncclUniqueId size");
     memcpy(id_out, &id, sizeof id);
     return FLX_OK;
@@ -103,7 +129,11 @@ extern "C" int flx_comm_init(flx_ctx *ctx, const void *id_in, int rank, int worl
     flx_comm *c = new flx_comm();
     c->rank = rank;
     c->world = world;
-    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    ncclResult_t r;
+    {
+        StdoutSilencer quiet;
+        r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    }
     if (r != ncclSuccess) {
         delete c;
         return flx_fail(ctx, FLX_ERR_STATE, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));

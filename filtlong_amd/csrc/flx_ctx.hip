@@ -19,6 +19,12 @@ int flx_fail(flx_ctx *ctx, int code, const char *fmt, ...) {
 }
 
 extern "C" int flx_abi_version(void) { return FLX_ABI_VERSION; }
+
+extern "C" int flx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
 extern "C" const char *flx_version(void) { return "filtlong-amd 0.1 (hot path of Filtlong v0.3.1; gfx950)"; }
 
 extern "C" const char *flx_last_phred_kernel(const flx_ctx *ctx) { return ctx ? ctx->last_phred_kernel : ""; }

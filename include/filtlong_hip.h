@@ -73,6 +73,9 @@ typedef struct flx_params {
  * ---------------------------------------------------------------------------------------- */
 int flx_abi_version(void);
 const char *flx_version(void);
+/* Number of HIP devices visible to this process (-1: no usable runtime).  Initialises the HIP runtime in the calling process:
+ * a host that forks its ranks (the CLI's --gpus N) asks from a short-lived probe child. */
+int flx_device_count(void);
 int flx_ctx_create(int device_ordinal, flx_ctx **out);
 void flx_ctx_destroy(flx_ctx *ctx);
 const char *flx_last_error(const flx_ctx *ctx); /* ctx may be NULL: last create error */

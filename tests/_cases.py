@@ -157,6 +157,16 @@ def long_fastq_bytes(reads):
     return b"\n".join(out) + b"\n"
 
 
+def fasta_cr_at_eof_bytes(reads):
+    """FASTA whose last line is a bare carriage return without a newline ("...\\n\\r<EOF>"): kseq keeps that '\\r' as the last
+    base of the last record — ks_getuntil2 returns at the end of the stream before its '\\r' strip (reference
+    src/kseq.h:141-146) — while every '\\r' in front of a newline is dropped."""
+    out = bytearray()
+    for name, s, _q in reads:
+        out += b">" + name.encode() + b"\r\n" + s + b"\r\n"
+    return bytes(out[:-2]) + b"\n\r"
+
+
 def c1_fastq_bytes(n=10_000, length=5000, seed=synth.SEED):
     """BASELINE.json configs[0] (C1): n reads x 5 kbp, Phred-only, as a FASTQ file (seq is irrelevant in Phred mode)."""
     seq = (b"ACGT" * (length // 4 + 1))[:length]

@@ -197,6 +197,10 @@ def main():
                                                                           "70"], td)
             e2e["synth_kmer|%s|split40" % mode] = e2e_case(kin, rargs + ["--trim", "--split", "40", "--min_length",
                                                                         "200", "--target_bases", str(ktot // 3)], td)
+        cin = os.path.join(td, "cr_at_eof.fasta")  # last line a bare '\r' without a newline: kseq keeps it (src/kseq.h:141-146)
+        with open(cin, "wb") as f:
+            f.write(_cases.fasta_cr_at_eof_bytes(kreads))
+        e2e["odd_format|cr_at_eof"] = e2e_case(cin, ["-a", fa, "--target_bases", str(ktot // 2)], td)
         # engineered Bloom false positive (3 sightings are enough when all 13 bits were pre-set; kmers.cpp:148-155)
         import numpy as np
         f1, f2, target, control = _cases.bloom_fp_case()

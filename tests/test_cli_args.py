@@ -46,6 +46,8 @@ CASES = [
     (["-a", "ASSEMBLY", "--split", "-10", "INPUT"], "Error: the value for --split must be a positive integer"),
     (["--min_length", "1000", "--window_size", "0", "INPUT"], "Error: the value for --window_size must be a positive integer"),
     (["--min_length", "1000", "--window_size", "-10", "INPUT"], "Error: the value for --window_size must be a positive integer"),
+    # the reference narrows --window_size to an int before it validates it (src/arguments.cpp:295,389)
+    (["--min_length", "1000", "--window_size", "2147483648", "INPUT"], "Error: the value for --window_size must be a positive integer"),
     (["-l", "-10", "INPUT"], "Error: the value for --min_length must be a positive integer"),
     (["-L", "-10", "INPUT"], "Error: the value for --max_length must be a positive integer"),
     (["-q", "0", "INPUT"], "Error: the value for --min_mean_q must be greater than 0"),

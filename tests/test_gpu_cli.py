@@ -57,6 +57,7 @@ def test_cli_matches_reference_binary_byte_for_byte(mode):
         pin = w("synth_phred.fastq", _cases.long_fastq_bytes(inp.preads))
         oin = w("odd.fastq", _cases.odd_fastq_bytes(inp.preads))
         kin = w("synth_kmer.fastq", _cases.long_fastq_bytes(inp.kreads))
+        cin = w("cr_at_eof.fasta", _cases.fasta_cr_at_eof_bytes(inp.kreads))
         n = 0
         todo = sorted(gold.items())
         if mode != "default":  # the other ingest / rank paths: every third golden plus all trim/split ones
@@ -75,7 +76,8 @@ def test_cli_matches_reference_binary_byte_for_byte(mode):
             if key == "bad_fastq":
                 inpath = os.path.join(FIX, "test_bad_fastq.fastq")
             elif parts[0] == "odd_format":
-                inpath = oin  # multi-line FASTQ, CRLF, blank lines: the kseq record grammar (src/kseq.h:176-224)
+                # multi-line FASTQ, CRLF, blank lines: the kseq record grammar (src/kseq.h:176-224); a last line that is a bare '\r'
+                inpath = cin if parts[1] == "cr_at_eof" else oin
             elif parts[0] == "c1":
                 inpath = c1  # BASELINE.json configs[0]: 10k reads x 5 kbp --min_length 1000 --keep_percent 90
             elif parts[0] in ("sort", "trim", "split"):
@@ -111,6 +113,15 @@ def test_cli_fasta_input_and_gz(tmp_path):
     rc2, out2, keep2, err2 = run(["--target_bases", "5000", str(gz)], str(tmp_path), {"FLX_CLI_NO_STREAM": "1"})
     rc3, out3, keep3, err3 = run(["--target_bases", "5000", str(gz)], str(tmp_path), {"FLX_CLI_BLOCK_BYTES": "700"})
     assert (rc2, out2, keep2) == (rc, out, keep) and (rc3, out3, keep3) == (rc, out, keep)
+
+
+def test_cli_window_size_narrows_like_the_reference(tmp_path):
+    """The reference stores --window_size in an int (src/arguments.h:90): 2^32 + 100 scores with a window of 100."""
+    fx = os.path.join(FIX, "test_sort.fastq")
+    a = run(["--window_size", "100", "--target_bases", "10001", "--verbose", fx], str(tmp_path))
+    b = run(["--window_size", "4294967396", "--target_bases", "10001", "--verbose", fx], str(tmp_path))
+    c = run(["--window_size", "250", "--target_bases", "10001", "--verbose", fx], str(tmp_path))
+    assert a[0] == 0 and a == b and a[3] != c[3]
 
 
 def test_cli_verbose_scores(tmp_path):

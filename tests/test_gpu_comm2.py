@@ -134,3 +134,32 @@ def test_cli_two_ranks_on_one_gpu(tmp_path, shim):
             assert len(one.stdout) > 0 and two.stdout == one.stdout, (args, gpus)
             keep = lambda e: [l.split("\r")[-1] for l in e.decode().split("\n") if any(t in l for t in ("target:", "keeping", "after ", "not enough", "already"))]
             assert keep(two.stderr) == keep(one.stderr), (args, gpus)
+
+
+def test_cli_gpus_launch_fails_fast_and_clean(tmp_path):
+    """--gpus N must not hang or leave anything behind when the job cannot start: more ranks than visible GPUs is refused
+    before any fork; ranks that cannot form a communicator (here: real RCCL refuses three ranks on ONE device) end the whole job
+    with a message, exit code 1, no orphan process and no temporary directory."""
+    import glob
+    import time
+    fq = tmp_path / "c1.fastq"
+    fq.write_bytes(_cases.c1_fastq_bytes(n=200, length=2000))
+    env = dict(os.environ, LANG="C", LC_ALL="C", TMPDIR=str(tmp_path))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FLX_DEVICE"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([BIN, "--gpus", "60", "--target_bases", "100000", str(fq)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=env, timeout=120)
+    assert r.returncode == 1 and b"--gpus 60 but only" in r.stderr and r.stdout == b""
+    env2 = dict(env, FLX_DEVICE="0")
+    env2.pop("FLX_RCCL_LIB", None)
+    r = subprocess.run([BIN, "--gpus", "3", "--target_bases", "100000", str(fq)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=env2, timeout=120)
+    assert r.returncode == 1 and b"Error" in r.stderr and r.stdout == b""
+    assert time.time() - t0 < 90
+    assert glob.glob(str(tmp_path / "flx_*")) == []  # the private directory of the output parts is gone
+    # a WORLD_SIZE inherited from some launcher's shell does not turn a plain run into a rank waiting for peers
+    env3 = dict(env, WORLD_SIZE="4", RANK="0")
+    one = subprocess.run([BIN, "--target_bases", "100000", str(fq)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    two = subprocess.run([BIN, "--target_bases", "100000", str(fq)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env3, timeout=120)
+    assert one.returncode == 0 and two.returncode == 0 and two.stdout == one.stdout and len(one.stdout) > 0
