@@ -433,6 +433,11 @@ int main(int argc, char **argv) {
     std::cerr << "\n";
     g_timing = getenv("FLX_CLI_TIMING") != nullptr;
     g_t0 = now_s();
+    if (g_timing) {
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        fprintf(stderr, "[timing] main() reached at wall clock %.3f\n", ts.tv_sec % 100000 + ts.tv_nsec * 1e-9);
+    }
     flx_ctx *ctx = nullptr;
     {
         const char *dev = getenv("FLX_DEVICE");
@@ -567,7 +572,9 @@ int main(int argc, char **argv) {
     prm.min_mean_q_set = args.min_mean_q_set; prm.min_mean_q = args.min_mean_q;
     prm.min_window_q_set = args.min_window_q_set; prm.min_window_q = args.min_window_q;
     prm.trim = args.trim; prm.split_set = args.split_set; prm.split = args.split;
-    uint64_t chunk_bytes = streamed ? std::max<uint64_t>(4096, BlockReader::block_bytes()) : 1ull << 30, chunk_reads = 4u << 20;
+    // two pinned staging slots of this size: pinning costs ~0.2 s per GiB and again when unpinned, so the slots are kept at
+    // 256 MiB (profiles/r03_e2e.txt: 1 GiB slots cost a 2 GB input 0.45 s of 1.3 s)
+    uint64_t chunk_bytes = streamed ? std::max<uint64_t>(4096, BlockReader::block_bytes()) : 256ull << 20, chunk_reads = 4u << 20;
     if (const char *e = getenv("FLX_CLI_CHUNK_MB")) chunk_bytes = std::max<uint64_t>(1, (uint64_t)atoll(e)) << 20;
     if (const char *e = getenv("FLX_CLI_CHUNK_BYTES")) chunk_bytes = std::max<uint64_t>(4096, (uint64_t)atoll(e));  // tests force many chunks
 
@@ -608,6 +615,9 @@ int main(int argc, char **argv) {
                 uint64_t total = 4096;
                 for (uint64_t i = 0; i < cnt; ++i) total += (((uint64_t)lengths[base + i] + 15) & ~15ull) + (lengths[base + i] >= 1024 ? 128 : 0);
                 chunk_bytes = std::min(chunk_bytes, total);
+                // small inputs: at least ~8 chunks, so that copy and scoring overlap the packing (but not below 64 MiB)
+                if (!getenv("FLX_CLI_CHUNK_MB") && !getenv("FLX_CLI_CHUNK_BYTES"))
+                    chunk_bytes = std::min(chunk_bytes, std::max<uint64_t>(total / 8, 64ull << 20));
                 chunk_reads = std::min<uint64_t>(chunk_reads, std::max<uint64_t>(1, cnt));
             }
             chunk_bytes = std::max(chunk_bytes, need);
@@ -991,11 +1001,30 @@ int main(int argc, char **argv) {
     }
     stage("output");
 
-    flx_pipeline_destroy(pipe);
-    pipe = nullptr;
-    if (kmers) flx_kmerset_destroy(kmers);
-    flx_ctx_destroy(ctx);
+    // The output is complete.  Unpinning the staging buffers, shutting the HIP runtime down and unmapping the input is work the
+    // kernel does faster when the process simply ends (0.5-0.9 s of 1.3-2.7 s on 2-10 GB inputs): flush and leave, unless a
+    // clean teardown is asked for (FLX_CLI_CLEAN_EXIT=1, the timing report, or ranks to reap).
+    const bool clean_exit = getenv("FLX_CLI_CLEAN_EXIT") != nullptr || g_timing;
+    if (clean_exit) {
+        flx_pipeline_destroy(pipe);
+        pipe = nullptr;
+        stage("pipeline teardown");
+        if (kmers) flx_kmerset_destroy(kmers);
+        flx_ctx_destroy(ctx);
+        stage("context teardown");
+    }
     if (!g_job.finish()) { std::cerr << "Error: a rank failed\n"; return 1; }
+    if (g_timing) {
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        fprintf(stderr, "[timing] main() returns at wall clock %.3f\n", ts.tv_sec % 100000 + ts.tv_nsec * 1e-9);
+    }
     if (rank == 0) std::cerr << "\n";
+    if (!clean_exit) {
+        fflush(stdout);
+        fflush(stderr);
+        _exit(0);
+    }
     return 0;
 }
+
