@@ -43,6 +43,13 @@ L2_LOOKUP_PEAK_G = 261.0     # tools/tabench: cache LINES per second from an L2-
 REF_LEN = 5_000_000
 
 
+def source_sha16(name):
+    """sha256[:16] of a kernel source file: figures quoted from profiles/ carry the hash of the source they were measured on."""
+    import hashlib
+    with open(os.path.join(ROOT, "filtlong_amd", "csrc", name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def _run_ref_bench(argv):
     ref_bench = os.path.join(ROOT, "oracle", "_ref", "ref_bench")
     env = dict(os.environ, LANG="C", LC_ALL="C")
@@ -260,7 +267,7 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
     fpath = os.path.join(ROOT, "profiles", "r03_kmer_requests.json")
     if os.path.exists(fpath):
         rec = json.load(open(fpath)).get(cfg)
-        if rec and rec.get("kernel") == cover_kernel:
+        if rec and rec.get("kernel") == cover_kernel and rec.get("kernel_source_sha16") == source_sha16("score_kmer.hip"):
             req = {"far_requests": rec["far_requests_per_base"] * b.bases, "traffic_bytes": rec["traffic_bytes_per_base"] * b.bases,
                    "l2_hits": rec["l2_hit_requests_per_base"] * b.bases}
     algo_bytes = b.bases + 33 * n + 25 * nc  # L + 8 + 25 per read, 8 + 17 per child
@@ -484,11 +491,12 @@ def main():
         # FETCH_SIZE x2 on gfx950 — calibrated for this kernel's 64-byte-per-read pattern on a known byte count,
         # profiles/r02_microbench.txt), recorded in profiles/ — NOT measured in this run; only quoted for the same workload.
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic_c2.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic_c2.json")
         if os.path.exists(tpath) and n == 10_000_000 and not args.fixed_len and args.window_size == 250 and profile == 0:
             rec = json.load(open(tpath))
-            if rec.get("kernel") == kernel_name:
-                traffic, traffic_src = int(rec["traffic_bytes"]), "profiles/r02_traffic_c2.json (PMC pass of this command, not this run)"
+            # only quoted while it still describes this kernel: same kernel name AND the kernel's source file unchanged since the pass
+            if rec.get("kernel") == kernel_name and rec.get("kernel_source_sha16") == source_sha16("score_phred_regs.hip"):
+                traffic, traffic_src = int(rec["traffic_bytes"]), "profiles/r03_traffic_c2.json (PMC pass of this command, not this run)"
         info = ctx.device_info()
         out = {
             "metric": "Mbases/s scored+sorted",

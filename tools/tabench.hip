@@ -98,6 +98,40 @@ __global__ void __launch_bounds__(256) k_mixed2(const uint32_t *small, uint32_t 
     if (acc == 0x12345) out[0] = acc;
 }
 
+// SCALAR path: every wave issues 8 s_load_dword to random addresses per iteration (one request per WAVE, not per lane), with
+// V vector far lookups per lane beside them: is the scalar data cache's miss path an independent route to far memory?
+template <int V>
+__global__ void __launch_bounds__(256) k_scalar(const uint32_t *big, uint64_t big_mask, int iters, uint32_t *out) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * 256u + threadIdx.x) >> 6);
+    uint64_t xs = wave * 0x9E3779B97F4A7C15ull + 777;                       // wave-uniform stream (SGPRs)
+    uint64_t x = (blockIdx.x * 256ull + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;  // per-lane stream
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        uint32_t f[V > 0 ? V : 1];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            f[j] = big[(x >> 20) & big_mask];
+        }
+        uint32_t s0, s1, s2, s3, s4, s5, s6, s7;
+        const uint32_t *p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            xs = xs * 6364136223846793005ull + 1442695040888963407ull;
+            p[j] = big + ((xs >> 20) & big_mask);
+        }
+        asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %9, 0x0\n\ts_load_dword %2, %10, 0x0\n\ts_load_dword %3, %11, 0x0\n\t"
+                     "s_load_dword %4, %12, 0x0\n\ts_load_dword %5, %13, 0x0\n\ts_load_dword %6, %14, 0x0\n\ts_load_dword %7, %15, 0x0\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3), "=&s"(s4), "=&s"(s5), "=&s"(s6), "=&s"(s7)
+                     : "s"(p[0]), "s"(p[1]), "s"(p[2]), "s"(p[3]), "s"(p[4]), "s"(p[5]), "s"(p[6]), "s"(p[7]));
+        acc ^= s0 ^ s1 ^ s2 ^ s3 ^ s4 ^ s5 ^ s6 ^ s7;
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc ^= f[j];
+    }
+    if (acc == 0x12345) out[0] = acc;
+}
+
 // far lookups only, F per iteration (same loop shape as k_mixed)
 template <int F>
 __global__ void __launch_bounds__(256) k_far(const uint32_t *big, uint64_t big_mask, int iters, uint32_t *out) {
@@ -152,7 +186,7 @@ static float timed(L launch) {
 }
 
 int main(int argc, char **argv) {
-    const bool only7 = argc > 1 && argv[1][0] == '7';
+    const bool only7 = argc > 1 && (argv[1][0] == '7' || argv[1][0] == '8');
     const uint64_t big_bytes = 512ull << 20;
     uint32_t *buf, *out;
     CK(hipMalloc(&buf, big_bytes));
@@ -212,6 +246,19 @@ int main(int argc, char **argv) {
             printf("F %d: mixed %8.3f ms   far alone %8.3f ms   L2 alone %8.3f ms   (sum %8.3f)\n", i, ms[i], fs[i], m0, m0 + fs[i]);
         printf("far alone, 16 in flight per thread: %7.1f G/s;  1 in flight: %7.1f G/s\n", per_iter * 100 / f16 / 1e6, per_iter / 16 * 100 / f1 / 1e6);
     }
+    }
+    printf("# (8) scalar path: 8 s_load_dword per wave and iteration to random addresses in 512 MiB, with V vector far lookups per lane beside them\n");
+    {
+        const uint64_t bm = big_bytes / 4 - 1;
+        const double waves = (double)blocks * 4;
+        float s0 = timed([&](int it) { hipLaunchKernelGGL((k_scalar<0>), dim3(blocks), dim3(256), 0, 0, buf, bm, it * 8, out); });
+        float s1 = timed([&](int it) { hipLaunchKernelGGL((k_scalar<1>), dim3(blocks), dim3(256), 0, 0, buf, bm, it * 8, out); });
+        float s4 = timed([&](int it) { hipLaunchKernelGGL((k_scalar<4>), dim3(blocks), dim3(256), 0, 0, buf, bm, it * 8, out); });
+        float f1 = timed([&](int it) { hipLaunchKernelGGL((k_far<1>), dim3(blocks), dim3(256), 0, 0, buf, bm, it * 8, out); });
+        float f4 = timed([&](int it) { hipLaunchKernelGGL((k_far<4>), dim3(blocks), dim3(256), 0, 0, buf, bm, it * 8, out); });
+        printf("scalar alone: %8.3f ms = %6.2f G scalar requests/s\n", s0, waves * 8 * 800 / s0 / 1e6);
+        printf("V=1: scalar+vector %8.3f ms, vector alone %8.3f ms  -> vector %6.1f G/s + scalar %6.2f G/s\n", s1, f1, (double)blocks * 256 * 800 / s1 / 1e6, waves * 8 * 800 / s1 / 1e6);
+        printf("V=4: scalar+vector %8.3f ms, vector alone %8.3f ms  -> vector %6.1f G/s + scalar %6.2f G/s\n", s4, f4, (double)blocks * 256 * 4 * 800 / s4 / 1e6, waves * 8 * 800 / s4 / 1e6);
     }
     printf("# (7) 16 lookups in a table of S MiB + 4 far lookups (512 MiB) per iteration, far loads plain / nt: ms per 100 iterations\n");
     {
