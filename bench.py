@@ -564,6 +564,24 @@ def main():
                     ts.append((time.perf_counter() - t1) * 1e3)
                 extras.setdefault("global_stage_ms", {})[name] = round(min(ts), 3)
             os.environ.pop("FLX_RANK_SORT", None)
+            # (1b) the exact-tie fallback (the reference's own std::sort over every entry on the host, csrc/rank.hip
+            #      exact_host_cut), forced on the same records: its cost when an order-dependent tie group straddles the cut
+            sel_flags = flags0.clone()
+            ctx.rank_and_cut_dev(n, p_mean, p_win, p_len, sel_flags.data_ptr(), target_bases=target, total_bases=total_bases)
+            os.environ["FLX_RANK_EXACT"] = "1"
+            try:
+                fb_flags = flags0.clone()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                fb = ctx.rank_and_cut_dev(n, p_mean, p_win, p_len, fb_flags.data_ptr(), target_bases=target, total_bases=total_bases)
+                torch.cuda.synchronize()
+                extras["exact_fallback_ms"] = {"ms": round((time.perf_counter() - t1) * 1e3, 1), "reads": n,
+                                               "taken": int(fb.exact_fallback), "host_threads": os.cpu_count(),
+                                               "same_flags_as_select": bool(torch.equal(fb_flags, sel_flags)),
+                                               "kept_bases": int(fb.kept_bases)}
+            finally:
+                os.environ.pop("FLX_RANK_EXACT", None)
+            del sel_flags, fb_flags
             # (2) the same Phred workload with a wide quality spread
             ctx.synth_qual_dev(synth.SEED, b.d_plane.data_ptr(), plane_bytes, b.d_off.data_ptr(), b.d_len.data_ptr(),
                                b.d_ids.data_ptr(), n, profile=1)

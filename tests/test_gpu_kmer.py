@@ -272,6 +272,18 @@ def test_prefilter_and_fold_variants_give_identical_results(be, synth, monkeypat
     assert len(base) == len(alt)
     for (name, _s, _q), a, b in zip(reads, base, alt):
         assert bits(a) == bits(b), name
+    # the two implementations of the coverage kernel: the wave-level one (pair tables, outermost-member search, far-first spans;
+    # default) and round 2's workgroup-per-read kernel (one bitmap lookup per candidate run end) — same coverage, every field
+    monkeypatch.delenv("FLX_KMER_PREFILTER")
+    monkeypatch.delenv("FLX_KMER_FOLD")
+    monkeypatch.setenv("FLX_KMER_COVER", "v2")
+    for ks_kw in (dict(assembly=synth["contigs"]), dict(short_files=synth["sr"])):
+        monkeypatch.setenv("FLX_KMER_COVER", "v2")
+        old_k = be.score(reads, pkw, be.kmers(**ks_kw))
+        monkeypatch.delenv("FLX_KMER_COVER")
+        new_k = be.score(reads, pkw, be.kmers(**ks_kw))
+        for (name, _s, _q), a, b in zip(reads, old_k, new_k):
+            assert bits(a) == bits(b), name
 
 
 def test_reads2_gather_matches_oracle(ctx, be, synth):
