@@ -481,6 +481,7 @@ struct FoldArgs {
     const int32_t *first;
     const int32_t *last;
     int ws;
+    int ring_words;  // RING kernels: words per lane in the LDS ring (a power of two)
     double ws_d;
     double delta;  // fl(1.0 / ws): the value of q/ws for a covered base (src/read.cpp:228-229)
     double clamp;  // 0.5 / ws
@@ -524,7 +525,7 @@ __device__ __forceinline__ double window_result(const FoldArgs &a, int len, int 
 // MODE 3: parent + count children at WORD level — a zero run can only be a bad range if it starts at position 0, reaches
 // the end of the read, or is at least --split long; with --split >= 32 (or unset) every such run crosses a 32-bit word
 // boundary, so the runs that lie inside one word never matter and the parent keeps MODE 0's branch-free steady state.
-template <int MODE>
+template <int MODE, bool RING>
 __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
     const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = slot < a.n_reads;
@@ -570,14 +571,20 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
     };
 
     // Two word streams over the read's coverage row — the leading edge (position j) and the trailing edge (position
-    // j - ws).  Each lane walks its own row, so a 4-byte load would still pull a whole 64-byte sector through the fabric
-    // (16x amplification: the rows of all resident lanes do not fit L1/L2 together).  The streams therefore move in
-    // 16-byte blocks (rows are 16-byte aligned and padded), one block ahead of their use.
+    // j - ws).  Each lane walks its own row: 64 lanes = 64 distinct lines per load instruction, and the rows of all resident
+    // lanes do not fit L1 / L2 together, so a line is gone again before the lane comes back to it — every load of a new piece
+    // is a far request (55 G/s, profiles/r03_microbench.txt).
+    //   RING (default): the row is read ONCE, 64 bytes per lane at a time (four 16-byte loads issued back to back to one
+    //   half line, a block ahead of their use), and parked in a per-lane ring of words in LDS (word k of lane l at
+    //   ((k mod R) * 64 + l): every access of a wave is conflict free and touches only the lane's own words, so no barrier).
+    //   Both edges then come out of the ring with ds_read_b32: one far request per 512 positions instead of two per 128,
+    //   which had made the folds request bound (round 2: 28 of the 36 ms per 10^11 positions).
+    //   !RING: both streams straight from global memory in 16-byte blocks (windows too long for the ring).
     const int n_words = (L + 31) >> 5;
-    struct WStream { uint4 cur, nxt; int blk; };
     auto ldq = [&](int b) -> uint4 {
         return (b * 4 < n_words) ? *reinterpret_cast<const uint4 *>(row + 4 * (size_t)b) : make_uint4(0u, 0u, 0u, 0u);
     };
+    struct WStream { uint4 cur, nxt; int blk; };
     auto advance = [&](WStream &st, int b) {  // streams only move forward, one block at a time
         if (b != st.blk) {
             st.cur = st.nxt;
@@ -591,19 +598,49 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
         const uint32_t v = c == 0 ? q.x : c == 1 ? q.y : c == 2 ? q.z : q.w;
         return wi < n_words ? v : 0u;  // the padding of the last block is not coverage
     };
-    WStream lead = {ldq(0), ldq(1), 0};
+    WStream lead = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), 0};
+    if (!RING) lead = {ldq(0), ldq(1), 0};
     WStream trail = lead;
-    uint32_t lead_w = word(lead, 0), trail_w = lead_w;
+    extern __shared__ uint32_t fold_ring[];
+    const int R = a.ring_words;  // power of two >= 16 + ceil(ws / 32) + 2
+    uint32_t *ring = fold_ring + (size_t)(threadIdx.x >> 6) * (size_t)R * 64 + (threadIdx.x & 63);
+    uint4 nq[4];       // the block after the newest one in the ring
+    int have_blk = -1;  // newest block in the ring (wave-uniform: every lane is at the same position)
+    if (RING) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nq[q] = ldq(q);
+    }
+    auto ring_fill = [&](int wi) {  // word wi (and everything up to the end of its block) into the ring; wi only moves forward
+        const int b = wi >> 4;
+        if (b > have_blk) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = (b * 16 + 4 * q) & (R - 1);
+                ring[(k + 0) * 64] = nq[q].x; ring[(k + 1) * 64] = nq[q].y; ring[(k + 2) * 64] = nq[q].z; ring[(k + 3) * 64] = nq[q].w;
+            }
+            have_blk = b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nq[q] = ldq((b + 1) * 4 + q);
+        }
+    };
+    auto ring_word = [&](int wi) -> uint32_t { return wi < n_words ? ring[(wi & (R - 1)) * 64] : 0u; };
+    auto lead_word = [&](int wi) -> uint32_t {  // the word holding the leading edge
+        if (RING) { ring_fill(wi); return ring_word(wi); }
+        advance(lead, wi >> 2);
+        return word(lead, wi);
+    };
+    auto trail_word = [&](int wi) -> uint32_t {  // words of the trailing edge: never ahead of the leading one
+        if (RING) return ring_word(wi);
+        advance(trail, wi >> 2);
+        return word(trail, wi);
+    };
+    uint32_t lead_w = 0, trail_w = 0;
     int Lmin = live ? L : 0x7fffffff;
     for (int o = 32; o > 0; o >>= 1) Lmin = min(Lmin, __shfl_xor(Lmin, o, 64));
     const unsigned int d_lo = (unsigned int)(__double_as_longlong(delta) & 0xffffffffll);
     const unsigned int d_hi = (unsigned int)(__double_as_longlong(delta) >> 32);
     for (int j0 = 0; j0 < Lmax; j0 += 32) {
-      {
-          const int wi = j0 >> 5;
-          advance(lead, wi >> 2);
-          lead_w = word(lead, wi);
-      }
+      lead_w = lead_word(j0 >> 5);
       if (MODE == 4) {
           // ---- children only: events per word, then 32 predicated positions ----
           int ev_end = -1, ev_zs = 0, snap = -1;
@@ -631,9 +668,8 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
           uint32_t tw = 0;
           if (tj0 > -32) {
               const int twi = tj0 >> 5, sh = tj0 & 31;  // twi == -1 for the word that straddles position 0
-              if (twi >= 0) advance(trail, twi >> 2);
-              const uint32_t lo = twi >= 0 ? word(trail, twi) : 0u;
-              tw = sh ? __builtin_amdgcn_alignbit(word(trail, twi + 1), lo, (unsigned)sh) : lo;
+              const uint32_t lo = twi >= 0 ? trail_word(twi) : 0u;
+              tw = sh ? __builtin_amdgcn_alignbit(trail_word(twi + 1), lo, (unsigned)sh) : lo;
           }
 #pragma unroll
           for (int i = 0; i < 32; ++i) {
@@ -694,9 +730,8 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
       if ((MODE == 0 || MODE == 3) && j0 >= ws && j0 + 32 <= Lmin) {
           // ---- steady state, parent only: 32 positions, every lane active, no per-bit control flow ----
           const int tj0 = j0 - ws, sh = tj0 & 31, twi = tj0 >> 5;
-          advance(trail, twi >> 2);
-          const uint32_t t0 = word(trail, twi);
-          const uint32_t tw = sh ? __builtin_amdgcn_alignbit(word(trail, twi + 1), t0, (unsigned)sh) : t0;
+          const uint32_t t0 = trail_word(twi);
+          const uint32_t tw = sh ? __builtin_amdgcn_alignbit(trail_word(twi + 1), t0, (unsigned)sh) : t0;
           P.cnt += __popc(lead_w);
 #pragma unroll
           for (int i = 0; i < 32; ++i) {
@@ -715,8 +750,7 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
         if (j >= Lmax) break;
         const int tj = j - ws;
         if (tj >= 0 && ((tj & 31) == 0 || jj == 0)) {
-            advance(trail, tj >> 7);
-            trail_w = word(trail, tj >> 5);
+            trail_w = trail_word(tj >> 5);
         }
         const bool act = j < L;
         const uint32_t b = act ? ((lead_w >> (j & 31)) & 1u) : 0u;
@@ -803,6 +837,27 @@ __global__ void k_widen_u32_i64(uint64_t n, const uint32_t *in, int64_t *out) {
 }
 
 }  // namespace
+
+// the fold kernels: with the LDS ring when it fits (R words per lane; 4 waves per workgroup up to R = 64, one wave up to R = 512),
+// else (windows beyond ~15 000 positions) both streams from global memory
+template <int MODE>
+static int launch_fold(flx_ctx *ctx, FoldArgs &a) {
+    int R = 32;
+    while (R < 18 + (a.ws + 31) / 32) R *= 2;
+    const char *env = getenv("FLX_KMER_FOLD_STREAMS");  // "global": the round-2 data path (second implementation, tests)
+    const bool ring = R <= 512 && !(env && strcmp(env, "global") == 0);
+    const unsigned threads = (!ring || R <= 64) ? 256u : 64u;
+    const unsigned nb = (unsigned)((a.n_reads + threads - 1) / threads);
+    a.ring_words = R;
+    if (ring) {
+        const size_t lds = (size_t)(threads / 64) * (size_t)R * 256;
+        FLX_HIP(ctx, hipFuncSetAttribute((const void *)k_kmer_fold<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_kmer_fold<MODE, true>), dim3(nb), dim3(threads), lds, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL((k_kmer_fold<MODE, false>), dim3(nb), dim3(threads), 0, ctx->stream, a);
+    }
+    return FLX_OK;
+}
 
 int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_plane, uint64_t plane_bytes,
                        const uint64_t *d_offsets, const int32_t *d_lengths, const uint32_t *d_order,
@@ -900,7 +955,7 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
 
     if (!want_children) {
         flx_time_begin(ctx, "flx_score_kmer_fold");
-        hipLaunchKernelGGL(k_kmer_fold<0>, dim3(nb), dim3(256), 0, st, a);
+        FLX_CHECK(launch_fold<0>(ctx, a));
         flx_time_end(ctx);
         if (out->child_offsets) FLX_HIP(ctx, hipMemsetAsync(out->child_offsets, 0, (n_reads + 1) * 8, st));
         FLX_HIP(ctx, hipGetLastError());
@@ -915,9 +970,9 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     const char *fold_env = getenv("FLX_KMER_FOLD");
     const bool bit_level = (params->split_set && params->split < 32) || (fold_env && strcmp(fold_env, "bits") == 0);
     if (bit_level)
-        hipLaunchKernelGGL(k_kmer_fold<1>, dim3(nb), dim3(256), 0, st, a);  // runs inside one word can be bad ranges
+        FLX_CHECK(launch_fold<1>(ctx, a));  // runs inside one word can be bad ranges
     else
-        hipLaunchKernelGGL(k_kmer_fold<3>, dim3(nb), dim3(256), 0, st, a);
+        FLX_CHECK(launch_fold<3>(ctx, a));
     flx_time_end(ctx);
     // child_offsets = exclusive scan of the counts (n + 1 entries; the last one is the total)
     hipLaunchKernelGGL(k_widen_u32_i64, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, st, n_reads + 1,
@@ -934,9 +989,9 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
         a.child_offsets = out->child_offsets;
         flx_time_begin(ctx, "flx_score_kmer_fold");
         if (bit_level)
-            hipLaunchKernelGGL(k_kmer_fold<2>, dim3(nb), dim3(256), 0, st, a);
+            FLX_CHECK(launch_fold<2>(ctx, a));
         else
-            hipLaunchKernelGGL(k_kmer_fold<4>, dim3(nb), dim3(256), 0, st, a);
+            FLX_CHECK(launch_fold<4>(ctx, a));
         flx_time_end(ctx);
     }
     FLX_HIP(ctx, hipGetLastError());

@@ -272,6 +272,20 @@ def test_prefilter_and_fold_variants_give_identical_results(be, synth, monkeypat
     assert len(base) == len(alt)
     for (name, _s, _q), a, b in zip(reads, base, alt):
         assert bits(a) == bits(b), name
+    # the two data paths of the fold kernels: coverage rows through the per-lane LDS ring (default) and both window edges
+    # streamed from global memory (what windows too long for the ring use); also with windows that need the longer rings
+    monkeypatch.delenv("FLX_KMER_PREFILTER")
+    monkeypatch.delenv("FLX_KMER_FOLD")
+    for ws in (250, 31, 1500, 5000):
+        pk = dict(pkw, window_size=ws)
+        ring = be.score(reads, pk, be.kmers(assembly=synth["contigs"]))
+        monkeypatch.setenv("FLX_KMER_FOLD_STREAMS", "global")
+        glob_ = be.score(reads, pk, be.kmers(assembly=synth["contigs"]))
+        monkeypatch.delenv("FLX_KMER_FOLD_STREAMS")
+        for (name, _s, _q), a, b in zip(reads, ring, glob_):
+            assert bits(a) == bits(b), (name, ws)
+    monkeypatch.setenv("FLX_KMER_PREFILTER", "0")
+    monkeypatch.setenv("FLX_KMER_FOLD", "bits")
     # the two implementations of the coverage kernel: the wave-level one (pair tables, outermost-member search, far-first spans;
     # default) and round 2's workgroup-per-read kernel (one bitmap lookup per candidate run end) — same coverage, every field
     monkeypatch.delenv("FLX_KMER_PREFILTER")

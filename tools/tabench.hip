@@ -132,6 +132,26 @@ __global__ void __launch_bounds__(256) k_scalar(const uint32_t *big, uint64_t bi
     if (acc == 0x12345) out[0] = acc;
 }
 
+// far lookups of 32 bytes: two 16-byte loads from one 32-byte aligned entry (W = 2), one 16-byte load (W = 1) or one byte (W = 0)
+template <int W>
+__global__ void __launch_bounds__(256) k_far_wide(const uint4 *big, uint64_t mask_entries, int iters, uint32_t *out) {
+    uint64_t x = (blockIdx.x * 256ull + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        uint4 v[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            const uint64_t e = (x >> 20) & mask_entries;
+            if (W == 0) { v[j][0].x = reinterpret_cast<const uint8_t *>(big)[e * 32]; v[j][0].y = v[j][0].z = v[j][0].w = 0; v[j][1] = v[j][0]; }
+            else { v[j][0] = big[e * 2]; v[j][1] = W == 2 ? big[e * 2 + 1] : v[j][0]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc ^= v[j][0].x ^ v[j][0].w ^ v[j][1].y ^ v[j][1].z;
+    }
+    if (acc == 0x12345) out[0] = acc;
+}
+
 // far lookups only, F per iteration (same loop shape as k_mixed)
 template <int F>
 __global__ void __launch_bounds__(256) k_far(const uint32_t *big, uint64_t big_mask, int iters, uint32_t *out) {
@@ -186,7 +206,7 @@ static float timed(L launch) {
 }
 
 int main(int argc, char **argv) {
-    const bool only7 = argc > 1 && (argv[1][0] == '7' || argv[1][0] == '8');
+    const bool only7 = argc > 1 && (argv[1][0] == '7' || argv[1][0] == '8' || argv[1][0] == '9');
     const uint64_t big_bytes = 512ull << 20;
     uint32_t *buf, *out;
     CK(hipMalloc(&buf, big_bytes));
@@ -246,6 +266,15 @@ int main(int argc, char **argv) {
             printf("F %d: mixed %8.3f ms   far alone %8.3f ms   L2 alone %8.3f ms   (sum %8.3f)\n", i, ms[i], fs[i], m0, m0 + fs[i]);
         printf("far alone, 16 in flight per thread: %7.1f G/s;  1 in flight: %7.1f G/s\n", per_iter * 100 / f16 / 1e6, per_iter / 16 * 100 / f1 / 1e6);
     }
+    }
+    printf("# (9) far lookups of one byte / 16 bytes / 32 bytes (two 16-byte loads of one aligned entry), 4 in flight per thread, 512 MiB\n");
+    {
+        const uint64_t me = big_bytes / 32 - 1;
+        float w0 = timed([&](int it) { hipLaunchKernelGGL((k_far_wide<0>), dim3(blocks), dim3(256), 0, 0, (const uint4 *)buf, me, it * 4, out); });
+        float w1 = timed([&](int it) { hipLaunchKernelGGL((k_far_wide<1>), dim3(blocks), dim3(256), 0, 0, (const uint4 *)buf, me, it * 4, out); });
+        float w2 = timed([&](int it) { hipLaunchKernelGGL((k_far_wide<2>), dim3(blocks), dim3(256), 0, 0, (const uint4 *)buf, me, it * 4, out); });
+        const double n = (double)blocks * 256 * 4 * 400;
+        printf("byte %7.1f G entries/s   16 B %7.1f G entries/s   32 B (2 loads) %7.1f G entries/s\n", n / w0 / 1e6, n / w1 / 1e6, n / w2 / 1e6);
     }
     printf("# (8) scalar path: 8 s_load_dword per wave and iteration to random addresses in 512 MiB, with V vector far lookups per lane beside them\n");
     {
