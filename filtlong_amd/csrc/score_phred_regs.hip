@@ -540,29 +540,37 @@ int launch_one(flx_ctx *ctx, PhredArgs &a) {
     return FLX_OK;
 }
 
-// waves per CU: 16 (4 per SIMD, <= 128 VGPRs) for rings of up to 12 pieces, 12 (<= 168 VGPRs) up to 20 pieces, 8 beyond;
-// the bank-private tables (66 KB) leave room for 11 slots of 8 KiB
+// waves per CU: 16 (4 per SIMD, <= 128 VGPRs) for rings of up to 12 pieces, 12 (<= 168 VGPRs) up to 20 pieces, 8 (<= 256) up to
+// 43 pieces, 4 beyond (one wave per SIMD: the ring spills into the accumulator half of the unified register file, up to
+// 256 + 102 registers at ws = 1007); the bank-private tables (66 KB) leave room for 11 slots of 8 KiB
 template <int A, bool PRIV>
 struct WavesFor {
-    static constexpr int plain = A <= 7 ? 16 : A <= 15 ? 12 : 8;
+    static constexpr int plain = A <= 7 ? 16 : A <= 15 ? 12 : A <= 38 ? 8 : 4;
     static constexpr int value = PRIV && plain > 11 ? 11 : plain;
 };
 
 template <int A>
 int launch_a(flx_ctx *ctx, PhredArgs &a, bool priv) {
-    return priv ? launch_one<A, true, WavesFor<A, true>::value>(ctx, a) : launch_one<A, false, WavesFor<A, false>::value>(ctx, a);
+    if constexpr (A >= 32) {  // big rings: plain tables only (each instantiation takes ~30 s to compile)
+        return launch_one<A, false, WavesFor<A, false>::value>(ctx, a);
+    } else {
+        return priv ? launch_one<A, true, WavesFor<A, true>::value>(ctx, a) : launch_one<A, false, WavesFor<A, false>::value>(ctx, a);
+    }
 }
 
 }  // namespace
 
-// The instantiations (window sizes 1..511, A = ws / 16 = 0..31) are spread over six translation units of this same file
-// (-DFLX_REGS_PART=0..5, see the Makefile) so that they compile in parallel.  Rings beyond 36 pieces (A >= 32) are no
-// longer kept in registers by hipcc (the array goes to scratch memory): from ws = 512 on the LDS-ring / stream kernels of
-// score_phred.hip take over.
+// The instantiations (window sizes 1..1007, A = ws / 16 = 0..62) are spread over fourteen translation units of this same file
+// (-DFLX_REGS_PART=0..13, see the Makefile) so that they compile in parallel.  Rings beyond 36 pieces (A >= 32) need
+// -mllvm -unroll-max-upperbound (the prologue loop has an early exit: LLVM unrolls such loops only up to 8 iterations by
+// default, and a ring that is not indexed statically everywhere ends up in scratch memory) and larger unroll thresholds.
 #define FLX_REGS_CASE(AA) \
     case AA:              \
         *launched = true; \
         return launch_a<AA>(ctx, a, priv);
+#define FLX_REGS_CAT2(a, b) a##b
+#define FLX_REGS_CAT(a, b) FLX_REGS_CAT2(a, b)
+#define FLX_REGS_WIDE_NAME FLX_REGS_CAT(flx_launch_score_phred_regs_part, FLX_REGS_PART)
 #if FLX_REGS_PART == 0
 int flx_launch_score_phred_regs_part0(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
     switch (a.ws / 16) { FLX_REGS_CASE(0) FLX_REGS_CASE(1) FLX_REGS_CASE(2) FLX_REGS_CASE(3) FLX_REGS_CASE(4) FLX_REGS_CASE(5) FLX_REGS_CASE(6) FLX_REGS_CASE(7) default: return FLX_OK; }
@@ -583,9 +591,21 @@ int flx_launch_score_phred_regs_part3(flx_ctx *ctx, PhredArgs &a, bool priv, boo
 int flx_launch_score_phred_regs_part4(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
     switch (a.ws / 16) { FLX_REGS_CASE(23) FLX_REGS_CASE(24) FLX_REGS_CASE(25) FLX_REGS_CASE(26) FLX_REGS_CASE(27) default: return FLX_OK; }
 }
-#else
+#elif FLX_REGS_PART == 5
 int flx_launch_score_phred_regs_part5(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
     switch (a.ws / 16) { FLX_REGS_CASE(28) FLX_REGS_CASE(29) FLX_REGS_CASE(30) FLX_REGS_CASE(31) default: return FLX_OK; }
+}
+#else
+// parts 6..13: four ring sizes each, A = 32 + 4 (part - 6) ..: window sizes 512..1007
+int FLX_REGS_WIDE_NAME(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
+    constexpr int A0 = 32 + 4 * (FLX_REGS_PART - 6);
+    switch (a.ws / 16) {
+        FLX_REGS_CASE(A0) FLX_REGS_CASE(A0 + 1) FLX_REGS_CASE(A0 + 2)
+#if FLX_REGS_PART < 13
+        FLX_REGS_CASE(A0 + 3)
+#endif
+        default: return FLX_OK;
+    }
 }
 #endif
 #undef FLX_REGS_CASE
@@ -596,6 +616,9 @@ int flx_launch_score_phred_regs_part2(flx_ctx *ctx, PhredArgs &a, bool priv, boo
 int flx_launch_score_phred_regs_part3(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
 int flx_launch_score_phred_regs_part4(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
 int flx_launch_score_phred_regs_part5(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
+#define FLX_REGS_DECL(P) int flx_launch_score_phred_regs_part##P(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
+FLX_REGS_DECL(6) FLX_REGS_DECL(7) FLX_REGS_DECL(8) FLX_REGS_DECL(9) FLX_REGS_DECL(10) FLX_REGS_DECL(11) FLX_REGS_DECL(12) FLX_REGS_DECL(13)
+#undef FLX_REGS_DECL
 
 namespace {
 // Which table layout?  Plain tables are ~6 % faster when a wavefront's quality values stay within ~32 consecutive table
@@ -636,7 +659,7 @@ int flx_launch_score_phred_stream(flx_ctx *ctx, PhredArgs a) {
 int flx_launch_score_phred_regs(flx_ctx *ctx, PhredArgs a, bool *launched) {
     *launched = false;
     const int A = a.ws / 16;
-    if (A > 31) return FLX_OK;
+    if (A > 62) return FLX_OK;
     const char *env = getenv("FLX_PHRED_TABLES");  // "plain" | "private" | unset = decide from a sample of the data
     bool priv = env && strcmp(env, "private") == 0;
     // scratch: [0,4) ticket, [4,8) redo count, [64, 1088) sample histogram, [2048, 2048 + 4 n) redo list
@@ -675,7 +698,15 @@ int flx_launch_score_phred_regs(flx_ctx *ctx, PhredArgs a, bool *launched) {
     else if (A <= 17) FLX_CHECK(flx_launch_score_phred_regs_part2(ctx, a, priv, launched));
     else if (A <= 22) FLX_CHECK(flx_launch_score_phred_regs_part3(ctx, a, priv, launched));
     else if (A <= 27) FLX_CHECK(flx_launch_score_phred_regs_part4(ctx, a, priv, launched));
-    else FLX_CHECK(flx_launch_score_phred_regs_part5(ctx, a, priv, launched));
+    else if (A <= 31) FLX_CHECK(flx_launch_score_phred_regs_part5(ctx, a, priv, launched));
+    else {
+        typedef int (*part_fn)(flx_ctx *, PhredArgs &, bool, bool *);
+        static const part_fn wide[8] = {flx_launch_score_phred_regs_part6, flx_launch_score_phred_regs_part7, flx_launch_score_phred_regs_part8,
+                                        flx_launch_score_phred_regs_part9, flx_launch_score_phred_regs_part10, flx_launch_score_phred_regs_part11,
+                                        flx_launch_score_phred_regs_part12, flx_launch_score_phred_regs_part13};
+        priv = false;  // big rings come with plain tables only
+        FLX_CHECK(wide[(A - 32) / 4](ctx, a, priv, launched));
+    }
     if (*launched && priv) {
         flx_time_begin(ctx, "flx_score_phred_redo");
         hipLaunchKernelGGL(flx_score_phred_redo, dim3(256), dim3(256), 0, ctx->stream, a);
