@@ -344,3 +344,61 @@ def test_reads2_gather_matches_oracle(ctx, be, synth):
                                             ("child_window_q", np.float64), ("child_passed", np.uint8))}
     empty["child_offsets"] = np.zeros(1, np.uint64)
     assert len(ctx.reads2_gather(np.zeros(0, np.int32), empty)["mean_q"]) == 0
+
+
+def test_cover_kernel_boundaries_vs_oracle(be, synth):
+    """The wave-level coverage kernel at its seams, against the oracle: read lengths around its lane (16) and span (1024) sizes, a
+    single error / a run of errors placed exactly at lane and span boundaries, isolated members (one clean 16-mer in noise),
+    clean reads (the far-first mode), homopolymers and tandem repeats (every position the same few 16-mers), the reverse strand,
+    non-ACGT bytes — each with and without the prefilter, and with --trim / --split so that first / last / children are checked."""
+    import os
+    contigs = synth["contigs"]
+    c0 = contigs[0]
+    rng = np.random.RandomState(99)
+    reads = []
+
+    def add(name, seq):
+        reads.append((name, bytes(seq), b"I" * len(seq)))
+
+    for L in (15, 16, 17, 18, 31, 32, 33, 47, 48, 1007, 1008, 1009, 1023, 1024, 1025, 1039, 1040, 1041, 2047, 2048, 2049, 3071, 3072, 3073, 5000):
+        add("clean_%d" % L, c0[100:100 + L])
+    for pos in (0, 1, 14, 15, 16, 17, 30, 31, 32, 1007, 1008, 1022, 1023, 1024, 1025, 1038, 1039, 1040, 2047, 2048, 2999):
+        r = bytearray(c0[500:3500])
+        r[pos] = ord("ACGT"[("ACGT".index(chr(r[pos])) + 1) % 4])  # one substitution exactly there
+        add("sub_at_%d" % pos, r)
+        r = bytearray(c0[500:3500])
+        for k in range(pos, min(pos + 40, len(r)), 3):  # a burst of errors starting there
+            r[k] = ord("ACGT"[("ACGT".index(chr(r[k])) + 2) % 4])
+        add("burst_at_%d" % pos, r)
+    for pos in (0, 5, 16, 1000, 1008, 1015, 1024, 2031):  # one clean 16-mer (or 17, 31, 32 clean bases) in random noise
+        for keep in (16, 17, 31, 32):
+            r = bytearray(rng.choice(list(b"ACGT"), size=2100).astype(np.uint8).tobytes())
+            r[pos:pos + keep] = c0[7000 + pos:7000 + pos + keep]
+            add("island_%d_%d" % (pos, keep), r)
+    add("homopolymer", b"A" * 2500)
+    add("tandem2", b"AC" * 1300)
+    add("tandem3", b"ACG" * 900)
+    add("noise", rng.choice(list(b"ACGT"), size=3000).astype(np.uint8).tobytes())
+    add("revcomp", _cases.revcomp(c0[2000:4500]))
+    r = bytearray(c0[9000:12000]); r[100] = ord("N"); r[1024] = ord("n"); r[1500:1510] = b"NNNNNNNNNN"; r[2000:2040] = bytes(r[2000:2040]).lower()
+    add("non_acgt", r)
+    # a reference that holds the homopolymer and the repeats as well
+    ref = contigs + [b"A" * 300, b"AC" * 200, c0[100:400] + b"ACG" * 100]
+    orc = _oracle.KmerSet(); orc.add_assembly(ref)
+    for pf in ("1", "0"):
+        os.environ["FLX_KMER_PREFILTER"] = pf
+        try:
+            ks = be.kmers(assembly=ref)
+        finally:
+            del os.environ["FLX_KMER_PREFILTER"]
+        assert len(ks) == len(orc)
+        for pkw in (dict(), dict(trim=True, split=20), dict(trim=True, split=300, window_size=40)):
+            got = be.score(reads, pkw, ks)
+            p = _oracle.make_params(**pkw)
+            for (name, seq, q), o in zip(reads, got):
+                w = _oracle.score_read(seq, q, p, orc, cap=65536)
+                assert w["mean_q"] == o["mean_q"] and w["window_q"] == o["window_q"], (name, pf, pkw, w["mean_q"], o["mean_q"])
+                assert (w["first"], w["last"], w["passed"]) == (o["first"], o["last"], o["passed"]), (name, pf, pkw)
+                assert w["child_ranges"] == o["child_ranges"], (name, pf, pkw)
+                for wc, oc in zip(w["children"], o["children"]):
+                    assert wc["mean_q"] == oc["mean_q"] and wc["window_q"] == oc["window_q"] and wc["passed"] == oc["passed"], (name, pf, pkw)
