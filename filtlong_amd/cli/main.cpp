@@ -665,116 +665,12 @@ int main(int argc, char **argv) {
         return 0;
     };
 
-    for (;;) {
-        Parsed batch_store;
-        Parsed &batch = streamed ? batch_store : kept;
-        if (streamed) {
-            if (!blocks.next(batch)) {
-                if (blocks.io_error) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
-                break;
-            }
-        } else {
-            if (n_batches > 0) break;
-            parse_all(data, batch);
-            stage("parse");
-        }
-        ++n_batches;
-        const std::vector<Record> &recs = batch.recs;
-        // the per-record checks of src/main.cpp:84-117, in file order, then the parser's own end status
-        if (!streamed) seen_names.reserve(recs.size() * 2);
-        for (const Record &r : recs) {
-            total_bases += (long long)r.seq.size();
-            const bool fasta_format = r.qual.empty() && !r.seq.empty();
-            const bool fastq_format = !r.qual.empty() && !r.seq.empty() && r.qual.size() == r.seq.size();
-            any_fasta = any_fasta || fasta_format;
-            any_fastq = any_fastq || fastq_format;
-            if (any_fasta && any_fastq) {
-                std::cerr << "\n\n" << "Error: could not parse input reads" << "\n";
-                std::cerr << "  problem occurred at read " << r.name << "\n";
-                return 1;
-            }
-            if (fasta_format && kmers_empty) {
-                std::cerr << "\n\n" << "Error: FASTA input not supported without an external reference" << "\n";
-                return 1;
-            }
-            std::string_view name = r.name.sv();
-            if (streamed) {  // the block's memory is reused: keep a copy
-                name_arena.emplace_back(name);
-                name = name_arena.back();
-            }
-            if (!seen_names.insert(name).second) { std::cerr << "Error: duplicate read name: " << r.name << "\n"; return 1; }
-            if (streamed) {
-                names.push_back(name);
-                units.note_record(blocks.points, blocks.offset_of(r.name.p - 1), n_records);
-            }
-            ++n_records;
-            if (total_bases - last_progress >= 483611) {
-                last_progress = total_bases;
-                if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)n_records) << " reads (" << int_to_string(total_bases) << " bp)";
-            }
-        }
-        if (batch.status == -2) { std::cerr << "Error: incorrect FASTQ format for read " << batch.bad.name << "\n"; return 1; }
-        if (!streamed) stage("record checks");
-        // this rank's share of the batch: everything when streaming (one rank), else a contiguous block of file order by count
-        uint64_t lo = 0, cnt = recs.size();
-        if (!streamed) {
-            const uint64_t n_all = recs.size();
-            lo = n_all / (uint64_t)world * (uint64_t)rank + std::min<uint64_t>((uint64_t)rank, n_all % (uint64_t)world);
-            cnt = n_all / (uint64_t)world + ((uint64_t)rank < n_all % (uint64_t)world ? 1 : 0);
-            lo_rec = lo;
-            names.reserve(cnt);
-            for (uint64_t i = 0; i < cnt; ++i) names.push_back(recs[lo + i].name.sv());
-        }
-        if (const int rc = score_records(recs, lo, cnt)) return rc;
-    }
-    { std::unordered_set<std::string_view>().swap(seen_names); }
-    if (streamed) units.finish(blocks.points, blocks.end_offset(), n_records);
-    if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)n_records) << " reads (" << int_to_string(total_bases) << " bp)";
-    if (!args.verbose) std::cerr << "\n";  // verbose: after the per-read blocks, as in main.cpp:110-129
-    const bool fasta_output = any_fasta, fastq_output = any_fastq;
-    const uint64_t n = lengths.size();
-    if (!pipe && flx_pipeline_create(ctx, kmers_empty ? nullptr : kmers, &prm, chunk_bytes, chunk_reads, &pipe) != FLX_OK) return fail_flx(ctx, "pipeline");
-    flx_scores res;
-    uint64_t n_scored = 0;
-    if (flx_pipeline_finish(pipe, &res, &n_scored) != FLX_OK || n_scored != n) return fail_flx(ctx, "scoring");
-    const double *mean_q = res.mean_q, *window_q = res.window_q, *c_mean = res.child_mean_q, *c_window = res.child_window_q;
-    const int32_t *c_ranges = res.child_ranges;
-    const uint64_t *child_off = res.child_offsets;
-    if (g_timing) fprintf(stderr, "[timing] %llu chunk(s) of <= %llu MiB\n", (unsigned long long)n_chunks, (unsigned long long)(chunk_bytes >> 20));
-
-    stage("pack + H2D + score (streamed)");
-    // ---- reads2: children replace their parents in place (src/main.cpp:138-147) -----------------------------
-    struct Out { uint64_t rec; int start, end; bool child; std::string name; };
-    std::vector<Out> reads2;
-    std::vector<double> r2_mean, r2_window;
-    std::vector<int32_t> r2_len;
-    std::vector<uint8_t> r2_pass;
-    {
-        // the gather itself is the library's (flx_reads2_gather): values in reads2 order + where every entry came from
-        const uint64_t cap2 = n + res.n_children;
-        r2_mean.resize(cap2); r2_window.resize(cap2); r2_len.resize(cap2); r2_pass.resize(cap2);
-        std::vector<uint32_t> parent2(cap2);
-        std::vector<int64_t> child2(cap2);
-        uint64_t n2_gathered = 0;
-        if (flx_reads2_gather(ctx, n, lengths.data(), &res, cap2, r2_mean.data(), r2_window.data(), r2_len.data(), r2_pass.data(),
-                              parent2.data(), child2.data(), &n2_gathered) != FLX_OK)
-            return fail_flx(ctx, "reads2 gather");
-        r2_mean.resize(n2_gathered); r2_window.resize(n2_gathered); r2_len.resize(n2_gathered); r2_pass.resize(n2_gathered);
-        reads2.reserve(n2_gathered);
-        for (uint64_t j = 0; j < n2_gathered; ++j) {
-            const uint64_t i = parent2[j];
-            if (child2[j] < 0) {
-                reads2.push_back({lo_rec + i, 0, lengths[i], false, std::string(names[i])});
-            } else {
-                const int s0 = c_ranges[2 * child2[j]], e0 = c_ranges[2 * child2[j] + 1];
-                reads2.push_back({lo_rec + i, s0, e0, true, std::string(names[i]) + "_" + std::to_string(s0 + 1) + "-" + std::to_string(e0)});  // read.cpp:135-136
-            }
-        }
-    }
-    size_t longest_name = 0;
-    for (auto &o : reads2) longest_name = std::max(longest_name, o.name.size());
-
-    if (args.verbose) {  // Read::print_verbose_read_info, src/read.cpp:169-194, in file order like the pass-1 loop (main.cpp:110-111)
+    // Read::print_verbose_read_info for reads [0, n_first) (src/read.cpp:169-194), in file order like the pass-1 loop (main.cpp:110-111)
+    auto print_read_blocks = [&](const flx_scores &res, uint64_t n_first) {
+        const double *mean_q = res.mean_q, *window_q = res.window_q, *c_mean = res.child_mean_q, *c_window = res.child_window_q;
+        const int32_t *c_ranges = res.child_ranges;
+        const uint64_t *child_off = res.child_offsets;
+        const uint64_t n = n_first;
         for (uint64_t i = 0; i < n; ++i) {
             const std::string_view rname = names[i];
             std::cerr << "\n" << rname << "\n";
@@ -811,6 +707,141 @@ int main(int argc, char **argv) {
                 }
             }
         }
+    };
+    // --verbose on an ERROR path: the reference scores and prints every read inside its pass-1 loop, so the blocks of the reads in
+    // front of the failing record (for a duplicate name: that record's too) are on stderr before the error line
+    // (src/main.cpp:108-117).  Scoring is batched here: the reads read so far are scored now, then their blocks printed.
+    auto verbose_before_error = [&](const std::vector<Record> &recs, uint64_t k, bool streamed_names) -> void {
+        if (!args.verbose || g_world > 1) return;
+        if (!streamed_names) for (uint64_t i = 0; i < k; ++i) names.push_back(recs[i].name.sv());
+        if (score_records(recs, 0, k) != 0) return;
+        if (!pipe && flx_pipeline_create(ctx, kmers_empty ? nullptr : kmers, &prm, chunk_bytes, chunk_reads, &pipe) != FLX_OK) return;
+        flx_scores res;
+        uint64_t n_scored = 0;
+        if (flx_pipeline_finish(pipe, &res, &n_scored) != FLX_OK || n_scored != lengths.size()) return;
+        print_read_blocks(res, n_scored);
+    };
+
+    for (;;) {
+        Parsed batch_store;
+        Parsed &batch = streamed ? batch_store : kept;
+        if (streamed) {
+            if (!blocks.next(batch)) {
+                if (blocks.io_error) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
+                break;
+            }
+        } else {
+            if (n_batches > 0) break;
+            parse_all(data, batch);
+            stage("parse");
+        }
+        ++n_batches;
+        const std::vector<Record> &recs = batch.recs;
+        // the per-record checks of src/main.cpp:84-117, in file order, then the parser's own end status
+        if (!streamed) seen_names.reserve(recs.size() * 2);
+        for (const Record &r : recs) {
+            total_bases += (long long)r.seq.size();
+            const bool fasta_format = r.qual.empty() && !r.seq.empty();
+            const bool fastq_format = !r.qual.empty() && !r.seq.empty() && r.qual.size() == r.seq.size();
+            any_fasta = any_fasta || fasta_format;
+            any_fastq = any_fastq || fastq_format;
+            if (any_fasta && any_fastq) {
+                verbose_before_error(recs, (uint64_t)(&r - recs.data()), streamed);
+                std::cerr << "\n\n" << "Error: could not parse input reads" << "\n";
+                std::cerr << "  problem occurred at read " << r.name << "\n";
+                return 1;
+            }
+            if (fasta_format && kmers_empty) {
+                verbose_before_error(recs, (uint64_t)(&r - recs.data()), streamed);
+                std::cerr << "\n\n" << "Error: FASTA input not supported without an external reference" << "\n";
+                return 1;
+            }
+            std::string_view name = r.name.sv();
+            if (streamed) {  // the block's memory is reused: keep a copy
+                name_arena.emplace_back(name);
+                name = name_arena.back();
+            }
+            if (!seen_names.insert(name).second) {
+                if (streamed) names.push_back(name);  // the duplicate itself is scored and printed before the check (main.cpp:108-113)
+                verbose_before_error(recs, (uint64_t)(&r - recs.data()) + 1, streamed);
+                std::cerr << "Error: duplicate read name: " << r.name << "\n";
+                return 1;
+            }
+            if (streamed) {
+                names.push_back(name);
+                units.note_record(blocks.points, blocks.offset_of(r.name.p - 1), n_records);
+            }
+            ++n_records;
+            if (total_bases - last_progress >= 483611) {
+                last_progress = total_bases;
+                if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)n_records) << " reads (" << int_to_string(total_bases) << " bp)";
+            }
+        }
+        if (batch.status == -2) {
+            verbose_before_error(recs, recs.size(), streamed);
+            std::cerr << "Error: incorrect FASTQ format for read " << batch.bad.name << "\n";
+            return 1;
+        }
+        if (!streamed) stage("record checks");
+        // this rank's share of the batch: everything when streaming (one rank), else a contiguous block of file order by count
+        uint64_t lo = 0, cnt = recs.size();
+        if (!streamed) {
+            const uint64_t n_all = recs.size();
+            lo = n_all / (uint64_t)world * (uint64_t)rank + std::min<uint64_t>((uint64_t)rank, n_all % (uint64_t)world);
+            cnt = n_all / (uint64_t)world + ((uint64_t)rank < n_all % (uint64_t)world ? 1 : 0);
+            lo_rec = lo;
+            names.reserve(cnt);
+            for (uint64_t i = 0; i < cnt; ++i) names.push_back(recs[lo + i].name.sv());
+        }
+        if (const int rc = score_records(recs, lo, cnt)) return rc;
+    }
+    { std::unordered_set<std::string_view>().swap(seen_names); }
+    if (streamed) units.finish(blocks.points, blocks.end_offset(), n_records);
+    if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)n_records) << " reads (" << int_to_string(total_bases) << " bp)";
+    if (!args.verbose) std::cerr << "\n";  // verbose: after the per-read blocks, as in main.cpp:110-129
+    const bool fasta_output = any_fasta, fastq_output = any_fastq;
+    const uint64_t n = lengths.size();
+    if (!pipe && flx_pipeline_create(ctx, kmers_empty ? nullptr : kmers, &prm, chunk_bytes, chunk_reads, &pipe) != FLX_OK) return fail_flx(ctx, "pipeline");
+    flx_scores res;
+    uint64_t n_scored = 0;
+    if (flx_pipeline_finish(pipe, &res, &n_scored) != FLX_OK || n_scored != n) return fail_flx(ctx, "scoring");
+    const int32_t *c_ranges = res.child_ranges;
+    if (g_timing) fprintf(stderr, "[timing] %llu chunk(s) of <= %llu MiB\n", (unsigned long long)n_chunks, (unsigned long long)(chunk_bytes >> 20));
+
+    stage("pack + H2D + score (streamed)");
+    // ---- reads2: children replace their parents in place (src/main.cpp:138-147) -----------------------------
+    struct Out { uint64_t rec; int start, end; bool child; std::string name; };
+    std::vector<Out> reads2;
+    std::vector<double> r2_mean, r2_window;
+    std::vector<int32_t> r2_len;
+    std::vector<uint8_t> r2_pass;
+    {
+        // the gather itself is the library's (flx_reads2_gather): values in reads2 order + where every entry came from
+        const uint64_t cap2 = n + res.n_children;
+        r2_mean.resize(cap2); r2_window.resize(cap2); r2_len.resize(cap2); r2_pass.resize(cap2);
+        std::vector<uint32_t> parent2(cap2);
+        std::vector<int64_t> child2(cap2);
+        uint64_t n2_gathered = 0;
+        if (flx_reads2_gather(ctx, n, lengths.data(), &res, cap2, r2_mean.data(), r2_window.data(), r2_len.data(), r2_pass.data(),
+                              parent2.data(), child2.data(), &n2_gathered) != FLX_OK)
+            return fail_flx(ctx, "reads2 gather");
+        r2_mean.resize(n2_gathered); r2_window.resize(n2_gathered); r2_len.resize(n2_gathered); r2_pass.resize(n2_gathered);
+        reads2.reserve(n2_gathered);
+        for (uint64_t j = 0; j < n2_gathered; ++j) {
+            const uint64_t i = parent2[j];
+            if (child2[j] < 0) {
+                reads2.push_back({lo_rec + i, 0, lengths[i], false, std::string(names[i])});
+            } else {
+                const int s0 = c_ranges[2 * child2[j]], e0 = c_ranges[2 * child2[j] + 1];
+                reads2.push_back({lo_rec + i, s0, e0, true, std::string(names[i]) + "_" + std::to_string(s0 + 1) + "-" + std::to_string(e0)});  // read.cpp:135-136
+            }
+        }
+    }
+    size_t longest_name = 0;
+    for (auto &o : reads2) longest_name = std::max(longest_name, o.name.size());
+
+    if (args.verbose) {  // Read::print_verbose_read_info, src/read.cpp:169-194, in file order like the pass-1 loop (main.cpp:110-111)
+        print_read_blocks(res, n);
         std::cerr << "\n";  // the line main.cpp:129 prints after the loop
     }
 

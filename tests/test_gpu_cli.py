@@ -140,7 +140,15 @@ def test_cli_verbose_matches_reference_stderr(tmp_path, mode):
     gold = json.load(open(os.path.join(_cases.GOLDEN, "verbose.json")))
     for key, g in sorted(gold.items()):
         args = [os.path.join(FIX, "test_reference.fasta") if a == "REF" else a for a in g["args"]]
-        rc, out, keep, err = run(args + [os.path.join(FIX, g["input"])], str(tmp_path), MODES[mode])
+        inp = g["input"]
+        if inp.startswith("CAT:"):  # fixtures concatenated (the error-path cases: duplicate names, mixed formats)
+            path = str(tmp_path / ("cat_" + inp[4:].replace("+", "_")))
+            with open(path, "wb") as f:
+                for part in inp[4:].split("+"):
+                    f.write(open(os.path.join(FIX, part), "rb").read())
+        else:
+            path = os.path.join(FIX, inp)
+        rc, out, keep, err = run(args + [path], str(tmp_path), MODES[mode])
         assert rc == g["rc"], (key, err)
         cut = err.find("16-mers\n\n")
         got = err[cut + len("16-mers\n\n"):] if cut >= 0 else err
