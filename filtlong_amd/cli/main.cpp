@@ -41,6 +41,7 @@
 #include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -206,6 +207,8 @@ static int add_sequences(flx_ctx *ctx, flx_kmerset *set, const std::vector<std::
 // could.  With `offsets` (n + 1 byte offsets, the sink a regular file that is not in append mode) every thread writes its
 // own pieces with pwrite at base + offsets[j] and the file position is moved behind the last one; without, this thread
 // writes the pieces in order as they become ready, and no more than 2 x threads of them exist at a time.
+static bool g_direct_pieces = false;  // write_pieces: the producers write their pieces themselves (pwrite at known offsets)
+static off_t g_direct_base = 0;
 template <class Produce>
 static bool write_pieces(size_t n, Produce &&produce, FILE *sink, const std::vector<uint64_t> *offsets) {
     fflush(sink);
@@ -215,6 +218,8 @@ static bool write_pieces(size_t n, Produce &&produce, FILE *sink, const std::vec
     const off_t base = lseek(fd, 0, SEEK_CUR);
     const bool direct = offsets && !getenv("FLX_CLI_ORDERED_OUTPUT") && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 &&
                         !(fl & O_APPEND) && base >= 0;
+    g_direct_pieces = direct;
+    g_direct_base = base;
     std::vector<std::string> piece(n);
     std::vector<char> state(n, 0);  // 1: ready (or written), 2: failed
     std::mutex mu;
@@ -232,9 +237,10 @@ static bool write_pieces(size_t n, Produce &&produce, FILE *sink, const std::vec
                 cv.wait(lk, [&] { return j < written + ahead; });
             }
             std::string &buf = piece[j];
-            if (offsets) buf.reserve((size_t)((*offsets)[j + 1] - (*offsets)[j]));
+            if (offsets && !direct) buf.reserve((size_t)((*offsets)[j + 1] - (*offsets)[j]));
             bool ok = produce(j, buf);
-            if (offsets) ok = ok && buf.size() == (*offsets)[j + 1] - (*offsets)[j];
+            const bool self_written = direct && ok && buf.empty() && (*offsets)[j + 1] != (*offsets)[j];  // the producer used pwritev itself
+            if (offsets && !self_written) ok = ok && buf.size() == (*offsets)[j + 1] - (*offsets)[j];
             if (direct) {
                 for (size_t done = 0; ok && done < buf.size();) {
                     const ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, base + (off_t)((*offsets)[j] + done));
@@ -970,9 +976,85 @@ int main(int argc, char **argv) {
             piece_at.push_back(bytes);
         }
         const size_t n_pieces = piece_first.size() - 1;
-        const bool ok = write_pieces(n_pieces, [&](size_t j, std::string &buf) {
-            for (uint64_t i = piece_first[j]; i < piece_first[j + 1]; ++i) emit(buf, i, kept.recs[reads2[i].rec]);
+        // A passed read whose record in the input already HAS the bytes of its output record — one header line "@name" or
+        // "@name comment" with a single blank, one sequence line, a bare "+" line, one quality line, LF ends — is not formatted at
+        // all: its bytes go from the mapping to the file in one pwritev, neighbours in the input merged into one range.  Anything
+        // else (children, CRLF, wrapped lines, "+name", tabs) is formatted into a side buffer as before; the byte count per read is
+        // the same either way, so the pieces keep their precomputed offsets.
+        const char *map_lo = data.data(), *map_hi = data.data() + data.size();
+        auto verbatim = [&](uint64_t i, const char *&from, size_t &len) -> bool {
+            const Out &o = reads2[i];
+            if (o.child) return false;
+            const Record &r = kept.recs[o.rec];
+            const char *h = r.name.p - 1;
+            if (h < map_lo || r.name.p + r.name.n >= map_hi || *h != (fasta_output ? '>' : '@')) return false;
+            const char *nl = r.name.p + r.name.n;  // the byte behind the name
+            if (!r.comment.empty()) {
+                if (*nl != ' ' || r.comment.p != nl + 1 || r.comment.p + r.comment.n >= map_hi) return false;
+                nl = r.comment.p + r.comment.n;
+            }
+            if (*nl != '\n' || r.seq.p != nl + 1 || r.seq.p + r.seq.n >= map_hi || r.seq.p[r.seq.n] != '\n') return false;
+            const char *end = r.seq.p + r.seq.n + 1;
+            if (fastq_output) {
+                if (end + 2 > map_hi || end[0] != '+' || end[1] != '\n' || r.qual.p != end + 2 || r.qual.n != r.seq.n ||
+                    r.qual.p + r.qual.n >= map_hi || r.qual.p[r.qual.n] != '\n') return false;
+                end = r.qual.p + r.qual.n + 1;
+            }
+            from = h;
+            len = (size_t)(end - h);
             return true;
+        };
+        const int out_fd = fileno(sink);
+        const bool ok = write_pieces(n_pieces, [&](size_t j, std::string &buf) {
+            if (!g_direct_pieces) {  // a pipe / terminal / append-mode file: the caller writes the formatted piece in order
+                for (uint64_t i = piece_first[j]; i < piece_first[j + 1]; ++i) emit(buf, i, kept.recs[reads2[i].rec]);
+                return true;
+            }
+            // regular file: this thread writes the piece itself, ranges of the mapping and formatted records interleaved
+            std::vector<struct iovec> iov;
+            std::deque<std::string> side;
+            bool last_is_map = false;
+            off_t at = g_direct_base + (off_t)piece_at[j];
+            auto flush = [&]() -> bool {
+                size_t k = 0;
+                while (k < iov.size()) {
+                    const int cnt = (int)std::min<size_t>(iov.size() - k, 512);
+                    ssize_t w = pwritev(out_fd, iov.data() + k, cnt, at);
+                    if (w <= 0) return false;
+                    at += w;
+                    while (w > 0 && k < iov.size()) {  // a short write: drop what went out
+                        if ((size_t)w >= iov[k].iov_len) { w -= (ssize_t)iov[k].iov_len; ++k; }
+                        else { iov[k].iov_base = (char *)iov[k].iov_base + w; iov[k].iov_len -= (size_t)w; w = 0; }
+                    }
+                }
+                iov.clear();
+                side.clear();
+                return true;
+            };
+            for (uint64_t i = piece_first[j]; i < piece_first[j + 1]; ++i) {
+                if (!r2_pass[i]) continue;
+                const char *from = nullptr;
+                size_t len = 0;
+                if (verbatim(i, from, len)) {
+                    if (last_is_map && (const char *)iov.back().iov_base + iov.back().iov_len == from) iov.back().iov_len += len;  // neighbours in the input
+                    else iov.push_back({(void *)from, len});
+                    last_is_map = true;
+                } else {
+                    side.emplace_back();
+                    emit(side.back(), i, kept.recs[reads2[i].rec]);
+                    if (!side.back().empty()) {
+                        iov.push_back({(void *)side.back().data(), side.back().size()});
+                        last_is_map = false;
+                    }
+                }
+                if (iov.size() >= 4096) {
+                    if (!flush()) return false;
+                    last_is_map = false;
+                }
+            }
+            if (!flush()) return false;
+            buf.clear();
+            return at == g_direct_base + (off_t)piece_at[j + 1];
         }, sink, &piece_at);
         if (!ok) { std::cerr << "Error: could not write the output\n"; return 1; }
     } else {
