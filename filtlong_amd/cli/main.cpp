@@ -444,16 +444,35 @@ int main(int argc, char **argv) {
         clock_gettime(CLOCK_REALTIME, &ts);
         fprintf(stderr, "[timing] main() reached at wall clock %.3f\n", ts.tv_sec % 100000 + ts.tv_nsec * 1e-9);
     }
+    // The context (HIP runtime start-up, ~0.1 s) is created on a second thread while this one maps, parses and checks the input,
+    // when nothing needs it before the scoring: one rank, no reference 16-mers to build.
     flx_ctx *ctx = nullptr;
+    int ctx_rc = FLX_OK;
+    std::thread ctx_thread;
+    struct ThreadJoiner {
+        std::thread &t;
+        ~ThreadJoiner() { if (t.joinable()) t.join(); }
+    } ctx_joiner{ctx_thread};
     {
         const char *dev = getenv("FLX_DEVICE");
         int ordinal = dev ? atoi(dev) : 0;
         if (!dev && g_world > 1) ordinal = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : g_rank;
-        if (flx_ctx_create(ordinal, &ctx) != FLX_OK) {
+        if (g_world == 1 && !args.assembly_set && args.short_reads.empty() && !g_timing) {
+            ctx_thread = std::thread([&ctx, &ctx_rc, ordinal] { ctx_rc = flx_ctx_create(ordinal, &ctx); });
+        } else if (flx_ctx_create(ordinal, &ctx) != FLX_OK) {
             std::cerr << "Error: " << flx_last_error(nullptr) << "\n";
             return 1;
         }
     }
+    auto ctx_ready = [&]() -> bool {  // before the first use of `ctx`
+        if (ctx_thread.joinable()) ctx_thread.join();
+        if (ctx_rc != FLX_OK) {
+            std::cerr << "Error: " << flx_last_error(nullptr) << "\n";
+            ctx_rc = FLX_OK;  // reported once
+            return false;
+        }
+        return ctx != nullptr;
+    };
     if (g_world > 1) {
         // the communicator's 128-byte id: --gpus hands it to every child through its pipe; under a launcher it travels through
         // FLX_COMM_ID_FILE (rank 0: exclusive create of a temp name, never through a symlink, then rename; the others accept
@@ -605,6 +624,7 @@ int main(int argc, char **argv) {
     // Pack records [lo, lo + cnt) of a batch chunk by chunk into the pipeline's pinned staging buffers (two slots: the GPU
     // copies and scores chunk k while the host threads pack chunk k+1); only per-read scalars survive a chunk.
     auto score_records = [&](const std::vector<Record> &recs, uint64_t lo, uint64_t cnt) -> int {
+        if (!ctx_ready()) return 1;
         const uint64_t base = lengths.size();
         int32_t longest = 0;
         for (uint64_t i = 0; i < cnt; ++i) {
@@ -807,6 +827,7 @@ int main(int argc, char **argv) {
     if (!args.verbose) std::cerr << "\n";  // verbose: after the per-read blocks, as in main.cpp:110-129
     const bool fasta_output = any_fasta, fastq_output = any_fastq;
     const uint64_t n = lengths.size();
+    if (!ctx_ready()) return 1;
     if (!pipe && flx_pipeline_create(ctx, kmers_empty ? nullptr : kmers, &prm, chunk_bytes, chunk_reads, &pipe) != FLX_OK) return fail_flx(ctx, "pipeline");
     flx_scores res;
     uint64_t n_scored = 0;
