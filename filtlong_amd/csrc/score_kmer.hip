@@ -22,6 +22,9 @@
 #include "kmerset.h"
 #include "rank_internal.h"
 
+#ifndef FLX_COVER_THREADS
+#define FLX_COVER_THREADS 256  // threads per workgroup of k_kmer_cover_w (its waves are independent)
+#endif
 #ifndef FLX_FARFIRST_LANES
 #define FLX_FARFIRST_LANES 16  // settled lanes of a span from which the next span asks the exact table first (score_kmer.hip, below)
 #endif
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
 //     one pair per side and round; a clean stretch costs one request per 16 positions, a false candidate costs one only
 //     when it lies outside the confirmed span.  Rounds repeat until no lane of the wave has an open question.
 template <bool HAS_PREFILTER>
-__global__ void __launch_bounds__(256) k_kmer_cover_w(const uint8_t *plane, const uint64_t *offsets, const int32_t *lengths,
+__global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_t *plane, const uint64_t *offsets, const int32_t *lengths,
                                                       const uint32_t *order, uint64_t n_reads, const uint8_t *exact15,
                                                       const uint8_t *pre11, uint32_t *cov, const uint64_t *cov_off,
                                                       int32_t *count, int32_t *first, int32_t *last) {
@@ -905,13 +908,13 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
         const bool old_cover = cover_env && strcmp(cover_env, "v2") == 0;
         flx_time_begin(ctx, "flx_score_kmer_cover");
         if (!old_cover) {
-            const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 3) / 4, 1u << 20);
+            const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + FLX_COVER_THREADS / 64 - 1) / (FLX_COVER_THREADS / 64), 1u << 22);
             if (flx_kmerset_pre11(set))
-                hipLaunchKernelGGL(k_kmer_cover_w<true>, dim3(wgrid), dim3(256), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
+                hipLaunchKernelGGL(k_kmer_cover_w<true>, dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
                                    flx_kmerset_exact15(set), flx_kmerset_pre11(set), (uint32_t *)d_cov, (const uint64_t *)d_covoff,
                                    d_cnt, first, last);
             else
-                hipLaunchKernelGGL(k_kmer_cover_w<false>, dim3(wgrid), dim3(256), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
+                hipLaunchKernelGGL(k_kmer_cover_w<false>, dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
                                    flx_kmerset_exact15(set), (const uint8_t *)nullptr, (uint32_t *)d_cov, (const uint64_t *)d_covoff,
                                    d_cnt, first, last);
         } else {
