@@ -175,6 +175,27 @@ def test_kmer_mode_properties(short_reads, size):
             assert torch.equal(t[k].view(torch.uint8), word_level[k].view(torch.uint8)), k
         for k, per in (("crng", 2), ("cmean", 1), ("cwin", 1), ("cpass", 1)):
             assert torch.equal(t[k][:per * n_word].view(torch.uint8), word_level[k][:per * n_word].view(torch.uint8)), k
+    # the two implementations of the coverage kernel (wave level with pair tables / round 2's workgroup-per-read kernel with one
+    # bitmap lookup per candidate run end) agree on every read and child of the batch
+    import os
+    wave_level = {k: v.clone() for k, v in t.items()}
+    n_wave = int(s.n_children)
+    os.environ["FLX_KMER_COVER"] = "v2"
+    try:
+        for v in t.values():
+            v.zero_()
+        torch.cuda.synchronize()
+        assert ctx.score_kmer_dev(ks, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n,
+                                  params, s) == 0
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["FLX_KMER_COVER"]
+    assert int(s.n_children) == n_wave
+    for k in ("mean", "win", "pass", "first", "last", "coff"):
+        assert torch.equal(t[k].view(torch.uint8), wave_level[k].view(torch.uint8)), k
+    for k, per in (("crng", 2), ("cmean", 1), ("cwin", 1), ("cpass", 1)):
+        assert torch.equal(t[k][:per * n_wave].view(torch.uint8), wave_level[k][:per * n_wave].view(torch.uint8)), k
+    del wave_level
     mean, win, first, last = (t[k].cpu().numpy() for k in ("mean", "win", "first", "last"))
     coff = t["coff"].cpu().numpy()
     nchild = int(s.n_children)
