@@ -208,7 +208,7 @@ int flx_scratch(flx_ctx *ctx, size_t bytes, void **out) {
 }
 
 int flx_workspace(flx_ctx *ctx, int slot, size_t bytes, void **out) {
-    if (slot < 0 || slot >= 2) return flx_fail(ctx, FLX_ERR_INVALID, "workspace slot %d", slot);
+    if (slot < 0 || slot >= 3) return flx_fail(ctx, FLX_ERR_INVALID, "workspace slot %d", slot);
     if (bytes > ctx->ws_bytes[slot]) {
         FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->ws[slot]) (void)hipFree(ctx->ws[slot]);

@@ -48,8 +48,8 @@ struct flx_ctx {
     size_t scratch_bytes = 0;
     // grow-only workspaces of the k-mer scoring path (kept between calls: a 12 GB hipMalloc + hipFree per batch costs
     // more than the fold kernels)
-    void *ws[2] = {nullptr, nullptr};
-    size_t ws_bytes[2] = {0, 0};
+    void *ws[3] = {nullptr, nullptr, nullptr};
+    size_t ws_bytes[3] = {0, 0, 0};
 };
 
 int flx_fail(flx_ctx *ctx, int code, const char *fmt, ...);

@@ -492,6 +492,10 @@ struct FoldArgs {
     double *mean_q;
     double *window_q;
     uint8_t *passed;
+    // MODE 5 / 6: one lane per child
+    uint32_t *child_parent;         // [n_children] read index of every child (written by MODE 5, read by MODE 6)
+    const uint32_t *child_order;    // [n_children] children by descending length (MODE 6)
+    uint64_t n_children;
     // children
     uint32_t *n_child;              // [n] (count pass)
     const uint64_t *child_offsets;  // [n+1] (emit pass)
@@ -528,19 +532,38 @@ __device__ __forceinline__ double window_result(const FoldArgs &a, int len, int 
 // MODE 3: parent + count children at WORD level — a zero run can only be a bad range if it starts at position 0, reaches
 // the end of the read, or is at least --split long; with --split >= 32 (or unset) every such run crosses a 32-bit word
 // boundary, so the runs that lie inside one word never matter and the parent keeps MODE 0's branch-free steady state.
+// MODE 5: the word-level events of MODE 3 once more, without any floating point: writes every child's (start, end) and its
+// read's index at the child's place in the CSR.  MODE 6: ONE LANE PER CHILD, children in descending order of length — a child
+// is a read of its own (src/read.cpp:131-137: Read(child name, seq + start, ...)), so its lane runs MODE 0's branch-free
+// recurrence on the parent's coverage bits [start, end) (the row words funnel-shifted by start mod 32) and writes the child's
+// mean / window / pass flag.  5 + 6 replace MODE 4, whose 32 predicated positions per word carry the event machinery through
+// every bit (67 of the 98 ms per 10^11 positions of C4's folds).
 template <int MODE, bool RING>
 __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
     const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = slot < a.n_reads;
-    uint32_t rid = 0;
+    const bool live = slot < (MODE == 6 ? a.n_children : a.n_reads);
+    uint32_t rid = 0;  // MODE 6: the child's index
     int L = 0;
-    if (live) {
+    const uint32_t *row = a.cov;
+    int row_words_left = 0;       // MODE 6: words of the parent's row from `row` on
+    uint32_t bit_off = 0;         // MODE 6: the child starts at bit `bit_off` (0..127) of row[0]
+    if (live && MODE != 6) {
         rid = a.order ? a.order[slot] : (uint32_t)slot;
         L = a.lengths[rid];
+        row = a.cov + (a.cov_off[rid] >> 2);
+    }
+    if (live && MODE == 6) {
+        rid = a.child_order[slot];
+        const uint32_t parent = a.child_parent[rid];
+        const int start = a.child_ranges[2 * (size_t)rid], end = a.child_ranges[2 * (size_t)rid + 1];
+        L = end - start;
+        const int base_word = (start >> 7) << 2;  // 16-byte aligned piece of the row the child starts in
+        row = a.cov + (a.cov_off[parent] >> 2) + base_word;
+        row_words_left = ((a.lengths[parent] + 31) >> 5) - base_word;
+        bit_off = (uint32_t)(start - 32 * base_word);
     }
     int Lmax = L;
     for (int o = 32; o > 0; o >>= 1) Lmax = max(Lmax, __shfl_xor(Lmax, o, 64));
-    const uint32_t *row = live ? a.cov + (a.cov_off[rid] >> 2) : a.cov;
     const int ws = a.ws;
     const double delta = a.delta;
 
@@ -552,13 +575,19 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
     int zs = -1;            // start of the current zero run (-1: none)
     bool any_bad = false;
     uint32_t nchild = 0;
-    const uint64_t cbase = ((MODE == 2 || MODE == 4) && live) ? a.child_offsets[rid] : 0;
+    const uint64_t cbase = ((MODE == 2 || MODE == 4 || MODE == 5) && live) ? a.child_offsets[rid] : 0;
     const bool split_set = a.p.split_set != 0;
     const bool trim = a.p.trim != 0;
     const int split = a.p.split;
 
     auto emit_child = [&](int start, int end, const Win &st) {
         if (end <= start) return;
+        if (MODE == 5) {
+            const uint64_t at = cbase + nchild;
+            a.child_ranges[2 * at] = start;
+            a.child_ranges[2 * at + 1] = end;
+            a.child_parent[at] = rid;
+        }
         if (MODE == 2 || MODE == 4) {
             const int len = end - start;
             const double mean = 100.0 * (double)st.cnt / (double)len;
@@ -583,7 +612,9 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
     //   Both edges then come out of the ring with ds_read_b32: one far request per 512 positions instead of two per 128,
     //   which had made the folds request bound (round 2: 28 of the 36 ms per 10^11 positions).
     //   !RING: both streams straight from global memory in 16-byte blocks (windows too long for the ring).
-    const int n_words = (L + 31) >> 5;
+    const int n_words = MODE == 6 ? row_words_left : (L + 31) >> 5;  // words of the row that exist behind `row`
+    const int o5 = (int)(bit_off >> 5);                                // MODE 6: the child's word k = row words k + o5, k + o5 + 1 ...
+    const unsigned o = bit_off & 31u;                                  // ... shifted right by o bits
     auto ldq = [&](int b) -> uint4 {
         return (b * 4 < n_words) ? *reinterpret_cast<const uint4 *>(row + 4 * (size_t)b) : make_uint4(0u, 0u, 0u, 0u);
     };
@@ -627,12 +658,30 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
         }
     };
     auto ring_word = [&](int wi) -> uint32_t { return wi < n_words ? ring[(wi & (R - 1)) * 64] : 0u; };
+    // MODE 6: bit p of the child is bit p + bit_off of the row, so 32 child positions from position p on are row words
+    // (p + bit_off) / 32 and the next one, funnel-shifted by (p + bit_off) mod 32
+    auto lead_bits = [&](int p) -> uint32_t {  // p a multiple of 32, moving forward
+        const int w = (p >> 5) + o5;
+        uint32_t lo, hi;
+        if (RING) { ring_fill(w + 1); lo = ring_word(w); hi = ring_word(w + 1); }
+        else { advance(lead, w >> 2); lo = word(lead, w); hi = word(lead, w + 1); }
+        return __builtin_amdgcn_alignbit(hi, lo, o);
+    };
+    auto trail_bits = [&](int p) -> uint32_t {  // any p >= 0 behind the leading edge, moving forward
+        const int t = p + (int)bit_off, w = t >> 5;
+        uint32_t lo, hi;
+        if (RING) { lo = ring_word(w); hi = ring_word(w + 1); }
+        else { advance(trail, w >> 2); lo = word(trail, w); hi = word(trail, w + 1); }
+        return __builtin_amdgcn_alignbit(hi, lo, (unsigned)(t & 31));
+    };
     auto lead_word = [&](int wi) -> uint32_t {  // the word holding the leading edge
+        if (MODE == 6) return lead_bits(wi << 5);
         if (RING) { ring_fill(wi); return ring_word(wi); }
         advance(lead, wi >> 2);
         return word(lead, wi);
     };
     auto trail_word = [&](int wi) -> uint32_t {  // words of the trailing edge: never ahead of the leading one
+        if (MODE == 6) return trail_bits(wi << 5);
         if (RING) return ring_word(wi);
         advance(trail, wi >> 2);
         return word(trail, wi);
@@ -709,7 +758,7 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
           }
           continue;
       }
-      if (MODE == 3 && j0 < L) {
+      if ((MODE == 3 || MODE == 5) && j0 < L) {
           const int v = min(32, L - j0);  // valid bits of this word
           const uint32_t w = v < 32 ? (lead_w & ((1u << v) - 1u)) : lead_w;
           if (j0 == 0 && !(w & 1u)) zs = 0;  // the read starts inside a zero run
@@ -719,7 +768,7 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
                   const bool bad = (split_set && j - zs >= split) || (trim && zs == 0);
                   if (bad) {
                       any_bad = true;
-                      if (zs > cs) ++nchild;
+                      emit_child(cs, zs, S);  // (counts it; MODE 5 also writes its range)
                       cs = j;
                   }
                   zs = -1;
@@ -730,11 +779,17 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
               zs = j0;
           }
       }
-      if ((MODE == 0 || MODE == 3) && j0 >= ws && j0 + 32 <= Lmin) {
-          // ---- steady state, parent only: 32 positions, every lane active, no per-bit control flow ----
-          const int tj0 = j0 - ws, sh = tj0 & 31, twi = tj0 >> 5;
-          const uint32_t t0 = trail_word(twi);
-          const uint32_t tw = sh ? __builtin_amdgcn_alignbit(trail_word(twi + 1), t0, (unsigned)sh) : t0;
+      if (MODE == 5) continue;
+      if ((MODE == 0 || MODE == 3 || MODE == 6) && j0 >= ws && j0 + 32 <= Lmin) {
+          // ---- steady state, one window per lane: 32 positions, every lane active, no per-bit control flow ----
+          uint32_t tw;
+          if (MODE == 6) {
+              tw = trail_bits(j0 - ws);
+          } else {
+              const int tj0 = j0 - ws, sh = tj0 & 31, twi = tj0 >> 5;
+              const uint32_t t0 = trail_word(twi);
+              tw = sh ? __builtin_amdgcn_alignbit(trail_word(twi + 1), t0, (unsigned)sh) : t0;
+          }
           P.cnt += __popc(lead_w);
 #pragma unroll
           for (int i = 0; i < 32; ++i) {
@@ -806,6 +861,14 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
     }
     if (!live) return;
 
+    if (MODE == 6) {  // the child's own scores (src/read.cpp:131-137 -> the Read constructor's folds on the child's slice)
+        const double mean = 100.0 * (double)P.cnt / (double)L;
+        const double window = window_result(a, L, P.cnt, P.mn);
+        a.child_mean_q[rid] = mean;
+        a.child_window_q[rid] = window;
+        a.child_passed[rid] = cutoffs(a.p, L, mean, window);
+        return;
+    }
     if (MODE != 0) {
         int end = L;
         if (zs >= 0) {  // the read ends inside a zero run [zs, L)
@@ -820,7 +883,7 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
         else nchild = 0;
     }
     if (MODE == 1 || MODE == 3) a.n_child[rid] = nchild;
-    if (MODE != 2 && MODE != 4) {
+    if (MODE != 2 && MODE != 4 && MODE != 5) {
         const double mean = 100.0 * (double)a.count[rid] / (double)L;  // exact: the qualities are 0.0 / 1.0
         const double window = window_result(a, L, P.cnt, P.mn);
         a.mean_q[rid] = mean;
@@ -839,6 +902,15 @@ __global__ void k_widen_u32_i64(uint64_t n, const uint32_t *in, int64_t *out) {
     if (i < n) out[i] = (int64_t)in[i];
 }
 
+// sort key of a child: longest first (the lanes of a wave then run the same number of steps)
+__global__ void k_child_keys(uint64_t n, const int32_t *ranges, uint64_t *keys, uint32_t *vals) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        keys[i] = (uint64_t)(0x7fffffffu - (uint32_t)(ranges[2 * i + 1] - ranges[2 * i]));
+        vals[i] = (uint32_t)i;
+    }
+}
+
 }  // namespace
 
 // the fold kernels: with the LDS ring when it fits (R words per lane; 4 waves per workgroup up to R = 64, one wave up to R = 512),
@@ -846,11 +918,11 @@ __global__ void k_widen_u32_i64(uint64_t n, const uint32_t *in, int64_t *out) {
 template <int MODE>
 static int launch_fold(flx_ctx *ctx, FoldArgs &a) {
     int R = 32;
-    while (R < 18 + (a.ws + 31) / 32) R *= 2;
+    while (R < (MODE == 6 ? 24 : 18) + (a.ws + 31) / 32) R *= 2;  // MODE 6 starts up to 4 words into its first block, and reads one word further
     const char *env = getenv("FLX_KMER_FOLD_STREAMS");  // "global": the round-2 data path (second implementation, tests)
     const bool ring = R <= 512 && !(env && strcmp(env, "global") == 0);
     const unsigned threads = (!ring || R <= 64) ? 256u : 64u;
-    const unsigned nb = (unsigned)((a.n_reads + threads - 1) / threads);
+    const unsigned nb = (unsigned)(((MODE == 6 ? a.n_children : a.n_reads) + threads - 1) / threads);
     a.ring_words = R;
     if (ring) {
         const size_t lds = (size_t)(threads / 64) * (size_t)R * 256;
@@ -950,6 +1022,9 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     a.window_q = out->window_q;
     a.passed = out->passed;
     a.n_child = nullptr;
+    a.child_parent = nullptr;
+    a.child_order = nullptr;
+    a.n_children = 0;
     a.child_offsets = nullptr;
     a.child_ranges = out->child_ranges;
     a.child_mean_q = out->child_mean_q;
@@ -991,10 +1066,34 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     if (total_children > 0) {
         a.child_offsets = out->child_offsets;
         flx_time_begin(ctx, "flx_score_kmer_fold");
-        if (bit_level)
+        // FLX_KMER_FOLD=words: the children inside their read's lane (MODE 4, second implementation of the word-level path)
+        const bool per_child = !bit_level && !(fold_env && strcmp(fold_env, "words") == 0);
+        if (bit_level) {
             FLX_CHECK(launch_fold<2>(ctx, a));
-        else
+        } else if (!per_child) {
             FLX_CHECK(launch_fold<4>(ctx, a));
+        } else {
+            // ranges (word-level events only) -> children by descending length -> one lane per child
+            const uint64_t nc = (uint64_t)total_children;
+            const size_t sort_ws = flx_radix_sort_workspace(nc);
+            void *cw = nullptr;
+            FLX_CHECK(flx_workspace(ctx, 2, 2 * up(nc * 8) + 3 * up(nc * 4) + up(sort_ws), &cw));
+            wp = (char *)cw;
+            uint64_t *keys0 = (uint64_t *)carve(nc * 8), *keys1 = (uint64_t *)carve(nc * 8);
+            uint32_t *vals0 = (uint32_t *)carve(nc * 4), *vals1 = (uint32_t *)carve(nc * 4);
+            a.child_parent = (uint32_t *)carve(nc * 4);
+            void *d_sortws = carve(sort_ws);
+            a.n_children = nc;
+            FLX_CHECK(launch_fold<5>(ctx, a));
+            flx_time_end(ctx);  // (the sort times its own passes)
+            hipLaunchKernelGGL(k_child_keys, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, nc, out->child_ranges, keys0, vals0);
+            uint64_t *skeys = nullptr;
+            uint32_t *svals = nullptr;
+            FLX_CHECK(flx_radix_sort_pairs(ctx, nc, keys0, keys1, vals0, vals1, d_sortws, sort_ws, &skeys, &svals));
+            a.child_order = svals;
+            flx_time_begin(ctx, "flx_score_kmer_fold");
+            FLX_CHECK(launch_fold<6>(ctx, a));
+        }
         flx_time_end(ctx);
     }
     FLX_HIP(ctx, hipGetLastError());

@@ -155,26 +155,28 @@ def test_kmer_mode_properties(short_reads, size):
     assert rc == 0
     torch.cuda.synchronize()
     if short_reads:
-        # the word-level child passes (default) and the bit-level ones (FLX_KMER_FOLD=bits) are two implementations of
-        # src/read.cpp:86-141: they must agree on every one of the 2x10^5 reads and ~2x10^5 children
+        # one lane per child (default), the children inside their read's lane at word level (FLX_KMER_FOLD=words) and bit by bit
+        # (FLX_KMER_FOLD=bits) are three implementations of src/read.cpp:86-141: they must agree on every one of the reads and
+        # children of the batch
         import os
-        word_level = {k: v.clone() for k, v in t.items()}
+        per_child = {k: v.clone() for k, v in t.items()}
         n_word = int(s.n_children)
-        os.environ["FLX_KMER_FOLD"] = "bits"
-        try:
-            for v in t.values():
-                v.zero_()
-            torch.cuda.synchronize()
-            assert ctx.score_kmer_dev(ks, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n,
-                                      params, s) == 0
-            torch.cuda.synchronize()
-        finally:
-            del os.environ["FLX_KMER_FOLD"]
-        assert int(s.n_children) == n_word
-        for k in ("mean", "win", "pass", "first", "last", "coff"):
-            assert torch.equal(t[k].view(torch.uint8), word_level[k].view(torch.uint8)), k
-        for k, per in (("crng", 2), ("cmean", 1), ("cwin", 1), ("cpass", 1)):
-            assert torch.equal(t[k][:per * n_word].view(torch.uint8), word_level[k][:per * n_word].view(torch.uint8)), k
+        for variant in ("words", "bits"):
+            os.environ["FLX_KMER_FOLD"] = variant
+            try:
+                for v in t.values():
+                    v.zero_()
+                torch.cuda.synchronize()
+                assert ctx.score_kmer_dev(ks, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n,
+                                          params, s) == 0
+                torch.cuda.synchronize()
+            finally:
+                del os.environ["FLX_KMER_FOLD"]
+            assert int(s.n_children) == n_word
+            for k in ("mean", "win", "pass", "first", "last", "coff"):
+                assert torch.equal(t[k].view(torch.uint8), per_child[k].view(torch.uint8)), (variant, k)
+            for k, per in (("crng", 2), ("cmean", 1), ("cwin", 1), ("cpass", 1)):
+                assert torch.equal(t[k][:per * n_word].view(torch.uint8), per_child[k][:per * n_word].view(torch.uint8)), (variant, k)
     # the two implementations of the coverage kernel (wave level with pair tables / round 2's workgroup-per-read kernel with one
     # bitmap lookup per candidate run end) agree on every read and child of the batch
     import os

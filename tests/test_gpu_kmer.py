@@ -276,14 +276,27 @@ def test_prefilter_and_fold_variants_give_identical_results(be, synth, monkeypat
     # streamed from global memory (what windows too long for the ring use); also with windows that need the longer rings
     monkeypatch.delenv("FLX_KMER_PREFILTER")
     monkeypatch.delenv("FLX_KMER_FOLD")
-    for ws in (250, 31, 1500, 5000):
-        pk = dict(pkw, window_size=ws)
-        ring = be.score(reads, pk, be.kmers(assembly=synth["contigs"]))
-        monkeypatch.setenv("FLX_KMER_FOLD_STREAMS", "global")
-        glob_ = be.score(reads, pk, be.kmers(assembly=synth["contigs"]))
-        monkeypatch.delenv("FLX_KMER_FOLD_STREAMS")
-        for (name, _s, _q), a, b in zip(reads, ring, glob_):
-            assert bits(a) == bits(b), (name, ws)
+    # ... and the three implementations of the children: one lane per child (default: ranges pass, children sorted by length,
+    # the parent's recurrence on the child's slice of the row), inside the read's lane at word level (FLX_KMER_FOLD=words), bit
+    # by bit (FLX_KMER_FOLD=bits)
+    ks = be.kmers(assembly=synth["contigs"])
+    for ws in (250, 31, 1, 1500, 5000):
+        for split in (100, 32, 1000):
+            pk = dict(pkw, window_size=ws, split=split)
+            ring = be.score(reads, pk, ks)
+            monkeypatch.setenv("FLX_KMER_FOLD_STREAMS", "global")
+            glob_ = be.score(reads, pk, ks)
+            monkeypatch.delenv("FLX_KMER_FOLD_STREAMS")
+            monkeypatch.setenv("FLX_KMER_FOLD", "words")
+            words = be.score(reads, pk, ks)
+            monkeypatch.setenv("FLX_KMER_FOLD", "bits")
+            bitl = be.score(reads, pk, ks)
+            monkeypatch.delenv("FLX_KMER_FOLD")
+            assert sum(len(a["child_ranges"]) for a in ring) > 0
+            for (name, _s, _q), a, b, c, d in zip(reads, ring, glob_, words, bitl):
+                assert bits(a) == bits(b), (name, ws, split, "global streams")
+                assert bits(a) == bits(c), (name, ws, split, "words")
+                assert bits(a) == bits(d), (name, ws, split, "bits")
     monkeypatch.setenv("FLX_KMER_PREFILTER", "0")
     monkeypatch.setenv("FLX_KMER_FOLD", "bits")
     # the two implementations of the coverage kernel: the wave-level one (pair tables, outermost-member search, far-first spans;
