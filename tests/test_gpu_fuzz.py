@@ -1,0 +1,260 @@
+"""Differential fuzz: seeded random inputs and flag combinations through filtlong_amd/bin/filtlong AND the reference binary
+(oracle/_ref/filtlong, built from /root/reference/src by oracle/Makefile; it travels to the GPU box), run on the same files
+with the same argv.  Exit code, stdout bytes and stderr as a terminal shows it must be the same for every case — valid runs
+in all three scoring modes (src/read.cpp:35-58), every hard cut-off and weight (src/arguments.cpp:126-221), --trim / --split
+down to 1 (src/read.cpp:86-141), exact score ties from records with equal content (src/main.cpp:247-257), odd record
+grammar (src/kseq.h:176-224) and the error paths of src/main.cpp:80-116."""
+import gzip
+import os
+import random
+import subprocess
+import zlib
+
+import pytest
+
+import _oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "filtlong_amd", "bin", "filtlong")
+
+LENGTHS = [0, 1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 99, 100, 101, 249, 250, 251, 500, 1000, 1023, 1024, 1025, 2000, 4000]
+WINDOWS = [1, 2, 15, 16, 17, 50, 100, 249, 250, 251, 600, 1500]
+SPLITS = [1, 2, 5, 31, 32, 33, 100, 250, 1000]
+
+
+def rand_bases(rng, n):
+    return bytes(rng.choice(b"ACGT") for _ in range(n))
+
+
+def mutate(rng, s, rate):
+    if rate == 0 or not s:
+        return s
+    b = bytearray(s)
+    for i in range(len(b)):
+        if rng.random() < rate:
+            b[i] = rng.choice(b"ACGT")
+    return bytes(b)
+
+
+def make_case(seed):
+    """-> dict(files={name: bytes}, argv=[...] with file names relative to the case directory)"""
+    rng = random.Random(seed)
+    mode = rng.choices(["phred", "asm", "sr"], [0.5, 0.3, 0.2])[0]
+    files = {}
+    argv = []
+    contigs = []
+    if mode != "phred":
+        contigs = [rand_bases(rng, rng.choice([40, 300, 1500, 5000])) for _ in range(rng.choice([1, 1, 2, 3]))]
+        if rng.random() < 0.15:
+            contigs.append(rand_bases(rng, rng.choice([0, 5, 15, 16])))  # references shorter than a 16-mer
+    if mode == "asm":
+        fa = b"".join(b">c%d some text\n" % i + (c.lower() if rng.random() < 0.2 else c) + b"\n" for i, c in enumerate(contigs))
+        files["ref.fasta"] = fa
+        argv += ["-a", "ref.fasta"]
+    elif mode == "sr":
+        # 100-mers tiled at a depth that puts most 16-mers in the set (4 copies, or 3 and a Bloom false positive: src/kmers.cpp:142-166)
+        pairs = [[], []]
+        for c in contigs:
+            if len(c) < 100:
+                continue
+            for _ in range(max(1, len(c) * rng.choice([3, 8, 12]) // 100)):
+                p = rng.randrange(0, len(c) - 99)
+                pairs[rng.randrange(2)].append(c[p:p + 100])
+        for k in (0, 1):
+            fq = b"".join(b"@s%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(pairs[k]))
+            files["sr_%d.fastq" % (k + 1)] = fq
+        argv += ["-1", "sr_1.fastq", "-2", "sr_2.fastq"]
+
+    # ---- reads ----
+    n = rng.choice([0, 1, 2, 3, 5, 10, 30, 60])
+    reads = []
+    total = 0
+    for i in range(n):
+        L = rng.choice(LENGTHS) if rng.random() < 0.6 else rng.randrange(1, 3000)
+        if contigs and rng.random() < 0.85:
+            c = rng.choice(contigs)
+            if len(c) > 0:
+                p = rng.randrange(0, len(c))
+                s = (c * (1 + L // max(1, len(c)) + 1))[p:p + L]
+                s = mutate(rng, s, rng.choice([0, 0, 0.02, 0.1, 0.3]))
+                if rng.random() < 0.5 and L > 60:  # junk inside and at the ends: split and trim have something to find
+                    b = bytearray(s)
+                    for _ in range(rng.choice([1, 1, 2, 3])):
+                        a = rng.randrange(0, L)
+                        w = rng.choice([1, 5, 20, 40, 120, 400])
+                        b[a:a + w] = rand_bases(rng, len(b[a:a + w]))
+                    if rng.random() < 0.5:
+                        w = rng.randrange(1, 60)
+                        b[:w] = rand_bases(rng, w)
+                    if rng.random() < 0.5:
+                        w = rng.randrange(1, 60)
+                        b[-w:] = rand_bases(rng, w)
+                    s = bytes(b)
+            else:
+                s = rand_bases(rng, L)
+            if rng.random() < 0.3:
+                s = _oracle_revcomp(s)
+        else:
+            s = rand_bases(rng, L)
+        if rng.random() < 0.1:
+            s = s.lower()
+        if rng.random() < 0.1 and L > 0:
+            b = bytearray(s)
+            for _ in range(rng.randrange(1, 6)):
+                b[rng.randrange(0, L)] = rng.choice(b"NnRYKM-*")
+            s = bytes(b)
+        centre = rng.randrange(33, 100)
+        spread = rng.choice([0, 2, 8, 30])
+        if rng.random() < 0.05:
+            q = bytes([33]) * L
+        elif rng.random() < 0.05:
+            q = bytes(rng.randrange(33, 127) for _ in range(L))
+        else:
+            q = bytes(min(126, max(33, centre + rng.randrange(-spread, spread + 1))) for _ in range(L))
+        name = b"r%d" % i
+        comment = rng.choice([b"", b"", b" len=%d" % L, b"\tx y z", b" "])
+        reads.append([name, comment, s, q])
+        total += L
+    if n >= 2 and rng.random() < 0.25:  # records of equal content under different names: exact score ties around the cut
+        for _ in range(rng.randrange(1, 1 + n // 2)):
+            a, b = rng.randrange(n), rng.randrange(n)
+            if a != b:
+                total += len(reads[a][2]) - len(reads[b][2])
+                reads[b][2], reads[b][3] = reads[a][2], reads[a][3]
+    error_kind = None
+    if n >= 2 and rng.random() < 0.06:
+        reads[rng.randrange(1, n)][0] = reads[0][0]  # duplicate name (src/main.cpp:113-117)
+        error_kind = "dup"
+
+    fasta = mode != "phred" and rng.random() < 0.2
+    if mode == "phred" and rng.random() < 0.04:
+        fasta = True  # FASTA without an external reference (src/main.cpp:103-106)
+    style = rng.choices(["plain", "wrapped", "crlf", "no_final_newline", "blank_lines", "truncated", "mixed"],
+                        [0.55, 0.1, 0.1, 0.1, 0.05, 0.05, 0.05])[0]
+    nl = b"\r\n" if style == "crlf" else b"\n"
+    out = bytearray()
+    for k, (name, comment, s, q) in enumerate(reads):
+        as_fasta = fasta != (style == "mixed" and k == n - 1 and n > 1)
+        head = (b">" if as_fasta else b"@") + name + comment + nl
+        if style == "wrapped" and len(s) > 0:
+            w = rng.choice([1, 7, 60, 61])
+            body = nl.join(s[i:i + w] for i in range(0, len(s), w)) + nl
+            qual = nl.join(q[i:i + w] for i in range(0, len(q), w)) + nl
+        else:
+            body, qual = s + nl, q + nl
+        out += head + body
+        if not as_fasta:
+            out += b"+" + (name if rng.random() < 0.1 else b"") + nl + qual
+        if style == "blank_lines" and rng.random() < 0.5:
+            out += nl
+    if style == "no_final_newline" and out.endswith(nl):
+        del out[-len(nl):]
+    if style == "truncated" and len(out) > 10:
+        del out[-rng.randrange(1, min(len(out), 200)):]
+    data = bytes(out)
+    inname = "reads.fasta" if fasta else "reads.fastq"
+    if rng.random() < 0.12:
+        data = gzip.compress(data, mtime=0)
+        inname += ".gz"
+    files[inname] = data
+
+    # ---- flags ----
+    if rng.random() < 0.3:
+        argv += ["--min_length", str(rng.choice([1, 16, 100, 250, 1000, 5000] + [0] * (rng.random() < 0.1)))]
+    if rng.random() < 0.12:
+        argv += ["--max_length", str(rng.choice([1, 100, 1000, 2500, 100000]))]
+    if rng.random() < 0.2:
+        argv += ["--min_mean_q", "%.3f" % rng.uniform(0, 100)]
+    if rng.random() < 0.2:
+        argv += ["--min_window_q", "%.3f" % rng.uniform(0, 100)]
+    r = rng.random()
+    if rng.random() < 0.03:
+        r = 0.45 if rng.random() < 0.5 else 2.0  # 2.0: no threshold at all (an argument error unless a hard cut-off is given)
+    if r < 0.4 or 0.9 < r <= 1.0:
+        argv += ["--keep_percent", rng.choice(["%d" % rng.randrange(1, 100), "%.2f" % rng.uniform(0.5, 99.9), "50", "99.999", "0.001"] + ["100"] * (rng.random() < 0.1))]
+    if 0.3 < r < 0.95 or 0.97 < r <= 1.0:
+        argv += ["--target_bases", str(rng.choice([1] * (rng.random() < 0.2) + [max(1, total // 3), max(1, total // 2), max(1, total - 1), total + 1, 10 ** 9,
+                                                     rng.randrange(1, total + 2)]))]
+    if rng.random() < 0.25:
+        for flag in ("--length_weight", "--mean_q_weight", "--window_q_weight"):
+            if rng.random() < 0.6:
+                argv += [flag, rng.choice(["0", "0.5", "1", "2", "10", "0.001"])]
+    if rng.random() < 0.35:
+        argv += ["--window_size", str(rng.choice(WINDOWS))]
+    if mode != "phred" or rng.random() < 0.05:
+        if rng.random() < 0.45:
+            argv += ["--trim"]
+        if rng.random() < 0.45:
+            argv += ["--split", str(rng.choice(SPLITS))]
+    if rng.random() < 0.15:
+        argv += ["--verbose"]
+    if rng.random() < 0.2:  # the short forms, glued to their value or not (src/arguments.cpp:126-221)
+        short = {"--target_bases": "-t", "--keep_percent": "-p", "--min_length": "-l", "--max_length": "-L", "--min_mean_q": "-q",
+                 "--min_window_q": "-w"}
+        new = []
+        for tok in argv:
+            if new and new[-1] in short.values() and rng.random() < 0.5:
+                new[-1] += tok  # -t100
+            else:
+                new.append(short.get(tok, tok))
+        argv = new
+    argv += [inname]
+    return {"files": files, "argv": argv, "mode": mode, "style": style, "error": error_kind}
+
+
+_COMP = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+
+
+def _oracle_revcomp(s):
+    return s.translate(_COMP)[::-1]
+
+
+def shown(err):
+    """stderr as a terminal shows it: the last carriage-return segment of every line"""
+    return [l.split("\r")[-1] for l in err.split("\n")]
+
+
+def run_both(case, td, extra_env=None):
+    for name, data in case["files"].items():
+        with open(os.path.join(td, name), "wb") as f:
+            f.write(data)
+    env = dict(os.environ, LANG="C", LC_ALL="C")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    ref = subprocess.run([_oracle.REF_FILTLONG] + case["argv"], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    env.update(extra_env or {})
+    new = subprocess.run([BIN] + case["argv"], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return ref, new
+
+
+N_CASES = int(os.environ.get("FLX_FUZZ_CASES", "240"))      # a longer campaign: FLX_FUZZ_CASES=2000 FLX_FUZZ_BASE=campaign-2
+SEED_BASE = os.environ.get("FLX_FUZZ_BASE", "filtlong-fuzz").encode()
+INGEST = {
+    "default": {},
+    "chunked": {"FLX_CLI_CHUNK_BYTES": "9000"},
+    "blocks": {"FLX_CLI_FORCE_STREAM": "1", "FLX_CLI_BLOCK_BYTES": "5000"},
+}
+
+
+@pytest.mark.parametrize("part", range(4))
+def test_random_invocations_match_the_reference_binary(tmp_path, part):
+    assert os.path.exists(_oracle.REF_FILTLONG), "oracle/_ref/filtlong missing: run `make -C oracle` where /root/reference exists"
+    seen = {"ok": 0, "error": 0, "children": 0, "empty_out": 0}
+    for i in range(part, N_CASES, 4):
+        seed = zlib.crc32(SEED_BASE + b"-%d" % i)
+        case = make_case(seed)
+        td = tmp_path / ("case%d" % i)
+        td.mkdir()
+        ingest = sorted(INGEST)[(i // 4) % 3] if i % 8 >= 4 else "default"
+        ref, new = run_both(case, str(td), INGEST[ingest])
+        what = (i, seed, ingest, case["argv"], case["mode"], case["style"])
+        assert ref.returncode in (0, 1), (what, ref.stderr[-400:])
+        assert new.returncode == ref.returncode, (what, new.stderr.decode(errors="replace")[-600:], ref.stderr.decode(errors="replace")[-600:])
+        assert new.stdout == ref.stdout, (what, len(new.stdout), len(ref.stdout))
+        if b"usage:" not in ref.stderr and b"--help" not in ref.stderr:
+            assert shown(new.stderr.decode(errors="replace")) == shown(ref.stderr.decode(errors="replace")), what
+        seen["ok" if ref.returncode == 0 else "error"] += 1
+        seen["children"] += ref.stdout.count(b"-") > 0 and ("--trim" in case["argv"] or "--split" in case["argv"])
+        seen["empty_out"] += len(ref.stdout) == 0
+    assert seen["ok"] >= 20 and seen["error"] >= 1, seen
