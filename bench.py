@@ -260,6 +260,7 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
     fold_ms, _ = ctx.timing_get("flx_score_kmer_fold")
     rank_ms, _ = ctx.timing_get("flx_rank")
     gather_ms, _ = ctx.timing_get("flx_reads2")
+    csort_ms, _ = ctx.timing_get("flx_sort")  # k-mer mode: the children ordered by length for the one-lane-per-child fold
     ctx.timing_enable(False)
     cover = cover_ms / max(cn, 1)
     lookups = b.bases - 15 * n
@@ -281,7 +282,7 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
         "value": round(b.bases / el / 1e6, 1), "unit": "Mbases/s", "ms_per_step": round(el * 1e3, 2),
         "bases": b.bases, "set_size": len(ks), "set_build_s_device": round(build_s, 2), "children": nc, "reads2": n2,
         "stage_ms_per_step": {"cover_kernel": round(cover, 2), "fold_kernels": round(fold_ms / steps, 2),
-                              "reads2_gather_kernels": round(gather_ms / steps, 3), "rank_kernels": round(rank_ms / steps, 2)},
+                              "child_sort_kernels": round(csort_ms / steps, 3), "reads2_gather_kernels": round(gather_ms / steps, 3), "rank_kernels": round(rank_ms / steps, 2)},
         "lookups_per_s_G": round(lookups / (cover * 1e-3) / 1e9, 2),
         "roofline": {
             # the contract's fraction: SURVEY §8(d) algorithmic bytes of the launch / kernel time / HBM peak

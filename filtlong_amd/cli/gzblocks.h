@@ -3,6 +3,7 @@
 #pragma once
 #include "fastx.h"
 #include "inflate_stream.h"
+#include "pinflate.h"
 
 // ---- block-wise parse of a compressed input -----------------------------------------------------------------------------
 // A gzip file cannot be mapped, and inflating all of it costs its uncompressed size in memory (the reference never holds
@@ -36,7 +37,7 @@ struct MappedFile {  // read-only mapping of a regular file (the compressed inpu
 struct BlockReader {
     static constexpr size_t kHistory = 32768;  // output kept in front of the write position: the window of an access point
     MappedFile file;
-    InflateStream z;
+    ParallelInflate z;  // pass 1 of a large gzip input on all host threads; zlib for everything else
     std::vector<char> buf;
     size_t have = 0;        // valid bytes in buf
     size_t view_from = 0;   // the parse window is [view_from, have); bytes before it are history
@@ -58,7 +59,7 @@ struct BlockReader {
         return (uint64_t)32 << 20;
     }
     bool open(const std::string &path, bool want_points) {
-        if (!file.open(path) || !z.open(file.p, file.n, file.gz())) return false;
+        if (!file.open(path) || !z.open(file.p, file.n, file.gz(), host_threads())) return false;
         buf.resize(block_bytes() + kHistory);
         span = want_points ? point_span() : 0;
         points.clear();

@@ -94,6 +94,8 @@ static int parse_only(const std::string &path, const char *mode) {
             if (parsed.status == -2) break;
         }
         if (rd.io_error) { std::cerr << "Error reading " << path << "\n"; return 1; }
+        std::cerr << "inflate: " << rd.z.parallel_bytes() << " of " << rd.z.total_out() << " bytes from the parallel path (" << rd.z.zlib_tail_bytes() << " by zlib behind the marker decoder), " << rd.z.rounds()
+                  << " round(s), " << rd.z.dropped_chunks() << " chunk(s) dropped\n";
         if (mode[0] == 'u' && parsed.status != -2) {
             // units: every piece between two access points (FLX_CLI_SPAN_BYTES apart) inflated and parsed on its own, on
             // several threads, as the output pass does; digest of the pieces in order
