@@ -59,7 +59,7 @@ struct BlockReader {
         return (uint64_t)32 << 20;
     }
     bool open(const std::string &path, bool want_points) {
-        if (!file.open(path) || !z.open(file.p, file.n, file.gz(), host_threads())) return false;
+        if (!file.open(path) || !z.open(file.p, file.n, file.gz(), ParallelInflate::default_threads(host_threads()))) return false;
         buf.resize(block_bytes() + kHistory);
         span = want_points ? point_span() : 0;
         points.clear();

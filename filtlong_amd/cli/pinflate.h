@@ -412,6 +412,11 @@ public:
         if (const char *e = getenv("FLX_CLI_PINFLATE_MIN")) return (size_t)atoll(e);
         return (size_t)8 << 20;
     }
+    static unsigned default_threads(unsigned host_threads) {  // decoding scales further than the host's memory-bound stages
+        if (const char *e = getenv("FLX_CLI_INFLATE_THREADS")) return (unsigned)std::max(1, atoi(e));
+        if (getenv("FLX_CLI_THREADS")) return host_threads;
+        return std::max(host_threads, std::min(32u, std::thread::hardware_concurrency()));
+    }
     static size_t chunk_bytes() {  // compressed bytes per chunk (tests force tiny chunks)
         if (const char *e = getenv("FLX_CLI_PINFLATE_CHUNK")) return std::max<size_t>(64, (size_t)atoll(e));
         return (size_t)2 << 20;
@@ -452,14 +457,31 @@ public:
     size_t read(char *dst, size_t cap, std::vector<GzPoint> *points = nullptr, uint64_t span = 0) {
         size_t produced = 0;
         while (produced < cap && !error_) {
-            if (!queue_.empty()) {
-                Piece &pc = queue_.front();
-                const size_t m = std::min(cap - produced, pc.n - pc.pos);
-                memcpy(dst + produced, pc.bytes.data() + pc.pos, m);
-                pc.pos += m; produced += m; delivered_ += m;
-                if (pc.pos >= pc.n) {
-                    if (pool_.size() < 2 * (size_t)threads_) pool_.push_back(std::move(pc.bytes));
-                    queue_.pop_front();
+            if (!queue_.empty()) {  // whole chunks to their places on all threads
+                struct Copy { const char *from; char *to; size_t n; };
+                std::vector<Copy> plan;
+                size_t at = produced;
+                for (const Piece &pc : queue_) {
+                    const size_t m = std::min(cap - at, pc.n - pc.pos);
+                    if (m == 0) break;
+                    for (size_t o = 0; o < m; o += (size_t)4 << 20)
+                        plan.push_back({pc.bytes.data() + pc.pos + o, dst + at + o, std::min<size_t>(m - o, (size_t)4 << 20)});
+                    at += m;
+                    if (m < pc.n - pc.pos) break;
+                }
+                pinflate::run_parallel(plan.size(), threads_, [&](size_t k) { memcpy(plan[k].to, plan[k].from, plan[k].n); });
+                size_t left = at - produced;
+                produced = at;
+                delivered_ += left;
+                while (left > 0) {
+                    Piece &pc = queue_.front();
+                    const size_t m = std::min(left, pc.n - pc.pos);
+                    pc.pos += m;
+                    left -= m;
+                    if (pc.pos >= pc.n) {
+                        if (pool_.size() < 2 * (size_t)threads_) pool_.push_back(std::move(pc.bytes));
+                        queue_.pop_front();
+                    }
                 }
                 while (!pending_.empty() && pending_.front().out <= delivered_) {
                     if (points && pending_.front().out - last_point_out_ >= span) {

@@ -1,9 +1,10 @@
 #!/bin/bash
 # End to end on a gzip-compressed FASTQ (the usual form of real inputs): filtlong-amd streams it block by block, the
 # in-memory path (FLX_CLI_NO_STREAM=1) and the reference binary beside it, same box, same file.
-# usage: tools/bench_e2e_gz.sh [n_reads=150000]   -> gpurun_out/r02_e2e_gz.json, gpurun_out/r02_e2e_gz.log
+# usage: tools/bench_e2e_gz.sh [n_reads=150000] [prefix=r03]   -> gpurun_out/<prefix>_e2e_gz.json, gpurun_out/<prefix>_e2e_gz.log
 R=${GRAFT_REPO_ROOT:-$PWD}
 N=${1:-150000}
+PFX=${2:-r03}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 export LANG=C LC_ALL=C
@@ -28,6 +29,13 @@ for rep in 1 2; do
   echo "filtlong-amd (streamed) run $rep: $AMD_S s"
 done
 tr '\r' '\n' < /tmp/amd.err | grep timing
+for TH in 1 16 32 64; do
+  rm -f /tmp/amd.out
+  S=$(date +%s%N); FLX_CLI_INFLATE_THREADS=$TH $R/filtlong_amd/bin/filtlong --target_bases $TARGET /tmp/gzin.fastq.gz > /tmp/amd.out 2> /dev/null; E=$(date +%s%N)
+  echo "filtlong-amd (streamed), $TH inflate thread(s) in pass 1: $(t $S $E) s"
+done
+rm -f /tmp/amd.out
+FLX_CLI_TIMING=1 $R/filtlong_amd/bin/filtlong --target_bases $TARGET /tmp/gzin.fastq.gz > /tmp/amd.out 2> /tmp/amd.err
 ANON=$(tr '\r' '\n' < /tmp/amd.err | grep timing | sed -E 's/.*RssAnon +([0-9]+) MiB.*/\1/' | sort -n | tail -1)
 S=$(date +%s%N)
 FLX_CLI_NO_STREAM=1 FLX_CLI_TIMING=1 $R/filtlong_amd/bin/filtlong --target_bases $TARGET /tmp/gzin.fastq.gz > /tmp/amd2.out 2> /tmp/amd2.err
@@ -43,7 +51,7 @@ REF_S=$(t $S $E)
 echo "reference: $REF_S s"
 if cmp /tmp/ref.out /tmp/amd.out && cmp /tmp/ref.out /tmp/amd2.out; then IDENT=true; echo "stdout identical ($(stat -c %s /tmp/amd.out) bytes)"; else IDENT=false; echo "STDOUT DIFFERS"; fi
 grep -E "target|keeping" /tmp/ref.err /tmp/amd.err
-} > $OUT/r02_e2e_gz.log 2>&1
+} > $OUT/${PFX}_e2e_gz.log 2>&1
 python - <<PY
 import json
 amd, mem, ref = float("$AMD_S"), float("$MEM_S"), float("$REF_S")
@@ -51,8 +59,8 @@ json.dump({"reads": $N, "bases": $BASES, "fastq_bytes": $RAW, "gz_bytes": $SIZE,
            "gzip_dc_alone_s": float("$INFLATE_S"), "filtlong_amd_streamed_s": amd, "filtlong_amd_in_memory_s": mem, "reference_s": ref,
            "speedup": ref / amd, "stdout_identical": "$IDENT" == "true",
            "peak_rss_anon_mib_streamed": int("$ANON" or 0), "peak_rss_anon_mib_in_memory": int("$ANON2" or 0),
-           "note": "pass 1 inflates on one zlib thread (the floor of this path); the output pass inflates the record-aligned pieces between the access points pass 1 left, on up to 16 threads; the reference inflates the file twice on one thread"},
-          open("$OUT/r02_e2e_gz.json", "w"), indent=1)
+           "note": "pass 1 inflates block-parallel (cli/pinflate.h: block starts found by search, markers for the unknown window, zlib from the last boundary as fallback); the output pass inflates the record-aligned pieces between the access points pass 1 left; the reference inflates the file twice on one thread"},
+          open("$OUT/${PFX}_e2e_gz.json", "w"), indent=1)
 PY
-tail -40 $OUT/r02_e2e_gz.log; cat $OUT/r02_e2e_gz.json
+tail -40 $OUT/${PFX}_e2e_gz.log; cat $OUT/${PFX}_e2e_gz.json
 rm -f /tmp/gzin.fastq.gz /tmp/amd.out /tmp/amd2.out /tmp/ref.out
