@@ -19,6 +19,8 @@
 #include <thread>
 #include <vector>
 
+#include "pinflate.h"
+
 // ------------------------------------------------------------------------------------------------ FASTA/FASTQ
 // In-memory parser with the record grammar of klib's kseq (src/kseq.h:176-224): records start at the next '>' or
 // '@'; the name ends at the first whitespace, the rest of the header line is the comment; sequence lines run until a
@@ -96,6 +98,32 @@ struct Input {
                     sink[i] = acc;
                 });
                 return true;
+            }
+        }
+        if (gz) {  // a gzip file (reads taken into memory, references): block-parallel inflate of the mapped file
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                bool ok = false;
+                {
+                    ParallelInflate z;
+                    if (z.open((const unsigned char *)m, (size_t)st.st_size, true, ParallelInflate::default_threads(host_threads()))) {
+                        size_t have = 0;
+                        owned.resize(std::max<size_t>((size_t)1 << 22, (size_t)st.st_size * 4));
+                        while (!z.eof() && !z.error()) {
+                            if (have == owned.size()) owned.resize(owned.size() * 2);
+                            have += z.read(&owned[have], owned.size() - have);
+                        }
+                        ok = !z.error();
+                        owned.resize(ok ? have : 0);
+                    }
+                }
+                munmap(m, (size_t)st.st_size);
+                if (ok) {
+                    ::close(fd);
+                    p = owned.data(); n = owned.size();
+                    return true;
+                }
+                owned.clear();  // a damaged file: what gzread makes of it, below
             }
         }
         ::close(fd);

@@ -426,19 +426,15 @@ public:
         data_ = data; size_ = size; threads_ = std::max(1u, threads);
         serial_mode_ = true; member_done_ = false; error_ = false;
         delivered_ = 0; queue_.clear(); pending_.clear();
+        stream_out_ = 0; member_base_ = 0; bgzf_mode_ = false; bgzf_at_ = 0;
         parallel_bytes_ = 0; zlib_tail_bytes_ = 0; rounds_ = 0; dropped_chunks_ = 0;
         const char *off = getenv("FLX_CLI_PINFLATE");  // 0: zlib only; "nozlib": every chunk to its end with the marker decoder (tests)
         zlib_tails_ = !(off && strcmp(off, "nozlib") == 0);
-        size_t hdr = 0;
-        if (gz && threads_ >= 2 && size >= min_bytes() && !(off && off[0] == '0') && gzip_header(&hdr)) {
-            serial_mode_ = false;
-            chain_bit_ = (uint64_t)hdr * 8;
-            member_out_ = 0;
-            crc_ = crc32(0L, Z_NULL, 0);
-            window_.clear();
-            last_point_out_ = 0;
+        if (gz && threads_ >= 2 && size >= min_bytes() && !(off && off[0] == '0')) {
             decoders_.resize(threads_);
-            return true;
+            last_point_out_ = 0;
+            begin_member(0);
+            return !error_;
         }
         return serial_.open(data, size, gz);
     }
@@ -498,7 +494,8 @@ public:
                 break;  // (less than asked for only at the end or on an error)
             }
             if (member_done_) break;
-            round();
+            if (bgzf_mode_) bgzf_round();
+            else round();
         }
         return produced;
     }
@@ -526,14 +523,25 @@ private:
         std::string window;  // the (up to) 32 KiB in front of it
     };
 
-    bool gzip_header(size_t *deflate_at) const {  // RFC 1952
-        if (size_ < 18 + 8 || data_[0] != 0x1f || data_[1] != 0x8b || data_[2] != 8) return false;
-        const unsigned flg = data_[3];
+    // RFC 1952 header at byte `at`; *bgzf_size: the member's total size if it carries the BGZF subfield (SAM spec 4.1), else 0
+    bool gzip_header(size_t at, size_t *deflate_at, size_t *bgzf_size) const {
+        *bgzf_size = 0;
+        if (at + 18 + 8 > size_ || data_[at] != 0x1f || data_[at + 1] != 0x8b || data_[at + 2] != 8) return false;
+        const unsigned flg = data_[at + 3];
         if (flg & 0xe0) return false;
-        size_t p = 10;
+        size_t p = at + 10;
         if (flg & 4) {
             if (p + 2 > size_) return false;
-            p += 2 + ((size_t)data_[p] | (size_t)data_[p + 1] << 8);
+            const size_t xlen = (size_t)data_[p] | (size_t)data_[p + 1] << 8;
+            p += 2;
+            if (p + xlen > size_) return false;
+            for (size_t q = p; q + 4 <= p + xlen;) {
+                const size_t slen = (size_t)data_[q + 2] | (size_t)data_[q + 3] << 8;
+                if (data_[q] == 'B' && data_[q + 1] == 'C' && slen == 2 && q + 6 <= p + xlen)
+                    *bgzf_size = ((size_t)data_[q + 4] | (size_t)data_[q + 5] << 8) + 1;
+                q += 4 + slen;
+            }
+            p += xlen;
         }
         for (int f = 8; f <= 16; f <<= 1)  // FNAME, FCOMMENT: zero-terminated
             if (flg & f) {
@@ -546,10 +554,114 @@ private:
         return true;
     }
 
+    // a member starts at byte `at` (stream offset delivered so far + queued = stream_out_): BGZF blocks are inflated side by side, a
+    // large plain member goes to the chunked decoder, anything else to zlib for the rest of the file
+    void begin_member(size_t at) {
+        size_t hdr = 0, bsize = 0;
+        member_done_ = false;
+        bgzf_at_ = 0;
+        bgzf_mode_ = false;
+        if (gzip_header(at, &hdr, &bsize)) {
+            if (bsize > 0 && at + bsize <= size_) {
+                serial_mode_ = false;
+                bgzf_mode_ = true;
+                bgzf_at_ = at;
+                return;
+            }
+            if (size_ - at >= min_bytes() || at == 0) {
+                serial_mode_ = false;
+                chain_bit_ = (uint64_t)hdr * 8;
+                member_base_ = stream_out_;
+                member_out_ = 0;
+                crc_ = crc32(0L, Z_NULL, 0);
+                window_.clear();
+                return;
+            }
+        }
+        GzPoint pt;
+        pt.in = at;
+        pt.out = stream_out_;
+        pt.raw = false;
+        serial_mode_ = true;
+        if (at == 0 ? !serial_.open(data_, size_, true) : !serial_.open_at(data_, size_, true, pt)) error_ = true;
+    }
+
+    // BGZF: up to threads x 128 blocks, every thread a run of neighbours through zlib (which checks each block's CRC-32 and size)
+    void bgzf_round() {
+        struct Member { size_t at, size; uint32_t isize; };
+        std::vector<Member> mem;
+        size_t at = bgzf_at_;
+        bool more = true;
+        while (mem.size() < (size_t)threads_ * 128) {
+            size_t hdr = 0, bsize = 0;
+            if (at + 2 > size_ || data_[at] != 0x1f || data_[at + 1] != 0x8b) { more = false; break; }  // the end of the file (or not a member)
+            if (!gzip_header(at, &hdr, &bsize) || bsize == 0 || at + bsize > size_ || bsize < hdr - at + 8) break;  // not BGZF: decided below
+            const size_t t = at + bsize - 4;
+            mem.push_back({at, bsize, (uint32_t)data_[t] | (uint32_t)data_[t + 1] << 8 | (uint32_t)data_[t + 2] << 16 | (uint32_t)data_[t + 3] << 24});
+            at += bsize;
+        }
+        if (mem.empty()) {
+            if (!more) { member_done_ = true; return; }
+            begin_member(at);  // a member of another kind
+            if (bgzf_mode_) { error_ = true; }  // (cannot happen: the loop above would have taken it)
+            return;
+        }
+        const size_t runs = std::min<size_t>(threads_, mem.size());
+        std::vector<Piece> pieces(runs);
+        std::vector<int> ok(runs, 1);
+        std::vector<size_t> first(runs + 1);
+        for (size_t r = 0; r <= runs; ++r) first[r] = mem.size() * r / runs;
+        pinflate::run_parallel(runs, threads_, [&](size_t r) {
+            size_t total = 0;
+            for (size_t k = first[r]; k < first[r + 1]; ++k) total += mem[k].isize;
+            Piece &pc = pieces[r];
+            pc.bytes = take_buffer();
+            if (pc.bytes.size() < total) pc.bytes.resize(total);
+            size_t have = 0;
+            z_stream z;
+            memset(&z, 0, sizeof z);
+            if (inflateInit2(&z, 31) != Z_OK) { ok[r] = 0; return; }
+            for (size_t k = first[r]; k < first[r + 1] && ok[r]; ++k) {
+                z.next_in = (Bytef *)data_ + mem[k].at; z.avail_in = (uInt)mem[k].size;
+                z.next_out = (Bytef *)pc.bytes.data() + have; z.avail_out = (uInt)mem[k].isize;
+                const int ret = inflate(&z, Z_FINISH);
+                if (ret != Z_STREAM_END || z.avail_in != 0 || z.avail_out != 0) ok[r] = 0;
+                have += mem[k].isize;
+                if (inflateReset(&z) != Z_OK) ok[r] = 0;
+            }
+            inflateEnd(&z);
+            pc.n = total;
+        });
+        ++rounds_;
+        for (size_t r = 0; r < runs; ++r) {
+            if (!ok[r]) {  // zlib reads this run again, alone, and says what is wrong with it
+                GzPoint pt;
+                pt.in = mem[first[r]].at;
+                pt.out = stream_out_;
+                pt.raw = false;
+                serial_mode_ = true;
+                bgzf_mode_ = false;
+                if (!serial_.open_at(data_, size_, true, pt)) error_ = true;
+                return;
+            }
+            if (stream_out_ > 0) {
+                GzPoint pt;
+                pt.in = mem[first[r]].at;
+                pt.out = stream_out_;
+                pt.raw = false;
+                pending_.push_back(std::move(pt));
+            }
+            stream_out_ += pieces[r].n;
+            parallel_bytes_ += pieces[r].n;
+            if (pieces[r].n > 0) queue_.push_back(std::move(pieces[r]));
+        }
+        bgzf_at_ = at;
+    }
+
     GzPoint point_at(uint64_t bit, uint64_t out, const std::string &window) const {
         GzPoint pt;
         pt.raw = true;
-        pt.out = out;
+        pt.out = member_base_ + out;
         pt.in = (bit + 7) >> 3;
         pt.bits = (int)((8 - (bit & 7)) & 7);
         pt.window = window;
@@ -732,8 +844,9 @@ private:
         for (size_t k = 0; k < chain.size(); ++k) {
             Chunk &c = ch[chain[k]];
             crc_ = crc32_combine(crc_, c.crc, (z_off_t)c.n);
-            if (c.out > 0) pending_.push_back(point_at(c.start, c.out, c.window));
+            if (member_base_ + c.out > 0) pending_.push_back(point_at(c.start, c.out, c.window));
             parallel_bytes_ += c.n;
+            stream_out_ += c.n;
             zlib_tail_bytes_ += c.n - c.n_sym;
             if (c.n > 0) {
                 Piece pc;
@@ -785,15 +898,7 @@ private:
         auto le32 = [&](size_t p) { return (uint32_t)data_[p] | (uint32_t)data_[p + 1] << 8 | (uint32_t)data_[p + 2] << 16 | (uint32_t)data_[p + 3] << 24; };
         if (le32(t) != (uint32_t)crc_ || le32(t + 4) != (uint32_t)member_out_) { error_ = true; return; }
         const size_t next = t + 8;
-        if (next + 2 <= size_ && data_[next] == 0x1f && data_[next + 1] == 0x8b) {  // another member: zlib reads on, like gzread
-            GzPoint pt;
-            pt.in = next;
-            pt.out = member_out_;
-            pt.raw = false;
-            serial_mode_ = true;
-            member_done_ = false;
-            if (!serial_.open_at(data_, size_, true, pt)) error_ = true;
-        }
+        if (next + 2 <= size_ && data_[next] == 0x1f && data_[next + 1] == 0x8b) begin_member(next);  // like gzread: members follow each other
     }
 
     const unsigned char *data_ = nullptr;
@@ -803,7 +908,11 @@ private:
     bool serial_mode_ = true, member_done_ = false, error_ = false, zlib_tails_ = true;
     uint64_t delivered_ = 0;   // bytes handed to the caller
     uint64_t chain_bit_ = 0;   // where the next round starts
-    uint64_t member_out_ = 0;  // bytes of the member decoded so far (the parallel decoder only does the first member: = stream offset)
+    uint64_t member_out_ = 0;  // bytes of the current member decoded so far
+    uint64_t member_base_ = 0; // stream offset of the current member's first byte
+    uint64_t stream_out_ = 0;  // bytes decoded so far (delivered or queued)
+    bool bgzf_mode_ = false;
+    size_t bgzf_at_ = 0;       // the next BGZF block
     uLong crc_ = 0;
     std::string window_;       // the last 32 KiB decoded
     uint64_t last_point_out_ = 0;

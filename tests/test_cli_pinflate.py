@@ -96,6 +96,9 @@ def test_parallel_inflate_gives_the_sequential_records(reads, level, chunk, thre
     # the same through zlib alone
     rc, got, err = run(gz, "unit", threads, FLX_CLI_PINFLATE=0, FLX_CLI_SPAN_BYTES=200000, FLX_CLI_BLOCK_BYTES=1 << 20)
     assert rc == 0 and got == want and stats(err)[0] == 0
+    # the whole file taken into memory (references, FLX_CLI_NO_STREAM): the same decoder behind Input::open
+    rc, got, err = run(gz, "seq", threads, FLX_CLI_PINFLATE_MIN=1, FLX_CLI_PINFLATE_CHUNK=chunk)
+    assert rc == 0 and got == want
 
 
 def test_zlib_takes_the_tail_of_a_chunk_once_the_markers_are_gone(reads):
@@ -182,6 +185,59 @@ def test_odd_streams(tmp_path):
     assert stats(err)[0] < len(mono)
 
 
+def bgzf(data, piece=60000, level=6):
+    """the blocked gzip of bgzip / htslib (SAM specification 4.1): members of at most 64 KiB that carry their own size"""
+    import struct
+    out = b""
+    for a in list(range(0, len(data), piece)) + [None]:
+        d = b"" if a is None else data[a:a + piece]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        cd = c.compress(d) + c.flush()
+        out += (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(cd) + 25) + cd
+                + struct.pack("<II", zlib.crc32(d) & 0xffffffff, len(d)))
+    return out
+
+
+def test_bgzf_and_members_side_by_side(tmp_path):
+    """A bgzip file is inflated block-parallel through zlib; plain members in front of it or behind it go their own way; a damaged
+    block ends the run like zlib alone."""
+    rng = np.random.RandomState(13)
+    data = read_like_fastq(rng, 200, 4000)
+    plain = str(tmp_path / "in.fastq")
+    open(plain, "wb").write(data)
+    rc, want, _ = run(plain, "seq")
+    assert rc == 0
+    assert gzip.decompress(bgzf(data)) == data
+    half = len(data) // 2
+    variants = {
+        "bgzf": bgzf(data),
+        "bgzf_small_blocks": bgzf(data, 700, 1),
+        "bgzf_then_plain": bgzf(data[:half]) + gzip.compress(data[half:], 6, mtime=0),
+        "plain_then_bgzf": gzip.compress(data[:half], 6, mtime=0) + bgzf(data[half:]),
+        "bgzf_garbage_behind": bgzf(data) + b"\0\0\0",
+    }
+    for name, blob in sorted(variants.items()):
+        gz = str(tmp_path / (name + ".fastq.gz"))
+        open(gz, "wb").write(blob)
+        for threads in (2, 7):
+            rc, got, err = run(gz, "unit", threads, FLX_CLI_PINFLATE_MIN=1, FLX_CLI_PINFLATE_CHUNK=4000, FLX_CLI_SPAN_BYTES=70000)
+            assert rc == 0, (name, err)
+            assert got == want, (name, threads)
+            assert stats(err)[0] == len(data), (name, err)
+        rc, got, err = run(gz, "seq", 4, FLX_CLI_PINFLATE_MIN=1)
+        assert rc == 0 and got == want, name
+    blob = bytearray(bgzf(data))
+    for k in range(6):
+        b = bytearray(blob)
+        b[int(rng.randint(30, len(b) - 30))] ^= 1 << int(rng.randint(8))
+        gz = str(tmp_path / ("bad%d.fastq.gz" % k))
+        open(gz, "wb").write(bytes(b))
+        for mode in ("blk", "seq"):
+            a = run(gz, mode, 5, FLX_CLI_PINFLATE=0)
+            p = run(gz, mode, 5, FLX_CLI_PINFLATE_MIN=1)
+            assert a[:2] == p[:2], (k, mode, a[2][-200:], p[2][-200:])
+
+
 def test_damaged_files_end_like_through_zlib(tmp_path):
     """Truncated anywhere, a flipped bit anywhere, a wrong CRC-32, a wrong length: exit code and records as with FLX_CLI_PINFLATE=0."""
     rng = np.random.RandomState(5)
@@ -207,4 +263,8 @@ def test_damaged_files_end_like_through_zlib(tmp_path):
         if a[0] == 0:
             assert a[1] == p[1], name
         differing += a[0] != 0
+        # taken into memory: whatever gzread makes of the damaged file, with and without the parallel decoder in front of it
+        a = run(gz, "seq", 5, FLX_CLI_PINFLATE=0)
+        p = run(gz, "seq", 5, FLX_CLI_PINFLATE_MIN=1, FLX_CLI_PINFLATE_CHUNK=3000)
+        assert a[:2] == p[:2], name
     assert differing >= 10  # (most of these are errors; a flipped bit in a literal is caught by the CRC-32 either way)

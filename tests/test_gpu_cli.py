@@ -35,7 +35,8 @@ MODES = {
     "chunked": {"FLX_CLI_CHUNK_BYTES": "20000"},
     # the gzip path: input read block by block (tail carried over, blocks and pipeline slots grown for long records),
     # nothing of the input kept but names and lengths, second pass over the file for the output
-    "blocks": {"FLX_CLI_FORCE_STREAM": "1", "FLX_CLI_BLOCK_BYTES": "6000"},
+    # (gzip files, the reference's short-read fixtures among them, through the block-parallel inflater in chunks of 2000 bytes)
+    "blocks": {"FLX_CLI_FORCE_STREAM": "1", "FLX_CLI_BLOCK_BYTES": "6000", "FLX_CLI_PINFLATE_MIN": "1", "FLX_CLI_PINFLATE_CHUNK": "2000"},
     # the one-process-per-GPU path with a single rank: RCCL communicator, flx_rank_and_cut_comm, part files
     "rank-env": {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "FLX_COMM_ID_FILE": "/tmp/flx_test_comm.id"},
 }

@@ -66,6 +66,11 @@ def make_case(seed):
             files["sr_%d.fastq" % (k + 1)] = fq
         argv += ["-1", "sr_1.fastq", "-2", "sr_2.fastq"]
 
+    if files and rng.random() < 0.3:  # gzip-compressed references (read through gzopen by the reference: src/kmers.cpp:86-90)
+        for name in list(files):
+            files[name + ".gz"] = gzip.compress(files.pop(name), rng.choice([1, 6, 9]), mtime=0)
+        argv = [a + ".gz" if a in ("ref.fasta", "sr_1.fastq", "sr_2.fastq") else a for a in argv]
+
     # ---- reads ----
     n = rng.choice([0, 1, 2, 3, 5, 10, 30, 60])
     reads = []
@@ -224,6 +229,8 @@ def run_both(case, td, extra_env=None):
         env.pop(k, None)
     ref = subprocess.run([_oracle.REF_FILTLONG] + case["argv"], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     env.update(extra_env or {})
+    # gzip inputs and references (about one case in eight): through the block-parallel inflater, in chunks of a few hundred bytes
+    env.update(FLX_CLI_PINFLATE_MIN="1", FLX_CLI_PINFLATE_CHUNK="300")
     new = subprocess.run([BIN] + case["argv"], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     return ref, new
 
