@@ -86,10 +86,13 @@ static int read_int_suffix(const std::string &name, const std::string &value) { 
     } catch (...) { throw ParseError("Error: argument '" + name + "' received invalid value '" + value + "'"); }
 }
 
-static long long read_ll(const std::string &name, const std::string &value) {  // default args.h reader (operator>>)
+// The reference's default reader for --window_size (src/args.h:1609-1627): stream extraction into the flag's current value, and an
+// error only if characters are left unread — so an empty value keeps the current one and a number beyond long long saturates.
+static long long read_ll(const std::string &name, const std::string &value, long long current) {
     std::istringstream ss(value);
-    long long v;
-    if (!(ss >> v) || !ss.eof()) throw ParseError("Argument '" + name + "' received invalid value type '" + value + "'");
+    long long v = current;
+    ss >> v;
+    if (ss.rdbuf()->in_avail() > 0) throw ParseError("Error: argument '" + name + "' received invalid value type '" + value + "'");
     return v;
 }
 
@@ -135,25 +138,34 @@ static ParsingResult parse_args(int argc, char **argv, Args &a) {
     bool short1_set = false, short2_set = false;
     std::string short1, short2;
     std::vector<std::string> positional;
+    bool options_ended = false;
     try {
         for (int i = 1; i < argc; ++i) {
             std::string tok = argv[i];
             std::string flag, value;
             bool have_value = false;
+            if (options_ended) {
+                positional.push_back(tok);
+                continue;
+            }
+            if (tok == "--") {  // everything behind it is positional (src/args.h: the terminator)
+                options_ended = true;
+                continue;
+            }
             if (tok.size() >= 2 && tok[0] == '-' && tok[1] == '-') {
                 flag = tok.substr(2);  // long flags take their value from the next token (LongSeparator(" "), arguments.cpp:128)
             } else if (tok.size() >= 2 && tok[0] == '-' && !(isdigit((unsigned char)tok[1]) && false)) {
                 flag = std::string(1, tok[1]);
                 if (tok.size() > 2) { value = tok.substr(2); have_value = true; }  // -t100
                 static const char *shorts = "tplLqa12h";
-                if (!strchr(shorts, tok[1])) throw ParseError("Flag could not be matched: " + std::string(1, tok[1]));
+                if (!strchr(shorts, tok[1])) throw ParseError("Error: flag could not be matched: '" + std::string(1, tok[1]) + "'");
             } else {
                 positional.push_back(tok);
                 continue;
             }
-            auto need = [&](const char *n) -> std::string {
+            auto need = [&](const char *) -> std::string {
                 if (have_value) return value;
-                if (i + 1 >= argc) throw ParseError(std::string("Flag '") + n + "' requires an argument but received none");
+                if (i + 1 >= argc) throw ParseError("Error: flag '" + flag + "' requires an argument but received none");
                 return argv[++i];
             };
             if (flag == "h" || flag == "help") { print_help(argv[0]); return HELP; }
@@ -173,11 +185,11 @@ static ParsingResult parse_args(int argc, char **argv, Args &a) {
             else if (flag == "mean_q_weight") a.mean_q_weight = read_double("float", need("mean_q_weight"));
             else if (flag == "window_q_weight") a.window_q_weight = read_double("float", need("window_q_weight"));
             else if (flag == "split") { a.split = read_int_suffix("split", need("split")); a.split_set = true; }
-            else if (flag == "window_size") a.window_size = read_ll("int", need("window_size"));
-            else if (flag == "gpus") a.gpus = (int)read_ll("int", need("gpus"));
-            else throw ParseError("Flag could not be matched: " + flag);
+            else if (flag == "window_size") a.window_size = read_ll("int", need("window_size"), a.window_size);
+            else if (flag == "gpus") a.gpus = (int)read_ll("int", need("gpus"), a.gpus);
+            else throw ParseError("Error: flag could not be matched: " + flag);
         }
-        if (positional.size() > 1) throw ParseError("Passed in argument, but no positional arguments were ready to receive it: " + positional[1]);
+        if (positional.size() > 1) throw ParseError("Error: passed in argument, but no positional arguments were ready to receive it: " + positional[1]);
     } catch (const ParseError &e) {
         std::cerr << e.what() << "\n";
         return BAD;

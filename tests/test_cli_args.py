@@ -53,7 +53,7 @@ CASES = [
     (["-q", "0", "INPUT"], "Error: the value for --min_mean_q must be greater than 0"),
     (["--length_weight", "-1", "--target_bases", "5", "INPUT"], "received invalid value type"),
     (["--target_bases", "12x", "INPUT"], "received invalid value '12x'"),
-    (["--target_bases=100", "INPUT"], "Flag could not be matched"),
+    (["--target_bases=100", "INPUT"], "Error: flag could not be matched: target_bases=100"),
     # unit suffixes (reference test/test_unit_suffixes.py:157-209)
     (["--target_bases", "10xyz", "INPUT"], "invalid value"),
     (["--target_bases", "k", "INPUT"], "invalid value"),
@@ -78,3 +78,17 @@ def test_help_and_version():
     assert rc == 0 and "usage:" in err
     rc, out, err = run("--version")
     assert rc == 0 and out == b"Filtlong v0.3.1\n"
+
+
+def test_rejected_command_lines_match_the_reference_binary():
+    """tests/golden/arg_errors.json (make_arg_error_golden.py, from the reference binary): unknown flags, missing and malformed values,
+    the `--` terminator, the default reader's quirks (src/args.h:1609-1627: an empty value keeps the default, a number beyond long
+    long saturates), range checks and their order — same exit code, same stderr, nothing on stdout."""
+    import json
+    gold = json.load(open(os.path.join(_cases.GOLDEN, "arg_errors.json")))
+    assert len(gold) >= 80
+    for g in gold:
+        argv = [INPUT if a == "INPUT" else ASM if a == "ASSEMBLY" else a for a in g["argv"]]
+        p = subprocess.run([BIN] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd="/tmp", env=dict(os.environ, LANG="C", LC_ALL="C"))
+        err = p.stderr.decode(errors="replace").replace(INPUT, "INPUT").replace(ASM, "ASSEMBLY")
+        assert (p.returncode, len(p.stdout), err) == (g["rc"], g["stdout_len"], g["stderr"]), g["argv"]

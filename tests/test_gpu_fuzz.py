@@ -195,8 +195,9 @@ def make_case(seed):
     if rng.random() < 0.15:
         argv += ["--verbose"]
     if rng.random() < 0.2:  # the short forms, glued to their value or not (src/arguments.cpp:126-221)
-        short = {"--target_bases": "-t", "--keep_percent": "-p", "--min_length": "-l", "--max_length": "-L", "--min_mean_q": "-q",
-                 "--min_window_q": "-w"}
+        short = {"--target_bases": "-t", "--keep_percent": "-p", "--min_length": "-l", "--max_length": "-L", "--min_mean_q": "-q"}
+        if rng.random() < 0.1:
+            short["--min_window_q"] = "-w"  # (no such flag: "Error: flag could not be matched: 'w'")
         new = []
         for tok in argv:
             if new and new[-1] in short.values() and rng.random() < 0.5:
