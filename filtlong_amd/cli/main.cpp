@@ -33,6 +33,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -750,6 +751,18 @@ int main(int argc, char **argv) {
         print_read_blocks(res, n_scored);
     };
 
+    // A record that is a header and nothing else (no sequence, no '+' line; kseq returns it with length 0, src/kseq.h:206-213) prints
+    // oddly in the reference's FASTQ output: src/main.cpp:279 sends the C string seq->qual.s, and kseq has only reset that buffer's
+    // LENGTH — the quality string of the last record in front of it that had a '+' line comes out again.  With no such record the
+    // pointer is null, std::cout goes bad and nothing at all is written from there on.  Both are reproduced: the string to print
+    // is noted here, in file order; the stream's death is decided in the output pass (only a record that passes prints).
+    std::unordered_map<uint64_t, std::string> stale_qual;  // header-only record -> the quality string the reference prints for it
+    std::unordered_set<uint64_t> null_qual;                 // header-only records in front of the first '+' line
+    bool have_plus = false;
+    View last_plus_qual;            // quality of the last record with a '+' line in the current batch ...
+    std::string last_plus_stash;    // ... or, from an earlier block of a streamed input, a copy of it
+    bool last_plus_in_batch = false;
+
     for (;;) {
         Parsed batch_store;
         Parsed &batch = streamed ? batch_store : kept;
@@ -799,11 +812,23 @@ int main(int argc, char **argv) {
                 names.push_back(name);
                 units.note_record(blocks.points, blocks.offset_of(r.name.p - 1), n_records);
             }
+            if (r.is_fastq) {
+                have_plus = true;
+                last_plus_qual = r.qual;
+                last_plus_in_batch = true;
+            } else if (r.seq.empty()) {
+                if (!have_plus) null_qual.insert(n_records);
+                else stale_qual.emplace(n_records, last_plus_in_batch ? std::string(last_plus_qual.p, last_plus_qual.n) : last_plus_stash);
+            }
             ++n_records;
             if (total_bases - last_progress >= 483611) {
                 last_progress = total_bases;
                 if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)n_records) << " reads (" << int_to_string(total_bases) << " bp)";
             }
+        }
+        if (streamed && last_plus_in_batch) {  // the block's memory goes away
+            last_plus_stash.assign(last_plus_qual.p, last_plus_qual.n);
+            last_plus_in_batch = false;
         }
         if (batch.status == -2) {
             verbose_before_error(recs, recs.size(), streamed);
@@ -958,8 +983,18 @@ int main(int argc, char **argv) {
         sink = fopen(part_path.c_str(), "wb");
         if (!sink) { std::cerr << "Error: cannot write " << part_path << "\n"; return 1; }
     }
+    // the first passing header-only record without a quality string to repeat: the reference's std::cout dies behind its "+" line
+    uint64_t dies_at = UINT64_MAX;
+    if (fastq_output && !null_qual.empty())
+        for (uint64_t i = 0; i < n2 && dies_at == UINT64_MAX; ++i)
+            if (r2_pass[i] && !reads2[i].child && null_qual.count(reads2[i].rec)) dies_at = i;
+    auto repeated_qual = [&](uint64_t i) -> const std::string * {
+        if (stale_qual.empty() || reads2[i].child) return nullptr;
+        const auto it = stale_qual.find(reads2[i].rec);
+        return it == stale_qual.end() ? nullptr : &it->second;
+    };
     auto emit = [&](std::string &out, uint64_t i, const Record &r) {  // output read i of reads2, cut out of its record
-        if (!r2_pass[i]) return;
+        if (!r2_pass[i] || i > dies_at) return;
         const Out &o = reads2[i];
         if (o.child && o.end - o.start <= 0) return;
         out += fasta_output ? '>' : '@';
@@ -970,7 +1005,9 @@ int main(int argc, char **argv) {
         out += '\n';
         if (fastq_output) {
             out += "+\n";
-            out.append(r.qual.p + o.start, (size_t)(o.end - o.start));
+            if (i == dies_at) return;
+            if (const std::string *q = repeated_qual(i)) out += *q;
+            else out.append(r.qual.p + o.start, (size_t)(o.end - o.start));
             out += '\n';
         }
     };
@@ -984,7 +1021,15 @@ int main(int argc, char **argv) {
             if (o.child && o.end - o.start <= 0) return 0;
             const Record &r = kept.recs[o.rec];
             const uint64_t L = (uint64_t)(o.end - o.start);
-            return 1 + o.name.size() + (r.comment.empty() ? 0 : 1 + r.comment.n) + 1 + L + 1 + (fastq_output ? 2 + L + 1 : 0);
+            if (i > dies_at) return 0;
+            uint64_t b = 1 + o.name.size() + (r.comment.empty() ? 0 : 1 + r.comment.n) + 1 + L + 1;
+            if (fastq_output) {
+                b += 2;
+                if (i == dies_at) return b;
+                const std::string *q = repeated_qual(i);
+                b += (q ? q->size() : L) + 1;
+            }
+            return b;
         };
         std::vector<uint64_t> piece_first{0}, piece_at{0};  // reads2 range and byte offset of every piece
         {
@@ -1007,7 +1052,7 @@ int main(int argc, char **argv) {
         const char *map_lo = data.data(), *map_hi = data.data() + data.size();
         auto verbatim = [&](uint64_t i, const char *&from, size_t &len) -> bool {
             const Out &o = reads2[i];
-            if (o.child) return false;
+            if (o.child || i >= dies_at) return false;
             const Record &r = kept.recs[o.rec];
             const char *h = r.name.p - 1;
             if (h < map_lo || r.name.p + r.name.n >= map_hi || *h != (fasta_output ? '>' : '@')) return false;
@@ -1119,11 +1164,17 @@ int main(int argc, char **argv) {
     fflush(sink);
     if (world > 1) {
         fclose(sink);
-        uint64_t done = 1;  // every part is complete before rank 0 reads it
-        if (flx_comm_sum_u64(ctx, &done, 1) != FLX_OK) return fail_flx(ctx, "exchange");
+        // every part is complete before rank 0 reads it; a rank whose output "died" (above) ends the whole output
+        std::vector<uint64_t> done((size_t)world + 1, 0);
+        done[0] = 1;
+        done[(size_t)rank + 1] = dies_at != UINT64_MAX;
+        if (flx_comm_sum_u64(ctx, done.data(), done.size()) != FLX_OK) return fail_flx(ctx, "exchange");
         if (rank == 0) {
             std::vector<char> buf(1 << 22);
+            bool dead = false;
             for (int r = 0; r < world; ++r) {
+                if (dead) { unlink((g_part_prefix + ".part" + std::to_string(r)).c_str()); continue; }
+                dead = done[(size_t)r + 1] != 0;
                 const std::string pth = g_part_prefix + ".part" + std::to_string(r);
                 FILE *f = fopen(pth.c_str(), "rb");
                 if (!f) { std::cerr << "Error: cannot read " << pth << "\n"; return 1; }

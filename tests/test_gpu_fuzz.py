@@ -266,3 +266,53 @@ def test_random_invocations_match_the_reference_binary(tmp_path, part):
         seen["children"] += ref.stdout.count(b"-") > 0 and ("--trim" in case["argv"] or "--split" in case["argv"])
         seen["empty_out"] += len(ref.stdout) == 0
     assert seen["ok"] >= 20 and seen["error"] >= 1, seen
+
+
+def test_header_only_records_print_what_the_reference_prints(tmp_path):
+    """A record that is only a header (kseq: length 0, no '+' line) comes out of the reference's FASTQ writer with the quality string
+    of the last record in front of it that had a '+' line (src/main.cpp:279 prints kseq's buffer, of which only the length was
+    reset); with no such record std::cout goes bad and the output ends behind that record's "+" line.  Same bytes here, for every
+    way of reading the input."""
+    rng = random.Random(99)
+
+    def rec(i, L, wrap=0):
+        s, q = rand_bases(rng, L), bytes(rng.randrange(40, 90) for _ in range(L))
+        if wrap:
+            s = b"\n".join(s[a:a + wrap] for a in range(0, L, wrap))
+            q = b"\n".join(q[a:a + wrap] for a in range(0, L, wrap))
+        return b"@r%d\n" % i + s + b"\n+\n" + q + b"\n"
+
+    inputs = {
+        "middle": rec(0, 300) + rec(1, 500) + b"@lonely\n" + rec(2, 400) + rec(3, 200),
+        "at_eof_no_newline": rec(0, 300) + rec(1, 500) + b"@lonely",
+        "at_eof_comment": rec(0, 300) + rec(1, 500) + b"@lonely with a comment\n",
+        "two_in_a_row": rec(0, 300) + b"@l1\n@l2 c\n" + rec(1, 500) + b"@l3\n",
+        "behind_wrapped_record": rec(0, 300, wrap=70) + b"@lonely\n" + rec(1, 500),
+        "first_record": b"@lonely\n" + rec(0, 300) + rec(1, 500),
+        "first_and_later": b"@lonely\n" + rec(0, 300) + b"@later\n" + rec(1, 500),
+        "behind_empty_plus_record": rec(0, 300) + b"@e\n\n+\n\n" + b"@lonely\n" + rec(1, 200),
+        "fasta_header_in_fastq": rec(0, 300) + b">lonely\n" + rec(1, 200),
+    }
+    flag_sets = [["-t", "1000000"], ["-p", "90"], ["--min_mean_q", "1"], ["--min_length", "1", "-t", "100000"], ["-t", "600"]]
+    n = 0
+    for name, data in sorted(inputs.items()):
+        for flags in flag_sets:
+            for ingest in sorted(INGEST):
+                td = tmp_path / ("%s_%d" % (name, n))
+                td.mkdir()
+                case = {"files": {"reads.fastq": data}, "argv": flags + ["reads.fastq"]}
+                ref, new = run_both(case, str(td), INGEST[ingest])
+                what = (name, flags, ingest)
+                assert new.returncode == ref.returncode, (what, new.stderr[-300:], ref.stderr[-300:])
+                assert new.stdout == ref.stdout, (what, new.stdout[-80:], ref.stdout[-80:])
+                assert shown(new.stderr.decode(errors="replace")) == shown(ref.stderr.decode(errors="replace")), what
+                n += 1
+    # gzip input: the streamed reader, the header-only record and its predecessor in different blocks
+    data = b"".join(rec(i, 900) for i in range(12)) + b"@lonely\n" + b"".join(rec(i, 700) for i in range(12, 20)) + b"@last"
+    for block in ("1900", "7000", "100000"):
+        td = tmp_path / ("gz_%s" % block)
+        td.mkdir()
+        case = {"files": {"reads.fastq.gz": gzip.compress(data, 6, mtime=0)}, "argv": ["-t", "1000000", "reads.fastq.gz"]}
+        ref, new = run_both(case, str(td), {"FLX_CLI_BLOCK_BYTES": block, "FLX_CLI_SPAN_BYTES": "2500"})
+        assert new.returncode == ref.returncode == 0 and new.stdout == ref.stdout, block
+        assert b"@lonely\n\n+\n" in ref.stdout and ref.stdout.count(b"\n") == 4 * 22
