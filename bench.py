@@ -625,7 +625,7 @@ def main():
             except Exception as e:  # an extra must not cost the headline line
                 extras["end_to_end_cli"] = {"measured_in_this_run": False, "error": repr(e)}
             # the 20 GB and gzip runs are too long for the default bench: recorded by tools/bench_e2e_big.sh / bench_e2e_gz.sh
-            for key, path in (("end_to_end_cli_20GB_recorded", "r02_e2e_big.json"), ("end_to_end_cli_gzip_recorded", "r02_e2e_gz.json")):
+            for key, path in (("end_to_end_cli_20GB_recorded", "r03_e2e_big.json"), ("end_to_end_cli_gzip_recorded", "r03_e2e_gz.json")):
                 fp = os.path.join(ROOT, "profiles", path)
                 if os.path.exists(fp):
                     e = json.load(open(fp))

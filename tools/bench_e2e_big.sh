@@ -1,8 +1,9 @@
 #!/bin/bash
 # End to end on a FASTQ larger than 20 GB: filtlong-amd (streaming ingest) vs the reference binary, same box, same file.
-# usage: tools/bench_e2e_big.sh [n_reads=1000000]   -> gpurun_out/r02_e2e_big.json, gpurun_out/r02_e2e_big.log
+# usage: tools/bench_e2e_big.sh [n_reads=1000000] [prefix=r03]   -> gpurun_out/${PFX}_e2e_big.json, gpurun_out/${PFX}_e2e_big.log
 R=${GRAFT_REPO_ROOT:-$PWD}
 N=${1:-1000000}
+PFX=${2:-r03}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 export LANG=C LC_ALL=C
@@ -41,7 +42,7 @@ REF_S=$(python -c "print(($E - $S) / 1e9)")
 echo "reference: $REF_S s"
 if cmp /tmp/ref.out /tmp/amd.out; then IDENT=true; echo "stdout identical ($(stat -c %s /tmp/amd.out) bytes)"; else IDENT=false; echo "STDOUT DIFFERS"; fi
 grep -E "target|keeping" /tmp/ref.err /tmp/amd.err
-} > $OUT/r02_e2e_big.log 2>&1
+} > $OUT/${PFX}_e2e_big.log 2>&1
 ANON=$(tr '\r' '\n' < /tmp/amd.err | grep timing | sed -E 's/.*RssAnon +([0-9]+) MiB.*/\1/' | sort -n | tail -1)
 python - <<PY
 import json
@@ -50,7 +51,7 @@ json.dump({"reads": $N, "bases": $BASES, "fastq_bytes": $SIZE, "target_bases": $
            "speedup": ref / amd, "e2e_gbases_per_s": $BASES / amd / 1e9, "stdout_identical": "$IDENT" == "true",
            "peak_rss_anon_mib_at_stage_ends": int("$ANON" or 0),
            "note": "file -> stdout(file), page cache warm on the second run; the streamed H2D moves 1 byte per base over PCIe"},
-          open("$OUT/r02_e2e_big.json", "w"), indent=1)
+          open("$OUT/${PFX}_e2e_big.json", "w"), indent=1)
 PY
-cat $OUT/r02_e2e_big.log | tail -30; cat $OUT/r02_e2e_big.json
+cat $OUT/${PFX}_e2e_big.log | tail -30; cat $OUT/${PFX}_e2e_big.json
 rm -f /tmp/big.fastq /tmp/amd.out /tmp/ref.out
