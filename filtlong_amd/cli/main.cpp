@@ -779,7 +779,32 @@ int main(int argc, char **argv) {
         ++n_batches;
         const std::vector<Record> &recs = batch.recs;
         // the per-record checks of src/main.cpp:84-117, in file order, then the parser's own end status
-        if (!streamed) seen_names.reserve(recs.size() * 2);
+        // Duplicate names (src/main.cpp:113-117: the first record whose name an earlier record has).  Streamed input: a set, block
+        // after block.  Mapped input: every thread owns the names whose hash falls into its share, walks the records in file order and
+        // stops at the first name it has seen before; the smallest such record over all threads is the reference's.
+        uint64_t dup_at = UINT64_MAX;
+        if (!streamed && recs.size() > 1) {
+            const size_t nrec = recs.size();
+            std::vector<uint64_t> name_hash(nrec);
+            const size_t hparts = std::min<size_t>(nrec, 64);
+            parallel_for(hparts, [&](size_t k) {
+                for (size_t i = nrec * k / hparts; i < nrec * (k + 1) / hparts; ++i) {
+                    uint64_t h = 1469598103934665603ull;
+                    const View &v = recs[i].name;
+                    for (size_t q = 0; q < v.n; ++q) { h ^= (unsigned char)v.p[q]; h *= 1099511628211ull; }
+                    name_hash[i] = h ^ (h >> 29);
+                }
+            });
+            const size_t owners = std::max<size_t>(1, std::min<size_t>(host_threads(), nrec / 4096));
+            std::vector<uint64_t> first_dup(owners, UINT64_MAX);
+            parallel_for(owners, [&](size_t t) {
+                std::unordered_set<std::string_view> mine;
+                mine.reserve(nrec / owners * 2 + 16);
+                for (size_t i = 0; i < nrec; ++i)
+                    if (name_hash[i] % owners == t && !mine.insert(recs[i].name.sv()).second) { first_dup[t] = i; return; }
+            });
+            for (uint64_t d : first_dup) dup_at = std::min(dup_at, d);
+        }
         for (const Record &r : recs) {
             total_bases += (long long)r.seq.size();
             const bool fasta_format = r.qual.empty() && !r.seq.empty();
@@ -802,7 +827,7 @@ int main(int argc, char **argv) {
                 name_arena.emplace_back(name);
                 name = name_arena.back();
             }
-            if (!seen_names.insert(name).second) {
+            if (streamed ? !seen_names.insert(name).second : (uint64_t)(&r - recs.data()) == dup_at) {
                 if (streamed) names.push_back(name);  // the duplicate itself is scored and printed before the check (main.cpp:108-113)
                 verbose_before_error(recs, (uint64_t)(&r - recs.data()) + 1, streamed);
                 std::cerr << "Error: duplicate read name: " << r.name << "\n";
