@@ -21,7 +21,9 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
@@ -422,23 +424,36 @@ public:
         return (size_t)2 << 20;
     }
 
+    ParallelInflate() = default;
+    ParallelInflate(const ParallelInflate &) = delete;
+    ParallelInflate &operator=(const ParallelInflate &) = delete;
+    ~ParallelInflate() { shutdown(); }
+
     bool open(const unsigned char *data, size_t size, bool gz, unsigned threads) {
+        shutdown();
         data_ = data; size_ = size; threads_ = std::max(1u, threads);
-        serial_mode_ = true; member_done_ = false; error_ = false;
+        serial_mode_ = true; done_ = false; error_ = false;
         delivered_ = 0; queue_.clear(); pending_.clear();
+        shared_q_.clear(); shared_pts_.clear(); queued_bytes_ = 0; finished_ = false; stop_ = false;
+        stage_q_.clear(); stage_pts_.clear(); p_finished_ = false; p_error_ = false; p_handover_set_ = false;
         stream_out_ = 0; member_base_ = 0; bgzf_mode_ = false; bgzf_at_ = 0;
         parallel_bytes_ = 0; zlib_tail_bytes_ = 0; rounds_ = 0; dropped_chunks_ = 0;
         const char *off = getenv("FLX_CLI_PINFLATE");  // 0: zlib only; "nozlib": every chunk to its end with the marker decoder (tests)
         zlib_tails_ = !(off && strcmp(off, "nozlib") == 0);
+        if (const char *e = getenv("FLX_CLI_PINFLATE_AHEAD_MB")) max_ahead_ = (size_t)std::max(1, atoi(e)) << 20;
         if (gz && threads_ >= 2 && size >= min_bytes() && !(off && off[0] == '0')) {
             decoders_.resize(threads_);
             last_point_out_ = 0;
             begin_member(0);
-            return !error_;
+            if (p_error_) { error_ = true; return false; }
+            if (p_handover_set_) return take_over();  // nothing for the parallel paths: zlib from the first byte
+            serial_mode_ = false;
+            producer_ = std::thread([this] { produce(); });  // decodes ahead of read(), at most max_ahead_ bytes
+            return true;
         }
         return serial_.open(data, size, gz);
     }
-    bool eof() const { return queue_.empty() && (serial_mode_ ? serial_.eof() : member_done_); }
+    bool eof() const { return queue_.empty() && (serial_mode_ ? serial_.eof() : done_); }
     bool error() const { return error_ || (serial_mode_ && serial_.error()); }
     uint64_t total_out() const { return delivered_; }
     // diagnostics: bytes that came out of the parallel path (of those: from zlib running behind the marker decoder), rounds, chunks whose
@@ -453,6 +468,27 @@ public:
     size_t read(char *dst, size_t cap, std::vector<GzPoint> *points = nullptr, uint64_t span = 0) {
         size_t produced = 0;
         while (produced < cap && !error_) {
+            if (queue_.empty() && !serial_mode_ && !done_) {  // what the producer has ready; wait for it if that is nothing
+                bool fin;
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return !shared_q_.empty() || finished_; });
+                    for (Piece &pc : shared_q_) queue_.push_back(std::move(pc));
+                    for (GzPoint &pt : shared_pts_) pending_.push_back(std::move(pt));
+                    shared_q_.clear();
+                    shared_pts_.clear();
+                    queued_bytes_ = 0;
+                    fin = finished_;
+                }
+                cv_.notify_all();
+                if (queue_.empty() && fin) {  // the producer has left: the end, an error, or zlib's turn
+                    if (producer_.joinable()) producer_.join();
+                    if (p_error_) error_ = true;
+                    else if (p_handover_set_) take_over();
+                    else done_ = true;
+                }
+                continue;
+            }
             if (!queue_.empty()) {  // whole chunks to their places on all threads
                 struct Copy { const char *from; char *to; size_t n; };
                 std::vector<Copy> plan;
@@ -475,7 +511,10 @@ public:
                     pc.pos += m;
                     left -= m;
                     if (pc.pos >= pc.n) {
-                        if (pool_.size() < 2 * (size_t)threads_) pool_.push_back(std::move(pc.bytes));
+                        {
+                            std::lock_guard<std::mutex> g(pool_mutex_);
+                            if (pool_.size() < 3 * (size_t)threads_) pool_.push_back(std::move(pc.bytes));
+                        }
                         queue_.pop_front();
                     }
                 }
@@ -493,9 +532,7 @@ public:
                 produced += m; delivered_ += m;
                 break;  // (less than asked for only at the end or on an error)
             }
-            if (member_done_) break;
-            if (bgzf_mode_) bgzf_round();
-            else round();
+            break;  // done_
         }
         return produced;
     }
@@ -558,18 +595,15 @@ private:
     // large plain member goes to the chunked decoder, anything else to zlib for the rest of the file
     void begin_member(size_t at) {
         size_t hdr = 0, bsize = 0;
-        member_done_ = false;
         bgzf_at_ = 0;
         bgzf_mode_ = false;
         if (gzip_header(at, &hdr, &bsize)) {
             if (bsize > 0 && at + bsize <= size_) {
-                serial_mode_ = false;
                 bgzf_mode_ = true;
                 bgzf_at_ = at;
                 return;
             }
             if (size_ - at >= min_bytes() || at == 0) {
-                serial_mode_ = false;
                 chain_bit_ = (uint64_t)hdr * 8;
                 member_base_ = stream_out_;
                 member_out_ = 0;
@@ -582,8 +616,47 @@ private:
         pt.in = at;
         pt.out = stream_out_;
         pt.raw = false;
+        hand_over(pt);
+    }
+
+    // producer: zlib reads on from this point (done by the reading thread once it has taken everything decoded before it)
+    void hand_over(const GzPoint &pt) {
+        p_handover_ = pt;
+        p_handover_set_ = true;
+        p_finished_ = true;
+    }
+    // reader: the serial stream takes over where the producer stopped
+    bool take_over() {
         serial_mode_ = true;
-        if (at == 0 ? !serial_.open(data_, size_, true) : !serial_.open_at(data_, size_, true, pt)) error_ = true;
+        const GzPoint &pt = p_handover_;
+        const bool ok = (pt.in == 0 && !pt.raw) ? serial_.open(data_, size_, true) : serial_.open_at(data_, size_, true, pt);
+        if (!ok) error_ = true;
+        return ok;
+    }
+    // the producer thread: round after round, published to the reader, never more than max_ahead_ bytes in front of it
+    void produce() {
+        for (;;) {
+            if (!p_finished_) {
+                if (bgzf_mode_) bgzf_round();
+                else round();
+            }
+            std::unique_lock<std::mutex> lk(mu_);
+            for (Piece &pc : stage_q_) { queued_bytes_ += pc.n; shared_q_.push_back(std::move(pc)); }
+            for (GzPoint &pt : stage_pts_) shared_pts_.push_back(std::move(pt));
+            stage_q_.clear();
+            stage_pts_.clear();
+            if (p_finished_ || stop_) { finished_ = true; lk.unlock(); cv_.notify_all(); return; }
+            cv_.notify_all();
+            cv_.wait(lk, [&] { return queued_bytes_ <= max_ahead_ || stop_; });
+            if (stop_) { finished_ = true; lk.unlock(); cv_.notify_all(); return; }
+        }
+    }
+    void shutdown() {
+        if (producer_.joinable()) {
+            { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+            cv_.notify_all();
+            producer_.join();
+        }
     }
 
     // BGZF: up to threads x 128 blocks, every thread a run of neighbours through zlib (which checks each block's CRC-32 and size)
@@ -601,9 +674,9 @@ private:
             at += bsize;
         }
         if (mem.empty()) {
-            if (!more) { member_done_ = true; return; }
+            if (!more) { p_finished_ = true; return; }
             begin_member(at);  // a member of another kind
-            if (bgzf_mode_) { error_ = true; }  // (cannot happen: the loop above would have taken it)
+            if (bgzf_mode_) { p_error_ = true; p_finished_ = true; }  // (cannot happen: the loop above would have taken it)
             return;
         }
         const size_t runs = std::min<size_t>(threads_, mem.size());
@@ -639,9 +712,8 @@ private:
                 pt.in = mem[first[r]].at;
                 pt.out = stream_out_;
                 pt.raw = false;
-                serial_mode_ = true;
                 bgzf_mode_ = false;
-                if (!serial_.open_at(data_, size_, true, pt)) error_ = true;
+                hand_over(pt);
                 return;
             }
             if (stream_out_ > 0) {
@@ -649,11 +721,11 @@ private:
                 pt.in = mem[first[r]].at;
                 pt.out = stream_out_;
                 pt.raw = false;
-                pending_.push_back(std::move(pt));
+                stage_pts_.push_back(std::move(pt));
             }
             stream_out_ += pieces[r].n;
             parallel_bytes_ += pieces[r].n;
-            if (pieces[r].n > 0) queue_.push_back(std::move(pieces[r]));
+            if (pieces[r].n > 0) stage_q_.push_back(std::move(pieces[r]));
         }
         bgzf_at_ = at;
     }
@@ -829,7 +901,7 @@ private:
             size_t tail = 0, all = 0;
             for (size_t k : chain) { tail += ch[k].n - ch[k].n_sym; all += ch[k].n; }
             fprintf(stderr, "[pinflate] round %u: search %.3f  decode %.3f  chain %.3f  resolve+crc %.3f s, %zu of %zu chunks chained, %zu bytes (%zu by zlib)\n",
-                    rounds_, t1 - t0, t2 - t1, t3 - t2, now() - t3, chain.size(), n, all, tail);
+                    rounds_.load(), t1 - t0, t2 - t1, t3 - t2, now() - t3, chain.size(), n, all, tail);
         }
         // the symbol buffers go back to the decoders
         for (size_t k = 0; k < n; ++k)
@@ -844,7 +916,7 @@ private:
         for (size_t k = 0; k < chain.size(); ++k) {
             Chunk &c = ch[chain[k]];
             crc_ = crc32_combine(crc_, c.crc, (z_off_t)c.n);
-            if (member_base_ + c.out > 0) pending_.push_back(point_at(c.start, c.out, c.window));
+            if (member_base_ + c.out > 0) stage_pts_.push_back(point_at(c.start, c.out, c.window));
             parallel_bytes_ += c.n;
             stream_out_ += c.n;
             zlib_tail_bytes_ += c.n - c.n_sym;
@@ -852,13 +924,12 @@ private:
                 Piece pc;
                 pc.bytes = std::move(c.bytes);
                 pc.n = c.n;
-                queue_.push_back(std::move(pc));
+                stage_q_.push_back(std::move(pc));
             }
         }
         if (broken != (size_t)-1) {  // zlib continues from the start of the chunk that did not work out
             const Chunk &c = ch[broken];
-            serial_mode_ = true;
-            if (!serial_.open_at(data_, size_, true, point_at(c.start, c.out, c.window))) error_ = true;
+            hand_over(point_at(c.start, c.out, c.window));
             return;
         }
         const Chunk &last = ch[chain.back()];
@@ -892,20 +963,24 @@ private:
     }
 
     void finish_member(uint64_t end_bit) {
-        member_done_ = true;
+        p_finished_ = true;
         const size_t t = (size_t)((end_bit + 7) >> 3);
-        if (t + 8 > size_) { error_ = true; return; }
+        if (t + 8 > size_) { p_error_ = true; return; }
         auto le32 = [&](size_t p) { return (uint32_t)data_[p] | (uint32_t)data_[p + 1] << 8 | (uint32_t)data_[p + 2] << 16 | (uint32_t)data_[p + 3] << 24; };
-        if (le32(t) != (uint32_t)crc_ || le32(t + 4) != (uint32_t)member_out_) { error_ = true; return; }
+        if (le32(t) != (uint32_t)crc_ || le32(t + 4) != (uint32_t)member_out_) { p_error_ = true; return; }
         const size_t next = t + 8;
-        if (next + 2 <= size_ && data_[next] == 0x1f && data_[next + 1] == 0x8b) begin_member(next);  // like gzread: members follow each other
+        if (next + 2 <= size_ && data_[next] == 0x1f && data_[next + 1] == 0x8b) {  // like gzread: members follow each other
+            p_finished_ = false;
+            begin_member(next);
+        }
     }
 
     const unsigned char *data_ = nullptr;
     size_t size_ = 0;
     unsigned threads_ = 1;
     InflateStream serial_;
-    bool serial_mode_ = true, member_done_ = false, error_ = false, zlib_tails_ = true;
+    // the reading thread's side
+    bool serial_mode_ = true, done_ = false, error_ = false, zlib_tails_ = true;
     uint64_t delivered_ = 0;   // bytes handed to the caller
     uint64_t chain_bit_ = 0;   // where the next round starts
     uint64_t member_out_ = 0;  // bytes of the current member decoded so far
@@ -916,11 +991,24 @@ private:
     uLong crc_ = 0;
     std::string window_;       // the last 32 KiB decoded
     uint64_t last_point_out_ = 0;
-    std::deque<Piece> queue_;  // decoded chunks, in order, not yet read
-    std::vector<std::vector<char>> pool_;  // byte buffers to use again
-    std::mutex pool_mutex_;
+    std::deque<Piece> queue_;  // decoded chunks, in order, taken from the producer and not yet read
     std::deque<GzPoint> pending_;
+    std::vector<std::vector<char>> pool_;  // byte buffers to use again (both threads)
+    std::mutex pool_mutex_;
+    // between the two threads
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Piece> shared_q_;
+    std::deque<GzPoint> shared_pts_;
+    size_t queued_bytes_ = 0, max_ahead_ = (size_t)256 << 20;
+    bool finished_ = false, stop_ = false;
+    std::thread producer_;
+    // the producer's side: what a round made, and how it ended
+    std::deque<Piece> stage_q_;
+    std::deque<GzPoint> stage_pts_;
+    bool p_finished_ = false, p_error_ = false, p_handover_set_ = false;
+    GzPoint p_handover_;
     std::vector<pinflate::Decoder> decoders_;
-    uint64_t parallel_bytes_ = 0, zlib_tail_bytes_ = 0;
-    unsigned rounds_ = 0, dropped_chunks_ = 0;
+    std::atomic<uint64_t> parallel_bytes_{0}, zlib_tail_bytes_{0};
+    std::atomic<unsigned> rounds_{0}, dropped_chunks_{0};
 };
