@@ -221,7 +221,7 @@ def shown(err):
     return [l.split("\r")[-1] for l in err.split("\n")]
 
 
-def run_both(case, td, extra_env=None):
+def run_both(case, td, extra_env=None, new_argv_prefix=()):
     for name, data in case["files"].items():
         with open(os.path.join(td, name), "wb") as f:
             f.write(data)
@@ -232,7 +232,7 @@ def run_both(case, td, extra_env=None):
     env.update(extra_env or {})
     # gzip inputs and references (about one case in eight): through the block-parallel inflater, in chunks of a few hundred bytes
     env.update(FLX_CLI_PINFLATE_MIN="1", FLX_CLI_PINFLATE_CHUNK="300")
-    new = subprocess.run([BIN] + case["argv"], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    new = subprocess.run([BIN] + list(new_argv_prefix) + case["argv"], cwd=td, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     return ref, new
 
 
@@ -316,3 +316,28 @@ def test_header_only_records_print_what_the_reference_prints(tmp_path):
         ref, new = run_both(case, str(td), {"FLX_CLI_BLOCK_BYTES": block, "FLX_CLI_SPAN_BYTES": "2500"})
         assert new.returncode == ref.returncode == 0 and new.stdout == ref.stdout, block
         assert b"@lonely\n\n+\n" in ref.stdout and ref.stdout.count(b"\n") == 4 * 22
+
+
+def test_random_invocations_with_forked_ranks(tmp_path):
+    """The same kind of random command lines through `--gpus 2` / `--gpus 3` (ranks forked by the command line, the library's
+    communicator over tests/shim's loopback RCCL on one GPU): reads sharded by count, the global stage across ranks, part files
+    stitched by rank 0 — still the reference binary's exit code, stdout and stderr.  (--verbose is refused with several ranks.)"""
+    shim_dir = os.path.join(ROOT, "tests", "shim")
+    subprocess.check_call(["make", "-s", "-C", shim_dir])
+    env = {"FLX_RCCL_LIB": os.path.join(shim_dir, "libloopback_rccl.so"), "FLX_DEVICE": "0"}
+    n = 0
+    for i in range(0, N_CASES, 5):
+        case = make_case(zlib.crc32(SEED_BASE + b"-ranks-%d" % i))
+        if "--verbose" in case["argv"]:
+            continue
+        td = tmp_path / ("case%d" % i)
+        td.mkdir()
+        gpus = "2" if i % 10 == 0 else "3"
+        ref, new = run_both(case, str(td), env, ["--gpus", gpus])
+        what = (i, gpus, case["argv"], case["mode"], case["style"])
+        assert new.returncode == ref.returncode, (what, new.stderr.decode(errors="replace")[-600:], ref.stderr.decode(errors="replace")[-600:])
+        assert new.stdout == ref.stdout, (what, len(new.stdout), len(ref.stdout))
+        if b"usage:" not in ref.stderr:
+            assert shown(new.stderr.decode(errors="replace")) == shown(ref.stderr.decode(errors="replace")), what
+        n += 1
+    assert n >= 30
