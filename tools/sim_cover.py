@@ -2,7 +2,8 @@
 """Host-side model of the wave-level cover kernel's lookups (csrc/score_kmer.hip, k_kmer_cover_w) on the synthetic C3 reads:
 how many far requests (exact-membership lookups) and rounds a lane needs when ONE request answers G consecutive positions
 (G = 1: a bit per 16-mer; 2: the exact15 pair table; 4 / 5: wider groups), with groups at fixed alignment or floating (the
-request is placed so that its range ends at the asked position).  Pure numpy + a python loop over lanes: a design tool, not
+request is placed so that its range ends at the asked position); "+ locus": the members along the read's own locus in the assembly
+are known beforehand (not built) and only the candidates outside what they cover are asked.  Pure numpy + a python loop over lanes: a design tool, not
 part of the product or the tests.   usage: sim_cover.py [n_reads] [ref_len]"""
 import os
 import sys
@@ -37,7 +38,7 @@ p12[np.concatenate([kmers(rc, 12), kmers(rr, 12)]).astype(np.int64)] = True
 print("set %d 16-mers, 12-mer table %.1f %% full" % (len(members), 100 * p12.mean()))
 
 
-def simulate(cand, memb, G, floating, lcand_bet=True, per_side=1):
+def simulate(cand, memb, G, floating, lcand_bet=True, per_side=1, locus=False):
     """cand / memb: bool arrays over the positions of one read (position j = 16-mer ending at j).  Returns (requests, sum of
     per-wave rounds, lanes)."""
     n = len(cand)
@@ -53,6 +54,9 @@ def simulate(cand, memb, G, floating, lcand_bet=True, per_side=1):
         w = len(c)
         probed = ~c
         hits = np.zeros(w, dtype=bool)
+        if locus:  # members confirmed by comparing the read with the assembly along its locus: known before any request
+            hits = c & m
+            probed = probed | hits
         lcand, lhit = prev_cand15, prev_hit15
 
         def ask(pos, top):
@@ -72,7 +76,7 @@ def simulate(cand, memb, G, floating, lcand_bet=True, per_side=1):
         while True:
             H = np.nonzero(hits)[0]
             opn = np.nonzero(c & ~probed)[0]
-            have_left = lcand and lhit and not first
+            have_left = lcand and lhit and (locus or not first)
             if len(H) or have_left:
                 hi = H[-1] if len(H) else -1
                 lo_h = -1 if have_left else H[0]
@@ -120,8 +124,9 @@ for i in range(n_reads):
     positions += L
     for name, G, fl, ps in (("G1", 1, False, 1), ("G2 fixed (shipped)", 2, False, 1), ("G2 floating", 2, True, 1),
                             ("G4 fixed", 4, False, 1), ("G4 floating", 4, True, 1), ("G5 floating", 5, True, 1),
-                            ("G8 floating", 8, True, 1), ("G2 fixed, 2 per side", 2, False, 2)):
-        r, wr, nl = simulate(cand, memb, G, fl, per_side=ps)
+                            ("G8 floating", 8, True, 1), ("G2 fixed, 2 per side", 2, False, 2),
+                            ("G2 floating + locus", 2, True, 1)):
+        r, wr, nl = simulate(cand, memb, G, fl, per_side=ps, locus=name.endswith("locus"))
         t = tot.setdefault(name, [0, 0, 0])
         t[0] += r
         t[1] += wr
