@@ -44,7 +44,6 @@ struct BlockReader {
     size_t carry_from = 0;  // where the next window starts (set by next())
     uint64_t buf_offset = 0;  // uncompressed offset of buf[0]
     bool done = false, io_error = false;
-    unsigned n_parsed = 0, n_parsed_concurrently = 0;  // block windows parsed / of those by several threads (diagnostic)
     std::vector<GzPoint> points;  // access points for a concurrent second pass (the first is the beginning of the file)
     uint64_t span = 0;
     BlockReader() = default;
@@ -91,24 +90,17 @@ struct BlockReader {
             const bool eof = z.eof();
             view.p = buf.data() + view_from;
             view.n = have - view_from;
+            out.arenas.emplace_back();
+            Parser ps(view, out.arenas.back());
+            Record r;
             size_t consumed = view.n;
-            ++n_parsed;
-            if (parse_view_concurrently(eof, out, consumed)) {
-                ++n_parsed_concurrently;
-            } else {
-                out = Parsed();
-                out.arenas.emplace_back();
-                Parser ps(view, out.arenas.back());
-                Record r;
-                consumed = view.n;
-                for (;;) {
-                    const size_t header = ps.peek_header();
-                    const long long len = ps.next(r);
-                    if (!eof && ps.pos >= view.n) { consumed = std::min(header, view.n); break; }  // ran into the end of the block: unfinished
-                    if (len == -1) break;
-                    if (len == -2) { out.status = -2; out.bad = r; done = true; break; }
-                    out.recs.push_back(r);
-                }
+            for (;;) {
+                const size_t header = ps.peek_header();
+                const long long len = ps.next(r);
+                if (!eof && ps.pos >= view.n) { consumed = std::min(header, view.n); break; }  // ran into the end of the block: unfinished
+                if (len == -1) break;
+                if (len == -2) { out.status = -2; out.bad = r; done = true; break; }
+                out.recs.push_back(r);
             }
             if (out.recs.empty() && !done && !eof && consumed == 0) {  // one record fills the whole block
                 buf.resize((buf.size() - kHistory) * 2 + kHistory);
@@ -123,73 +115,6 @@ struct BlockReader {
 
 private:
     Input view;  // non-owning window on buf
-
-    // The block's window parsed by several threads, like parse_parallel (fastx.h): pieces that start at certain record starts and
-    // must end exactly at the next piece's start; the LAST piece follows the block's own rule (a record that reaches the end of a
-    // block which is not the end of the input is unfinished and carried over).  false: not accepted, the caller parses sequentially.
-    bool parse_view_concurrently(bool eof, Parsed &out, size_t &consumed) {
-        const unsigned t = host_threads();
-        size_t min_bytes = 32u << 20;
-        if (const char *e = getenv("FLX_CLI_PARALLEL_PARSE_MIN")) min_bytes = (size_t)atoll(e);  // tests force it on small blocks
-        if (t < 2 || view.n < min_bytes || view.n < t) return false;
-        std::vector<size_t> start(t + 1, view.n);
-        start[0] = 0;
-        size_t h0 = 0;
-        while (h0 < view.n && view.p[h0] != '>' && view.p[h0] != '@') ++h0;
-        const bool fastq = h0 < view.n && view.p[h0] == '@';
-        for (unsigned k = 1; k < t; ++k) {
-            start[k] = find_record_start(view, view.n / t * k, view.n / t * (k + 1), fastq);
-            if (start[k] >= view.n || start[k] <= start[k - 1]) return false;
-        }
-        struct Piece {
-            std::vector<Record> recs;
-            std::deque<std::string> arena;
-            bool ok = false, bad_record = false;
-            Record bad;
-            size_t consumed = 0;
-        };
-        std::vector<Piece> pieces(t);
-        parallel_for(t, [&](size_t k) {
-            Piece &c = pieces[k];
-            Parser ps(view, c.arena);
-            ps.pos = start[k];
-            Record r;
-            if (k + 1 < t) {
-                const size_t stop = start[k + 1];
-                for (;;) {
-                    const size_t h = ps.peek_header();
-                    if (h >= stop) { c.ok = (h == stop); return; }
-                    if (ps.next(r) < 0) { c.ok = false; return; }
-                    c.recs.push_back(r);
-                }
-            }
-            c.ok = true;
-            c.consumed = view.n;
-            for (;;) {
-                const size_t header = ps.peek_header();
-                const long long len = ps.next(r);
-                if (!eof && ps.pos >= view.n) { c.consumed = std::min(header, view.n); break; }
-                if (len == -1) break;
-                if (len == -2) { c.bad_record = true; c.bad = r; break; }
-                c.recs.push_back(r);
-            }
-        });
-        size_t total = 0;
-        for (const Piece &c : pieces) {
-            if (!c.ok) return false;
-            total += c.recs.size();
-        }
-        out = Parsed();
-        out.recs.reserve(total);
-        for (Piece &c : pieces) {
-            out.recs.insert(out.recs.end(), c.recs.begin(), c.recs.end());
-            out.arenas.push_back(std::move(c.arena));
-        }
-        const Piece &last = pieces[t - 1];
-        consumed = last.consumed;
-        if (last.bad_record) { out.status = -2; out.bad = last.bad; done = true; }
-        return true;
-    }
 };
 
 // The work units of the output pass over a streamed input: unit j is the text from the first record that starts at or

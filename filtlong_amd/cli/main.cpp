@@ -97,7 +97,6 @@ static int parse_only(const std::string &path, const char *mode) {
         if (rd.io_error) { std::cerr << "Error reading " << path << "\n"; return 1; }
         std::cerr << "inflate: " << rd.z.parallel_bytes() << " of " << rd.z.total_out() << " bytes from the parallel path (" << rd.z.zlib_tail_bytes() << " by zlib behind the marker decoder), " << rd.z.rounds()
                   << " round(s), " << rd.z.dropped_chunks() << " chunk(s) dropped\n";
-        std::cerr << "blocks: " << rd.n_parsed << " window(s) parsed, " << rd.n_parsed_concurrently << " by several threads\n";
         if (mode[0] == 'u' && parsed.status != -2) {
             // units: every piece between two access points (FLX_CLI_SPAN_BYTES apart) inflated and parsed on its own, on
             // several threads, as the output pass does; digest of the pieces in order

@@ -198,27 +198,3 @@ def test_access_point_units_on_fixture_gz():
         for span in (10000, 1 << 20):
             got, _ = digest(path, "unit", threads=8, block=1 << 16, span=span)
             assert got == seq, (name, span)
-
-
-def test_block_windows_are_parsed_by_several_threads(tmp_path):
-    """The streamed reader parses a block's window on several threads when it can cut it at certain record starts (the last piece
-    follows the block rule: a record that reaches the end of a block is carried over) — same records as the sequential parse, for
-    whole and truncated inputs, and the concurrent path is really taken."""
-    import gzip
-    rng = np.random.RandomState(77)
-    for style in ("plain", "crlf", "multiline", "mixedlen"):
-        data = random_fastq(rng, 3000, style)
-        for cut in (len(data), len(data) - 137, len(data) // 2 + 11):
-            path = str(tmp_path / ("w_%s_%d.fastq" % (style, cut)))
-            open(path, "wb").write(data[:cut])
-            seq, _ = digest(path, "seq")
-            for block, threads in ((60000, 3), (250000, 8), (1 << 22, 5)):
-                env = dict(os.environ, FLX_CLI_PARSE_ONLY="blk", FLX_CLI_PARALLEL_PARSE_MIN="1", FLX_CLI_THREADS=str(threads),
-                           FLX_CLI_BLOCK_BYTES=str(block), LANG="C", LC_ALL="C")
-                p = subprocess.run([BIN, "--target_bases", "1", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
-                assert p.returncode == 0, p.stderr.decode()
-                assert p.stdout.decode().strip().replace(" parallel 1 ", " parallel 0 ") == seq, (style, cut, block, threads)
-                line = [l for l in p.stderr.decode().split("\n") if l.startswith("blocks:")][0].split()
-                assert int(line[1]) >= 1
-                if style in ("plain", "crlf"):
-                    assert int(line[4]) >= 1, (style, cut, block, threads, line)
