@@ -144,8 +144,14 @@ static ParsingResult parse_args(int argc, char **argv, Args &a) {
             std::string tok = argv[i];
             std::string flag, value;
             bool have_value = false;
-            if (options_ended) {
+            // (the reference's parser reports a second positional where it meets it, before anything behind it: src/args.h:1437)
+            auto take_positional = [&]() {
+                if (!positional.empty())
+                    throw ParseError("Error: passed in argument, but no positional arguments were ready to receive it: " + tok);
                 positional.push_back(tok);
+            };
+            if (options_ended) {
+                take_positional();
                 continue;
             }
             if (tok == "--") {  // everything behind it is positional (src/args.h: the terminator)
@@ -160,7 +166,7 @@ static ParsingResult parse_args(int argc, char **argv, Args &a) {
                 static const char *shorts = "tplLqa12h";
                 if (!strchr(shorts, tok[1])) throw ParseError("Error: flag could not be matched: '" + std::string(1, tok[1]) + "'");
             } else {
-                positional.push_back(tok);
+                take_positional();
                 continue;
             }
             auto need = [&](const char *) -> std::string {
@@ -189,7 +195,6 @@ static ParsingResult parse_args(int argc, char **argv, Args &a) {
             else if (flag == "gpus") a.gpus = (int)read_ll("int", need("gpus"), a.gpus);
             else throw ParseError("Error: flag could not be matched: " + flag);
         }
-        if (positional.size() > 1) throw ParseError("Error: passed in argument, but no positional arguments were ready to receive it: " + positional[1]);
     } catch (const ParseError &e) {
         std::cerr << e.what() << "\n";
         return BAD;
