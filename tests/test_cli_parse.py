@@ -198,3 +198,52 @@ def test_access_point_units_on_fixture_gz():
         for span in (10000, 1 << 20):
             got, _ = digest(path, "unit", threads=8, block=1 << 16, span=span)
             assert got == seq, (name, span)
+
+
+def test_malformed_inputs_fail_like_the_reference_binary(tmp_path):
+    """Soups of records (Phred mode: nothing needs the GPU before the input has been parsed and checked): good records, FASTA records,
+    quality strings too short or too long, header-only records, wrapped records, records without a quality line, stray lines, CRLF,
+    cut anywhere, repeated names.  Whenever the reference binary (oracle/_ref/filtlong; skipped where it is not built) ends with an
+    error, this one ends with the same exit code, the same stderr as a terminal shows it, and nothing on stdout (src/main.cpp:76-117,
+    src/kseq.h:176-224).  Inputs the reference accepts are the business of tests/test_gpu_fuzz.py."""
+    import random
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "filtlong")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/filtlong not built (needs /root/reference)")
+    env = dict(os.environ, LANG="C", LC_ALL="C")
+    shown = lambda e: [l.split("\r")[-1] for l in e.decode(errors="replace").split("\n")]
+    path = str(tmp_path / "in.fastq")
+    compared = 0
+    for i in range(500):
+        rng = random.Random(zlib.crc32(b"soup-%d" % i))
+        lines = []
+        for _ in range(rng.randrange(1, 8)):
+            L = rng.choice([0, 1, 3, 10, 10, 10, 50])
+            s = bytes(rng.choice(b"ACGTN") for _ in range(L))
+            q = bytes(rng.randrange(33, 127) for _ in range(L))
+            kind = rng.random()
+            name = b"r%d" % rng.randrange(0, 6 if rng.random() < 0.2 else 1000)
+            if kind < 0.55: rec = [b"@" + name, s, b"+", q]
+            elif kind < 0.65: rec = [b">" + name, s]
+            elif kind < 0.72: rec = [b"@" + name, s, b"+", q[:max(0, L - rng.randrange(1, 3))]]
+            elif kind < 0.78: rec = [b"@" + name, s, b"+" + name, q + b"x" * rng.randrange(1, 3)]
+            elif kind < 0.84: rec = [b"@" + name]
+            elif kind < 0.9: rec = [b"@" + name, s[:L // 2], s[L // 2:], b"+", q[:L // 3], q[L // 3:]]
+            elif kind < 0.95: rec = [b"@" + name + b" c o m", s, b"+"]
+            else: rec = [rng.choice([b"", b"+", b"garbage", b"@", b">", b"\r"])]
+            lines += rec
+            if rng.random() < 0.1:
+                lines.insert(rng.randrange(len(lines) + 1), rng.choice([b"", b"\r", b" "]))
+        nl = b"\r\n" if rng.random() < 0.15 else b"\n"
+        data = nl.join(lines) + (nl if rng.random() < 0.8 else b"")
+        if rng.random() < 0.1 and len(data) > 3:
+            data = data[:rng.randrange(1, len(data))]
+        open(path, "wb").write(data)
+        argv = rng.choice([["-t", "1000"], ["-p", "50"], ["--min_length", "1"], ["-t", "5", "--min_mean_q", "10"]]) + [path]
+        r = subprocess.run([ref_bin] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if r.returncode == 0:
+            continue
+        n = subprocess.run([BIN] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert (n.returncode, n.stdout, shown(n.stderr)) == (r.returncode, r.stdout, shown(r.stderr)), (i, argv[:-1], data[:300])
+        compared += 1
+    assert compared >= 250
