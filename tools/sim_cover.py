@@ -105,7 +105,48 @@ def simulate(cand, memb, G, floating, lcand_bet=True, per_side=1, locus=False):
     return req, wave_rounds, n_lanes
 
 
+def simulate_known(cand, memb, known, G, floating):
+    """like simulate(..., locus=True) with only the members in `known` given beforehand: the rest of the members are found by requests"""
+    # members that are not known must still be asked for: model by running the plain policy on the read with the known members'
+    # positions answered for free — i.e. requests are only counted for lanes where some candidate is not a known member
+    req, wr, nl = 0, 0, 0
+    n = len(cand)
+    free = np.zeros(n, dtype=bool)
+    for lo in range(0, n, 1024):
+        hi = min(lo + 1024, n)
+        seg = slice(lo, hi)
+        if known[seg].any():
+            r, w, l = simulate(cand[seg], memb[seg], G, floating, locus=True)
+        else:
+            r, w, l = simulate(cand[seg], memb[seg], G, floating, locus=False)
+        req += r
+        wr += w
+        nl += l
+    return req, wr, nl
+
+
+def locus_mask(memb, K, span=1024):
+    """members known beforehand when every span of `span` positions looks for its own seed: the 16-mers ending at span_start + 15 +
+    16 j, j < K, are tried in turn (one far request each) and the first member among them places the span on its diagonal; a span
+    without a seed gets nothing.  (The synthetic reads are substitution-only, so a member IS on the read's diagonal.)  Returns the
+    mask and the number of seed requests."""
+    known = np.zeros(len(memb), dtype=bool)
+    tries = 0
+    for lo in range(0, len(memb), span):
+        hi = min(lo + span, len(memb))
+        for j in range(K):
+            p = lo + 15 + 16 * j
+            if p >= hi:
+                break
+            tries += 1
+            if memb[p]:
+                known[lo:hi] = memb[lo:hi]
+                break
+    return known, tries
+
+
 tot = {}
+seed_tries = {}
 positions = 0
 lens = synth.lengths(n_reads)
 for i in range(n_reads):
@@ -125,8 +166,15 @@ for i in range(n_reads):
     for name, G, fl, ps in (("G1", 1, False, 1), ("G2 fixed (shipped)", 2, False, 1), ("G2 floating", 2, True, 1),
                             ("G4 fixed", 4, False, 1), ("G4 floating", 4, True, 1), ("G5 floating", 5, True, 1),
                             ("G8 floating", 8, True, 1), ("G2 fixed, 2 per side", 2, False, 2),
-                            ("G2 floating + locus", 2, True, 1)):
-        r, wr, nl = simulate(cand, memb, G, fl, per_side=ps, locus=name.endswith("locus"))
+                            ("G2 floating + locus", 2, True, 1), ("G2 floating + locus, seeds per span K=4", 2, True, 1),
+                            ("G2 floating + locus, seeds per span K=8", 2, True, 1)):
+        if "K=" in name:
+            known, tries = locus_mask(memb, int(name.split("K=")[1]))
+            seed_tries[name] = seed_tries.get(name, 0) + tries
+            # what the kernel sees: candidates as before, but the known members are hits before any request
+            r, wr, nl = simulate(cand, memb, G, fl, per_side=ps, locus=True) if known.all() else simulate_known(cand, memb, known, G, fl)
+        else:
+            r, wr, nl = simulate(cand, memb, G, fl, per_side=ps, locus=name.endswith("locus"))
         t = tot.setdefault(name, [0, 0, 0])
         t[0] += r
         t[1] += wr
@@ -135,4 +183,6 @@ for i in range(n_reads):
         print("read 0: L %d, members %.3f, candidates %.3f" % (L, memb.mean(), cand.mean()))
 print("%d reads, %d positions" % (n_reads, positions))
 for name, (r, wr, nl) in tot.items():
-    print("%-24s far requests / position %.4f   rounds per wave-span %.2f" % (name, r / positions, wr / max(1, (nl + 63) // 64)))
+    extra = seed_tries.get(name, 0)
+    print("%-42s far requests / position %.4f%s   rounds per wave-span %.2f" % (
+        name, (r + extra) / positions, " (%.4f of them seeds)" % (extra / positions) if extra else "", wr / max(1, (nl + 63) // 64)))
