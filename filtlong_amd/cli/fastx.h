@@ -67,6 +67,10 @@ struct Input {
     void *map = nullptr;
     size_t map_len = 0;
     std::string owned;
+    // The bytes end where zlib's gzread reported a DATA ERROR to the reference's parser: kseq is then in its error state
+    // (src/kseq.h:47,71-76,105-108: every further read returns -3) — not at the end of the file.  The Parser below turns that into
+    // what kseq_read returns from there (a truncated stream is simply shorter: gzread delivers what it could decode, then EOF).
+    bool stream_error = false;
     Input() = default;
     Input(const Input &) = delete;
     Input &operator=(const Input &) = delete;
@@ -113,8 +117,12 @@ struct Input {
                             if (have == owned.size()) owned.resize(owned.size() * 2);
                             have += z.read(&owned[have], owned.size() - have);
                         }
-                        ok = !z.error();
-                        owned.resize(ok ? have : 0);
+                        ok = true;
+                        if (z.error()) {  // a damaged file: the bytes gzread would have delivered, then kseq's error state
+                            have = (size_t)std::min<uint64_t>(have, z.deliverable());
+                            stream_error = true;
+                        }
+                        owned.resize(have);
                     }
                 }
                 munmap(m, (size_t)st.st_size);
@@ -123,19 +131,20 @@ struct Input {
                     p = owned.data(); n = owned.size();
                     return true;
                 }
-                owned.clear();  // a damaged file: what gzread makes of it, below
+                owned.clear();
             }
         }
         ::close(fd);
+        // pipes and whatever could not be mapped: through gzread itself, in kseq's own calls (16 KiB, zlib's default buffer —
+        // src/kseq.h:234), so that a damaged stream ends for the parser exactly where it ends for the reference's
         gzFile fp = gzopen(path.c_str(), "r");  // transparent for uncompressed streams too
         if (!fp) return false;
-        gzbuffer(fp, 1 << 20);
-        std::vector<char> buf(1 << 22);
+        char buf[16384];
         for (;;) {
-            const int got = gzread(fp, buf.data(), (unsigned)buf.size());
-            if (got < 0) { gzclose(fp); return false; }
+            const int got = gzread(fp, buf, (unsigned)sizeof buf);
+            if (got < 0) { stream_error = true; break; }
             if (got == 0) break;
-            owned.append(buf.data(), (size_t)got);
+            owned.append(buf, (size_t)got);
         }
         gzclose(fp);
         p = owned.data(); n = owned.size();
@@ -177,6 +186,8 @@ struct Parser {
             v.p = arena.back().data();
             v.n = arena.back().size();
         }
+        // in kseq's error state ks_getuntil2 leaves with -3 in front of the strip (src/kseq.h:105-108): a line the error cut off keeps its '\r'
+        if (d.stream_error && pos >= d.size() && (d.size() == 0 || d.p[d.size() - 1] != '\n')) return;
         // kseq strips the '\r' at the end of ks_getuntil2 — which returns before that (-1) when the stream is at its end right
         // behind the line's first character, the one kseq_read consumed itself with ks_getc (src/kseq.h:141,188-190): a last
         // line that is a bare '\r' without a newline keeps it
@@ -193,25 +204,33 @@ struct Parser {
         while (pos < d.size() && d.p[pos] != '>' && d.p[pos] != '@') ++pos;
         return pos;
     }
-    // returns length >= 0, -1 at EOF, -2 on truncated / mismatching quality   (src/kseq.h:176-224)
+    // returns length >= 0, -1 at EOF, -2 on truncated / mismatching quality, -3 in the stream's error state   (src/kseq.h:176-224)
+    //
+    // d.stream_error: where the bytes end, gzread returned -1 and every ks_getc / ks_getuntil2 from there on returns -3 instead of
+    // "end of file" (src/kseq.h:71-76,105-108).  kseq_read only LOOKS at that in three places — the search for the header and the
+    // name return it, the '+' line compares with -1 only — so a record the error cuts off ends as: header search / name: -3;
+    // sequence: a FASTA-like record of what was read; behind the '+': -2 unless nothing is missing (or the record is empty).
     long long next(Record &r) {
         int c;
+        const long long at_end = d.stream_error ? -3 : -1;
         if (last_char == 0) {
             while ((c = getc()) >= 0 && c != '>' && c != '@') {}
-            if (c < 0) return -1;
+            if (c < 0) return at_end;
             last_char = c;
         }
         r = Record();
-        if (pos >= d.size()) return -1;
+        if (pos >= d.size()) return at_end;
         size_t e = pos;
         while (e < d.size() && !isspace((unsigned char)d.p[e])) ++e;  // the name ends at the first whitespace
         r.name.p = d.data() + pos;
         r.name.n = e - pos;
+        if (e >= d.size() && d.stream_error) return -3;  // ks_getuntil ran into the error before it found the delimiter
         c = e < d.size() ? (unsigned char)d.p[e] : -1;
         pos = e < d.size() ? e + 1 : e;
         if (c != '\n' && c >= 0) {
             rest_of_line(pos, r.comment);
-            if (r.comment.n > 1 && r.comment.p[r.comment.n - 1] == '\r') --r.comment.n;
+            const bool cut_off = d.stream_error && pos >= d.size() && d.p[d.size() - 1] != '\n';  // (-3 leaves ks_getuntil2 in front of the strip)
+            if (!cut_off && r.comment.n > 1 && r.comment.p[r.comment.n - 1] == '\r') --r.comment.n;
         }
         bool seq_owned = false, qual_owned = false;
         while ((c = getc()) >= 0 && c != '>' && c != '+' && c != '@') {
@@ -222,7 +241,7 @@ struct Parser {
         r.is_fastq = (c == '+');
         if (!r.is_fastq) { if (c < 0) last_char = 0; return (long long)r.seq.size(); }
         while ((c = getc()) >= 0 && c != '\n') {}
-        if (c == -1) return -2;
+        if (c == -1 && !d.stream_error) return -2;  // (ks_getc gives -3 in the error state, and kseq_read only compares with -1)
         for (;;) {
             if (pos >= d.size()) break;
             append_line(r.qual, qual_owned, pos, false);
@@ -238,7 +257,7 @@ struct Parser {
 struct Parsed {
     std::vector<Record> recs;
     std::deque<std::deque<std::string>> arenas;  // owners of the multi-line fields the records point into
-    long long status = -1;                       // -1: clean EOF, -2: the record `bad` is truncated / mismatching
+    long long status = -1;                       // -1: clean EOF, -2: the record `bad` is truncated / mismatching, -3: the stream's error state
     Record bad;
 };
 
@@ -288,7 +307,7 @@ static bool parse_parallel(const Input &d, Parsed &out) {
     const unsigned t = host_threads();
     size_t min_bytes = 32u << 20;
     if (const char *e = getenv("FLX_CLI_PARALLEL_PARSE_MIN")) min_bytes = (size_t)atoll(e);  // tests force it on small files
-    if (t < 2 || d.n < min_bytes || d.n < t) return false;
+    if (t < 2 || d.n < min_bytes || d.n < t || d.stream_error) return false;  // (a damaged stream: the sequential parser knows how kseq ends)
     std::vector<size_t> start(t + 1, d.n);
     start[0] = 0;
     size_t h0 = 0;  // the kind of the first record decides which lines can start a record

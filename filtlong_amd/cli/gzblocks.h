@@ -36,6 +36,11 @@ struct MappedFile {  // read-only mapping of a regular file (the compressed inpu
 
 struct BlockReader {
     static constexpr size_t kHistory = 32768;  // output kept in front of the write position: the window of an access point
+    // A damaged gzip stream ends for the reference's parser up to 32 KiB BEFORE the byte at which zlib notices the damage (gzread
+    // loses the whole 16 KiB call, inflate_stream.h: gzread_delivered_before_error).  So the last 32 KiB inflated are held back
+    // from the parser until more has been inflated behind them or the stream has ended: no record is ever handed out that the
+    // reference's kseq would not have seen whole.
+    static constexpr size_t kHoldback = 32768;
     MappedFile file;
     ParallelInflate z;  // pass 1 of a large gzip input on all host threads; zlib for everything else
     std::vector<char> buf;
@@ -44,6 +49,7 @@ struct BlockReader {
     size_t carry_from = 0;  // where the next window starts (set by next())
     uint64_t buf_offset = 0;  // uncompressed offset of buf[0]
     bool done = false, io_error = false;
+    bool stream_error = false;  // the stream ended in a data error: the last batch was parsed with kseq's error state behind its bytes
     std::vector<GzPoint> points;  // access points for a concurrent second pass (the first is the beginning of the file)
     uint64_t span = 0;
     BlockReader() = default;
@@ -60,7 +66,8 @@ struct BlockReader {
     }
     bool open(const std::string &path, bool want_points) {
         if (!file.open(path) || !z.open(file.p, file.n, file.gz(), ParallelInflate::default_threads(host_threads()))) return false;
-        buf.resize(block_bytes() + kHistory);
+        holdback = file.gz() ? kHoldback : 0;
+        buf.resize(block_bytes() + kHistory + holdback);
         span = want_points ? point_span() : 0;
         points.clear();
         if (want_points) points.emplace_back();
@@ -83,13 +90,21 @@ struct BlockReader {
             carry_from = 0;
         }
         for (;;) {
-            if (!z.eof() && have < buf.size()) {
+            if (!z.eof() && !z.error() && have < buf.size())
                 have += z.read(buf.data() + have, buf.size() - have, span ? &points : nullptr, span);
-                if (z.error()) { io_error = true; done = true; return false; }
+            bool eof = z.eof();
+            size_t released = eof ? have : (have > holdback ? have - holdback : 0);
+            if (z.error()) {  // the bytes gzread would have delivered, then kseq's error state (fastx.h: Input::stream_error)
+                const uint64_t d = z.deliverable();
+                released = d > buf_offset ? (size_t)std::min<uint64_t>(have, d - buf_offset) : 0;
+                have = std::max(released, view_from);
+                stream_error = true;
+                eof = true;
             }
-            const bool eof = z.eof();
+            released = std::max(released, view_from);
             view.p = buf.data() + view_from;
-            view.n = have - view_from;
+            view.n = released - view_from;
+            view.stream_error = stream_error;
             out.arenas.emplace_back();
             Parser ps(view, out.arenas.back());
             Record r;
@@ -99,11 +114,12 @@ struct BlockReader {
                 const long long len = ps.next(r);
                 if (!eof && ps.pos >= view.n) { consumed = std::min(header, view.n); break; }  // ran into the end of the block: unfinished
                 if (len == -1) break;
+                if (len == -3) { out.status = -3; done = true; break; }
                 if (len == -2) { out.status = -2; out.bad = r; done = true; break; }
                 out.recs.push_back(r);
             }
             if (out.recs.empty() && !done && !eof && consumed == 0) {  // one record fills the whole block
-                buf.resize((buf.size() - kHistory) * 2 + kHistory);
+                buf.resize((buf.size() - kHistory - holdback) * 2 + kHistory + holdback);
                 out = Parsed();
                 continue;
             }
@@ -114,6 +130,7 @@ struct BlockReader {
     }
 
 private:
+    size_t holdback = 0;
     Input view;  // non-owning window on buf
 };
 

@@ -92,12 +92,12 @@ static int parse_only(const std::string &path, const char *mode) {
         while (rd.next(parsed)) {
             mix_all(parsed);
             for (const Record &r : parsed.recs) idx.note_record(rd.points, rd.offset_of(r.name.p - 1), n_records++);
-            if (parsed.status == -2) break;
+            if (parsed.status <= -2) break;
         }
         if (rd.io_error) { std::cerr << "Error reading " << path << "\n"; return 1; }
         std::cerr << "inflate: " << rd.z.parallel_bytes() << " of " << rd.z.total_out() << " bytes from the parallel path (" << rd.z.zlib_tail_bytes() << " by zlib behind the marker decoder), " << rd.z.rounds()
                   << " round(s), " << rd.z.dropped_chunks() << " chunk(s) dropped\n";
-        if (mode[0] == 'u' && parsed.status != -2) {
+        if (mode[0] == 'u' && parsed.status > -2) {
             // units: every piece between two access points (FLX_CLI_SPAN_BYTES apart) inflated and parsed on its own, on
             // several threads, as the output pass does; digest of the pieces in order
             idx.finish(rd.points, rd.end_offset(), n_records);
@@ -303,7 +303,8 @@ struct Job {
     }
     void remove_dir() {
         if (dir.empty()) return;
-        for (size_t r = 0; r <= children.size(); ++r) unlink((dir + "/out.part" + std::to_string(r)).c_str());
+        for (size_t r = 0; r <= children.size(); ++r)
+            for (const char *kind : {"part", "vblocks", "vtable"}) unlink((dir + "/out." + kind + std::to_string(r)).c_str());
         rmdir(dir.c_str());
         dir.clear();
     }
@@ -433,7 +434,6 @@ int main(int argc, char **argv) {
     }
     JobGuard job_guard;  // rank 0 of --gpus: whatever way main() is left, no child and no part file stays behind
     if (g_rank < 0 || g_rank >= g_world) { std::cerr << "Error: RANK " << g_rank << " outside WORLD_SIZE " << g_world << "\n"; return 1; }
-    if (g_world > 1 && args.verbose) { std::cerr << "Error: --verbose is not available with more than one GPU\n"; return 1; }
     if (g_rank > 0) {  // rank 0 speaks for the job
         if (!freopen("/dev/null", "w", stderr)) return 1;
         if (!freopen("/dev/null", "w", stdout)) return 1;
@@ -695,15 +695,15 @@ int main(int argc, char **argv) {
     };
 
     // Read::print_verbose_read_info for reads [0, n_first) (src/read.cpp:169-194), in file order like the pass-1 loop (main.cpp:110-111)
-    auto print_read_blocks = [&](const flx_scores &res, uint64_t n_first) {
+    auto print_read_blocks = [&](std::ostream &os, const flx_scores &res, uint64_t n_first) {
         const double *mean_q = res.mean_q, *window_q = res.window_q, *c_mean = res.child_mean_q, *c_window = res.child_window_q;
         const int32_t *c_ranges = res.child_ranges;
         const uint64_t *child_off = res.child_offsets;
         const uint64_t n = n_first;
         for (uint64_t i = 0; i < n; ++i) {
             const std::string_view rname = names[i];
-            std::cerr << "\n" << rname << "\n";
-            std::cerr << "            length = " << pad(std::to_string(lengths[i]), 11) << "mean quality = " << double_to_string(mean_q[i])
+            os << "\n" << rname << "\n";
+            os << "            length = " << pad(std::to_string(lengths[i]), 11) << "mean quality = " << double_to_string(mean_q[i])
                       << "      window quality = " << double_to_string(window_q[i]) << "\n";
             const uint64_t a = child_off[i], b = child_off[i + 1];
             // m_bad_ranges (read.cpp:86-117): disjoint, non-adjacent and sorted, so with children they are exactly the gaps the
@@ -721,17 +721,17 @@ int main(int argc, char **argv) {
                 bad.push_back({0, lengths[i]});
             }
             if (!bad.empty()) {
-                std::cerr << "        bad ranges = ";
-                for (size_t k = 0; k < bad.size(); ++k) std::cerr << bad[k].first << "-" << bad[k].second << (k + 1 < bad.size() ? ", " : "");
-                std::cerr << "\n";
+                os << "        bad ranges = ";
+                for (size_t k = 0; k < bad.size(); ++k) os << bad[k].first << "-" << bad[k].second << (k + 1 < bad.size() ? ", " : "");
+                os << "\n";
             }
             if (a != b) {
-                std::cerr << "      child ranges = ";
-                for (uint64_t k = a; k < b; ++k) std::cerr << c_ranges[2 * k] << "-" << c_ranges[2 * k + 1] << (k + 1 < b ? ", " : "");
-                std::cerr << "\n";
+                os << "      child ranges = ";
+                for (uint64_t k = a; k < b; ++k) os << c_ranges[2 * k] << "-" << c_ranges[2 * k + 1] << (k + 1 < b ? ", " : "");
+                os << "\n";
                 for (uint64_t k = a; k < b; ++k) {
-                    std::cerr << "\n" << rname << "_" << c_ranges[2 * k] + 1 << "-" << c_ranges[2 * k + 1] << "\n";
-                    std::cerr << "            length = " << pad(std::to_string(c_ranges[2 * k + 1] - c_ranges[2 * k]), 11) << "mean quality = "
+                    os << "\n" << rname << "_" << c_ranges[2 * k] + 1 << "-" << c_ranges[2 * k + 1] << "\n";
+                    os << "            length = " << pad(std::to_string(c_ranges[2 * k + 1] - c_ranges[2 * k]), 11) << "mean quality = "
                               << double_to_string(c_mean[k]) << "      window quality = " << double_to_string(c_window[k]) << "\n";
                 }
             }
@@ -741,14 +741,14 @@ int main(int argc, char **argv) {
     // front of the failing record (for a duplicate name: that record's too) are on stderr before the error line
     // (src/main.cpp:108-117).  Scoring is batched here: the reads read so far are scored now, then their blocks printed.
     auto verbose_before_error = [&](const std::vector<Record> &recs, uint64_t k, bool streamed_names) -> void {
-        if (!args.verbose || g_world > 1) return;
+        if (!args.verbose || g_rank > 0) return;  // (several ranks: rank 0 alone scores the reads in front of the error — no exchange is involved)
         if (!streamed_names) for (uint64_t i = 0; i < k; ++i) names.push_back(recs[i].name.sv());
         if (score_records(recs, 0, k) != 0) return;
         if (!pipe && flx_pipeline_create(ctx, kmers_empty ? nullptr : kmers, &prm, chunk_bytes, chunk_reads, &pipe) != FLX_OK) return;
         flx_scores res;
         uint64_t n_scored = 0;
         if (flx_pipeline_finish(pipe, &res, &n_scored) != FLX_OK || n_scored != lengths.size()) return;
-        print_read_blocks(res, n_scored);
+        print_read_blocks(std::cerr, res, n_scored);
     };
 
     // A record that is a header and nothing else (no sequence, no '+' line; kseq returns it with length 0, src/kseq.h:206-213) prints
@@ -763,12 +763,16 @@ int main(int argc, char **argv) {
     std::string last_plus_stash;    // ... or, from an earlier block of a streamed input, a copy of it
     bool last_plus_in_batch = false;
 
+    // An error of the INPUT is found by every rank at the same record (all of them index the whole file): rank 0 reports it and
+    // ends the job; the others leave quietly with status 0, so that the watchdog does not take their exit for a rank that died
+    // while rank 0 is still scoring and printing the --verbose blocks in front of the error.
+    const int input_error_rc = g_rank > 0 ? 0 : 1;
     for (;;) {
         Parsed batch_store;
         Parsed &batch = streamed ? batch_store : kept;
         if (streamed) {
             if (!blocks.next(batch)) {
-                if (blocks.io_error) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
+                if (blocks.io_error) { std::cerr << "Error reading " << args.input_reads << "\n"; return input_error_rc; }
                 break;
             }
         } else {
@@ -815,12 +819,12 @@ int main(int argc, char **argv) {
                 verbose_before_error(recs, (uint64_t)(&r - recs.data()), streamed);
                 std::cerr << "\n\n" << "Error: could not parse input reads" << "\n";
                 std::cerr << "  problem occurred at read " << r.name << "\n";
-                return 1;
+                return input_error_rc;
             }
             if (fasta_format && kmers_empty) {
                 verbose_before_error(recs, (uint64_t)(&r - recs.data()), streamed);
                 std::cerr << "\n\n" << "Error: FASTA input not supported without an external reference" << "\n";
-                return 1;
+                return input_error_rc;
             }
             std::string_view name = r.name.sv();
             if (streamed) {  // the block's memory is reused: keep a copy
@@ -831,7 +835,7 @@ int main(int argc, char **argv) {
                 if (streamed) names.push_back(name);  // the duplicate itself is scored and printed before the check (main.cpp:108-113)
                 verbose_before_error(recs, (uint64_t)(&r - recs.data()) + 1, streamed);
                 std::cerr << "Error: duplicate read name: " << r.name << "\n";
-                return 1;
+                return input_error_rc;
             }
             if (streamed) {
                 names.push_back(name);
@@ -858,7 +862,12 @@ int main(int argc, char **argv) {
         if (batch.status == -2) {
             verbose_before_error(recs, recs.size(), streamed);
             std::cerr << "Error: incorrect FASTQ format for read " << batch.bad.name << "\n";
-            return 1;
+            return input_error_rc;
+        }
+        if (batch.status == -3) {  // a damaged gzip stream: kseq's error state behind the bytes gzread delivered (src/main.cpp:85-88)
+            verbose_before_error(recs, recs.size(), streamed);
+            std::cerr << "Error reading " << args.input_reads << "\n";
+            return input_error_rc;
         }
         if (!streamed) stage("record checks");
         // this rank's share of the batch: everything when streaming (one rank), else a contiguous block of file order by count
@@ -919,9 +928,33 @@ int main(int argc, char **argv) {
     size_t longest_name = 0;
     for (auto &o : reads2) longest_name = std::max(longest_name, o.name.size());
 
-    if (args.verbose) {  // Read::print_verbose_read_info, src/read.cpp:169-194, in file order like the pass-1 loop (main.cpp:110-111)
-        print_read_blocks(res, n);
-        std::cerr << "\n";  // the line main.cpp:129 prints after the loop
+    // Read::print_verbose_read_info, src/read.cpp:169-194, in file order like the pass-1 loop (main.cpp:110-111).  Several ranks:
+    // rank r > 0 leaves the blocks of its reads in a file of the job's private directory; rank 0 prints its own and, behind the
+    // exchange of the totals below (every rank has written its file when that returns), the others' in rank = file order.
+    auto verbose_part = [&](const char *kind, int r) { return g_part_prefix + "." + kind + std::to_string(r); };
+    auto print_verbose_parts = [&](const char *kind) -> bool {
+        std::vector<char> vbuf(1 << 20);
+        for (int r = 1; r < world; ++r) {
+            const std::string pth = verbose_part(kind, r);
+            FILE *f = fopen(pth.c_str(), "rb");
+            if (!f) { std::cerr << "Error: cannot read " << pth << "\n"; return false; }
+            size_t got;
+            while ((got = fread(vbuf.data(), 1, vbuf.size(), f)) > 0) std::cerr.write(vbuf.data(), (std::streamsize)got);
+            fclose(f);
+            unlink(pth.c_str());
+        }
+        return true;
+    };
+    if (args.verbose) {
+        if (rank == 0) {
+            print_read_blocks(std::cerr, res, n);
+        } else {
+            std::ofstream f(verbose_part("vblocks", rank), std::ios::binary);
+            print_read_blocks(f, res, n);
+            f.close();
+            if (!f) return fail_flx(ctx, "verbose part");
+        }
+        if (world == 1) std::cerr << "\n";  // the line main.cpp:129 prints after the loop
     }
 
     // totals over all ranks (one rank: the local values)
@@ -932,13 +965,18 @@ int main(int argc, char **argv) {
     uint64_t n2_total = n2_local;
     long long after_total = after_local;
     if (world > 1) {
-        std::vector<uint64_t> sums((size_t)world + 1, 0);
+        std::vector<uint64_t> sums(2 * (size_t)world + 1, 0);
         sums[rank] = n2_local;
         sums[world] = (uint64_t)after_local;
+        sums[(size_t)world + 1 + rank] = longest_name;  // (the --verbose table pads every name to the longest of ALL reads2, main.cpp:199-201)
         if (flx_comm_sum_u64(ctx, sums.data(), sums.size()) != FLX_OK) return fail_flx(ctx, "exchange");
         n2_total = 0;
-        for (int r = 0; r < world; ++r) { n2_of[r] = sums[r]; n2_total += sums[r]; }
+        for (int r = 0; r < world; ++r) { n2_of[r] = sums[r]; n2_total += sums[r]; longest_name = std::max<size_t>(longest_name, sums[(size_t)world + 1 + r]); }
         after_total = (long long)sums[world];
+        if (args.verbose && rank == 0) {
+            if (!print_verbose_parts("vblocks")) return 1;
+            std::cerr << "\n";
+        }
     }
     if ((args.trim || args.split_set) && rank == 0) {  // src/main.cpp:155-166
         if (args.trim && args.split_set) std::cerr << "  after trimming and splitting: ";
@@ -964,8 +1002,12 @@ int main(int argc, char **argv) {
         if (rc != FLX_OK) return fail_flx(ctx, "rank and cut");
     }
     if (args.verbose) {  // src/main.cpp:199-214: the table shows the NORMALISED qualities and the final score, host libm like the reference
-        std::cerr << "\n\n" << "Read name" << "\t" << "Length score" << "\t" << "Mean quality score" << "\t" << "Window quality score"
-                  << "\t" << "Final score" << "\n";
+        std::ofstream table_file;
+        if (rank > 0) table_file.open(verbose_part("vtable", rank), std::ios::binary);
+        std::ostream &tos = rank > 0 ? (std::ostream &)table_file : (std::ostream &)std::cerr;
+        if (rank == 0)
+            std::cerr << "\n\n" << "Read name" << "\t" << "Length score" << "\t" << "Mean quality score" << "\t" << "Window quality score"
+                      << "\t" << "Final score" << "\n";
         const double zspan = rep.max_z - rep.min_z;
         double (*volatile powfn)(double, double) = pow;
         for (uint64_t i = 0; i < n2; ++i) {
@@ -982,10 +1024,16 @@ int main(int argc, char **argv) {
             if (mq > 0.0) scale = std::min(wq / mq, 1.0);
             const double wfrac = args.window_q_weight / (args.length_weight + args.mean_q_weight + args.window_q_weight);
             const double fs = gm * ((1.0 - wfrac) + (scale * wfrac));
-            std::cerr << pad(reads2[i].name, longest_name) << "\t" << double_to_string(lscore) << "\t" << double_to_string(mq) << "\t"
-                      << double_to_string(wq) << "\t" << double_to_string(fs) << "\n";
+            tos << pad(reads2[i].name, longest_name) << "\t" << double_to_string(lscore) << "\t" << double_to_string(mq) << "\t"
+                << double_to_string(wq) << "\t" << double_to_string(fs) << "\n";
         }
-        std::cerr << "\n";
+        if (world > 1) {  // every rank's rows are in its file when this exchange returns; rank 0 prints them in rank = file order
+            if (rank > 0) { table_file.close(); if (!table_file) return fail_flx(ctx, "verbose part"); }
+            uint64_t one = 1;
+            if (flx_comm_sum_u64(ctx, &one, 1) != FLX_OK) return fail_flx(ctx, "exchange");
+            if (rank == 0 && !print_verbose_parts("vtable")) return 1;
+        }
+        if (rank == 0) std::cerr << "\n";
     }
     if (cutting && rank == 0) {
         std::cerr << "Filtering long reads\n";

@@ -396,13 +396,19 @@ static bool find_block_start(Decoder &d, uint64_t from, uint64_t to, uint64_t *s
     return false;
 }
 
+// false: a worker threw (an allocation that failed): the caller leaves the job to zlib instead of ending the process
 template <class F>
-static void run_parallel(size_t n, unsigned threads, F &&body) {
-    if (n <= 1 || threads <= 1) { for (size_t i = 0; i < n; ++i) body(i); return; }
+static bool run_parallel(size_t n, unsigned threads, F &&body) {
+    std::atomic<bool> ok{true};
+    auto guarded = [&](size_t i) {
+        try { body(i); } catch (...) { ok = false; }
+    };
+    if (n <= 1 || threads <= 1) { for (size_t i = 0; i < n; ++i) guarded(i); return ok; }
     std::vector<std::thread> th;
     const unsigned t = (unsigned)std::min<size_t>(threads, n);
-    for (unsigned k = 0; k < t; ++k) th.emplace_back([&, k] { for (size_t i = k; i < n; i += t) body(i); });
+    for (unsigned k = 0; k < t; ++k) th.emplace_back([&, k] { for (size_t i = k; i < n; i += t) guarded(i); });
     for (auto &x : th) x.join();
+    return ok;
 }
 
 }  // namespace pinflate
@@ -435,7 +441,7 @@ public:
         serial_mode_ = true; done_ = false; error_ = false;
         delivered_ = 0; queue_.clear(); pending_.clear();
         shared_q_.clear(); shared_pts_.clear(); queued_bytes_ = 0; finished_ = false; stop_ = false;
-        stage_q_.clear(); stage_pts_.clear(); p_finished_ = false; p_error_ = false; p_handover_set_ = false;
+        stage_q_.clear(); stage_pts_.clear(); p_finished_ = false; p_error_ = false; p_handover_set_ = false; p_deliverable_ = 0;
         stream_out_ = 0; member_base_ = 0; bgzf_mode_ = false; bgzf_at_ = 0;
         parallel_bytes_ = 0; zlib_tail_bytes_ = 0; rounds_ = 0; dropped_chunks_ = 0;
         const char *off = getenv("FLX_CLI_PINFLATE");  // 0: zlib only; "nozlib": every chunk to its end with the marker decoder (tests)
@@ -455,6 +461,10 @@ public:
     }
     bool eof() const { return queue_.empty() && (serial_mode_ ? serial_.eof() : done_); }
     bool error() const { return error_ || (serial_mode_ && serial_.error()); }
+    // after error(): how many bytes of the stream zlib's gzread would have handed to the reference's parser before its error
+    // state (inflate_stream.h: gzread_delivered_before_error) — up to 32 KiB fewer than read() has produced.  A stream that is
+    // merely TRUNCATED is no error: everything decodable comes out, then eof(), like gzread.
+    uint64_t deliverable() const { return serial_mode_ && serial_.error() ? serial_.deliverable() : p_deliverable_; }
     uint64_t total_out() const { return delivered_; }
     // diagnostics: bytes that came out of the parallel path (of those: from zlib running behind the marker decoder), rounds, chunks whose
     // work was dropped
@@ -637,8 +647,35 @@ private:
     void produce() {
         for (;;) {
             if (!p_finished_) {
-                if (bgzf_mode_) bgzf_round();
-                else round();
+                // a round that cannot get its memory (std::bad_alloc out of a vector) must not end the process: what it staged is
+                // dropped, the few words of state it advanced are put back, and zlib reads on alone from where the round began
+                const uint64_t chain_bit0 = chain_bit_, member_out0 = member_out_, stream_out0 = stream_out_;
+                const uLong crc0 = crc_;
+                const size_t bgzf_at0 = bgzf_at_;
+                const bool bgzf0 = bgzf_mode_;
+                const std::string window0 = window_;
+                const size_t staged_q = stage_q_.size(), staged_p = stage_pts_.size();
+                bool threw = false;
+                try {
+                    if (bgzf_mode_) bgzf_round();
+                    else if (!round()) threw = true;
+                } catch (...) { threw = true; }
+                if (threw) {
+                    stage_q_.resize(staged_q);
+                    stage_pts_.resize(staged_p);
+                    chain_bit_ = chain_bit0; member_out_ = member_out0; stream_out_ = stream_out0; crc_ = crc0; window_ = window0;
+                    p_error_ = false;
+                    if (bgzf0) {
+                        GzPoint pt;
+                        pt.in = bgzf_at0;
+                        pt.out = stream_out0;
+                        pt.raw = false;
+                        bgzf_mode_ = false;
+                        hand_over(pt);
+                    } else {
+                        hand_over(point_at(chain_bit0, member_out0, window0, true));
+                    }
+                }
             }
             std::unique_lock<std::mutex> lk(mu_);
             for (Piece &pc : stage_q_) { queued_bytes_ += pc.n; shared_q_.push_back(std::move(pc)); }
@@ -664,16 +701,27 @@ private:
         struct Member { size_t at, size; uint32_t isize; };
         std::vector<Member> mem;
         size_t at = bgzf_at_;
-        bool more = true;
+        bool more = true, forged = false;
         while (mem.size() < (size_t)threads_ * 128) {
             size_t hdr = 0, bsize = 0;
             if (at + 2 > size_ || data_[at] != 0x1f || data_[at + 1] != 0x8b) { more = false; break; }  // the end of the file (or not a member)
             if (!gzip_header(at, &hdr, &bsize) || bsize == 0 || at + bsize > size_ || bsize < hdr - at + 8) break;  // not BGZF: decided below
             const size_t t = at + bsize - 4;
-            mem.push_back({at, bsize, (uint32_t)data_[t] | (uint32_t)data_[t + 1] << 8 | (uint32_t)data_[t + 2] << 16 | (uint32_t)data_[t + 3] << 24});
+            const uint32_t isize = (uint32_t)data_[t] | (uint32_t)data_[t + 1] << 8 | (uint32_t)data_[t + 2] << 16 | (uint32_t)data_[t + 3] << 24;
+            if (isize > 65536) { forged = true; break; }  // a BGZF block holds at most 64 KiB (SAM spec 4.1): not one, or damaged — zlib's
+            mem.push_back({at, bsize, isize});
             at += bsize;
         }
         if (mem.empty()) {
+            if (forged) {
+                GzPoint pt;
+                pt.in = at;
+                pt.out = stream_out_;
+                pt.raw = false;
+                bgzf_mode_ = false;
+                hand_over(pt);
+                return;
+            }
             if (!more) { p_finished_ = true; return; }
             begin_member(at);  // a member of another kind
             if (bgzf_mode_) { p_error_ = true; p_finished_ = true; }  // (cannot happen: the loop above would have taken it)
@@ -684,7 +732,7 @@ private:
         std::vector<int> ok(runs, 1);
         std::vector<size_t> first(runs + 1);
         for (size_t r = 0; r <= runs; ++r) first[r] = mem.size() * r / runs;
-        pinflate::run_parallel(runs, threads_, [&](size_t r) {
+        const bool all_ran = pinflate::run_parallel(runs, threads_, [&](size_t r) {
             size_t total = 0;
             for (size_t k = first[r]; k < first[r + 1]; ++k) total += mem[k].isize;
             Piece &pc = pieces[r];
@@ -705,6 +753,7 @@ private:
             inflateEnd(&z);
             pc.n = total;
         });
+        if (!all_ran) ok.assign(runs, 0);  // a worker could not get its memory: zlib reads on alone from the first run
         ++rounds_;
         for (size_t r = 0; r < runs; ++r) {
             if (!ok[r]) {  // zlib reads this run again, alone, and says what is wrong with it
@@ -730,13 +779,18 @@ private:
         bgzf_at_ = at;
     }
 
-    GzPoint point_at(uint64_t bit, uint64_t out, const std::string &window) const {
+    // check: the point is a hand-over to zlib inside the member — crc_ covers the member's bytes in front of it, and whoever
+    // inflates on verifies the trailer (an access point of the output pass re-reads validated bytes: no check)
+    GzPoint point_at(uint64_t bit, uint64_t out, const std::string &window, bool check = false) const {
         GzPoint pt;
         pt.raw = true;
         pt.out = member_base_ + out;
         pt.in = (bit + 7) >> 3;
         pt.bits = (int)((8 - (bit & 7)) & 7);
         pt.window = window;
+        pt.check = check;
+        pt.member_base = member_base_;
+        pt.crc = crc_;
         return pt;
     }
 
@@ -794,7 +848,8 @@ private:
     }
 
     // one round: up to `threads` chunks searched, decoded, chained, resolved; their bytes are queued for read()
-    void round() {
+    // (false: a worker ran out of memory — nothing of this round counts)
+    bool round() {
         using namespace pinflate;
         ++rounds_;
         static const bool timing = getenv("FLX_CLI_PINFLATE_TIMING") != nullptr;
@@ -814,7 +869,7 @@ private:
         ch[0].found = true;
         ch[0].start = chain_bit_;
         const size_t limit = std::max<size_t>(cb * 24, (size_t)1 << 20);  // a text compresses 3-5x; beyond 24x zlib does it alone
-        run_parallel(n, threads_, [&](size_t i) {
+        bool all_ran = run_parallel(n, threads_, [&](size_t i) {
             Decoder &d = decoders_[i];
             d.in.init(data_, size_);
             if (i == 0) return;
@@ -823,7 +878,8 @@ private:
             ch[i].found = ch[i].begin < ch[i].end && find_block_start(d, ch[i].begin, ch[i].end, &ch[i].start);
         });
         const double t1 = now();
-        run_parallel(n, threads_, [&](size_t i) {
+        if (!all_ran) return false;
+        all_ran = run_parallel(n, threads_, [&](size_t i) {
             Chunk &c = ch[i];
             if (!c.found) return;
             Decoder &d = decoders_[i];
@@ -859,6 +915,7 @@ private:
             }
         });
         const double t2 = now();
+        if (!all_ran) return false;
         // the chain from chunk 0; windows one after the other
         std::vector<size_t> chain;
         size_t i = 0;
@@ -879,7 +936,7 @@ private:
         for (size_t k = 0; k < n; ++k) dropped_chunks_ += ch[k].found && std::find(chain.begin(), chain.end(), k) == chain.end() && k != broken;
         // markers -> bytes, CRC-32 per chunk
         const double t3 = now();
-        run_parallel(chain.size(), threads_, [&](size_t k) {
+        all_ran = run_parallel(chain.size(), threads_, [&](size_t k) {
             Chunk &c = ch[chain[k]];
             char *dst = c.bytes.data();
             const uint16_t *s = c.sym.data();
@@ -897,6 +954,7 @@ private:
                 crc = crc32(crc, (const Bytef *)dst + at, (uInt)std::min<size_t>(c.n - at, (size_t)1 << 30));
             c.crc = crc;
         });
+        if (!all_ran) return false;
         if (timing) {
             size_t tail = 0, all = 0;
             for (size_t k : chain) { tail += ch[k].n - ch[k].n_sym; all += ch[k].n; }
@@ -929,14 +987,15 @@ private:
         }
         if (broken != (size_t)-1) {  // zlib continues from the start of the chunk that did not work out
             const Chunk &c = ch[broken];
-            hand_over(point_at(c.start, c.out, c.window));
-            return;
+            hand_over(point_at(c.start, c.out, c.window, true));
+            return true;
         }
         const Chunk &last = ch[chain.back()];
         member_out_ = out;
         window_ = window;
         chain_bit_ = last.stop;
         if (last.final_block) finish_member(last.stop);
+        return true;
     }
 
     // the 32 KiB behind chunk c from the 32 KiB in front of it, its symbols and its bytes; false: a marker points in front of the data
@@ -965,9 +1024,13 @@ private:
     void finish_member(uint64_t end_bit) {
         p_finished_ = true;
         const size_t t = (size_t)((end_bit + 7) >> 3);
-        if (t + 8 > size_) { p_error_ = true; return; }
+        if (t + 8 > size_) return;  // the trailer is cut off: to gzread that is the end of the file, everything decoded is delivered
         auto le32 = [&](size_t p) { return (uint32_t)data_[p] | (uint32_t)data_[p + 1] << 8 | (uint32_t)data_[p + 2] << 16 | (uint32_t)data_[p + 3] << 24; };
-        if (le32(t) != (uint32_t)crc_ || le32(t + 4) != (uint32_t)member_out_) { p_error_ = true; return; }
+        if (le32(t) != (uint32_t)crc_ || le32(t + 4) != (uint32_t)member_out_) {  // zlib: "incorrect data check" / "incorrect length check"
+            p_error_ = true;
+            p_deliverable_ = gzread_delivered_before_error(member_base_, member_out_, false);
+            return;
+        }
         const size_t next = t + 8;
         if (next + 2 <= size_ && data_[next] == 0x1f && data_[next + 1] == 0x8b) {  // like gzread: members follow each other
             p_finished_ = false;
@@ -1007,6 +1070,7 @@ private:
     std::deque<Piece> stage_q_;
     std::deque<GzPoint> stage_pts_;
     bool p_finished_ = false, p_error_ = false, p_handover_set_ = false;
+    uint64_t p_deliverable_ = 0;  // with p_error_: the bytes gzread would have delivered
     GzPoint p_handover_;
     std::vector<pinflate::Decoder> decoders_;
     std::atomic<uint64_t> parallel_bytes_{0}, zlib_tail_bytes_{0};

@@ -239,7 +239,7 @@ def test_bgzf_and_members_side_by_side(tmp_path):
 
 
 def test_damaged_files_end_like_through_zlib(tmp_path):
-    """Truncated anywhere, a flipped bit anywhere, a wrong CRC-32, a wrong length: exit code and records as with FLX_CLI_PINFLATE=0."""
+    """Truncated anywhere, a flipped bit anywhere, a wrong CRC-32, a wrong length: records and end state as with FLX_CLI_PINFLATE=0."""
     rng = np.random.RandomState(5)
     data = read_like_fastq(rng, 120, 3000)
     blob = bytearray(gzip.compress(data, 6, mtime=0))
@@ -259,10 +259,8 @@ def test_damaged_files_end_like_through_zlib(tmp_path):
         open(gz, "wb").write(bb)
         a = run(gz, "blk", 5, FLX_CLI_PINFLATE=0)
         p = run(gz, "blk", 5, FLX_CLI_PINFLATE_MIN=1, FLX_CLI_PINFLATE_CHUNK=3000)
-        assert a[0] == p[0], (name, a[2][-300:], p[2][-300:])
-        if a[0] == 0:
-            assert a[1] == p[1], name
-        differing += a[0] != 0
+        assert a[0] == 0 and a[:2] == p[:2], (name, a[2][-300:], p[2][-300:])
+        differing += " status -1 " not in a[1]  # (what the end states must BE: tests/test_cli_damaged_gzip.py, against the reference's reader)
         # taken into memory: whatever gzread makes of the damaged file, with and without the parallel decoder in front of it
         a = run(gz, "seq", 5, FLX_CLI_PINFLATE=0)
         p = run(gz, "seq", 5, FLX_CLI_PINFLATE_MIN=1, FLX_CLI_PINFLATE_CHUNK=3000)

@@ -133,12 +133,21 @@ def test_cli_verbose_scores(tmp_path):
     assert [rows["test_sort_%d" % i][4].strip() for i in (1, 2, 3)] == ["0.00", "70.70", "61.54"]
 
 
-@pytest.mark.parametrize("mode", ["default", "blocks"])
+@pytest.mark.parametrize("mode", ["default", "blocks", "gpus2", "gpus3"])
 def test_cli_verbose_matches_reference_stderr(tmp_path, mode):
     """--verbose stderr, character for character after the hashing section (tests/golden/verbose.json, written by
     make_verbose_golden.py from the reference binary): per-read blocks with `bad ranges` / `child ranges`
-    (src/read.cpp:169-194), the blank line after them (main.cpp:129), the score table with host-libm final scores."""
+    (src/read.cpp:169-194), the blank line after them (main.cpp:129), the score table with host-libm final scores.
+    gpus2 / gpus3: `--gpus N` (forked ranks over the loopback communicator on one GPU) — every rank leaves the blocks and the
+    table rows of its reads in the job's directory, rank 0 prints them in file order; on the error paths rank 0 alone scores
+    the reads in front of the error."""
     gold = json.load(open(os.path.join(_cases.GOLDEN, "verbose.json")))
+    prefix = []
+    if mode.startswith("gpus"):
+        shim_dir = os.path.join(ROOT, "tests", "shim")
+        subprocess.check_call(["make", "-s", "-C", shim_dir])
+        MODES[mode] = {"FLX_RCCL_LIB": os.path.join(shim_dir, "libloopback_rccl.so"), "FLX_DEVICE": "0"}
+        prefix = ["--gpus", mode[4:]]
     for key, g in sorted(gold.items()):
         args = [os.path.join(FIX, "test_reference.fasta") if a == "REF" else a for a in g["args"]]
         inp = g["input"]
@@ -149,7 +158,7 @@ def test_cli_verbose_matches_reference_stderr(tmp_path, mode):
                     f.write(open(os.path.join(FIX, part), "rb").read())
         else:
             path = os.path.join(FIX, inp)
-        rc, out, keep, err = run(args + [path], str(tmp_path), MODES[mode])
+        rc, out, keep, err = run(prefix + args + [path], str(tmp_path), MODES[mode])
         assert rc == g["rc"], (key, err)
         cut = err.find("16-mers\n\n")
         got = err[cut + len("16-mers\n\n"):] if cut >= 0 else err

@@ -45,7 +45,7 @@ def score_hip(ctx, reads, pkw, use_order=True):
 
 
 def select_kernel(monkeypatch, kernel):
-    """default = register-history kernel where the window size has one (48..319, else LDS ring), table layout chosen from a
+    """default = register-history kernel where the window size has one (1..1007, else LDS ring), table layout chosen from a
     sample of the data; "plain" / "private" force its table layout; "ring" / "direct" force the older kernels."""
     if kernel in ("ring", "direct", "stream"):
         monkeypatch.setenv("FLX_PHRED_KERNEL", kernel)
@@ -79,7 +79,7 @@ def test_reference_fixture_phred(ctx):
 
 @pytest.mark.parametrize("kernel", ["plain", "private"])
 def test_regs_kernel_every_window_remainder(ctx, kernel, monkeypatch):
-    """Register-history kernel: window sizes across its range 48..319 and just outside, every remainder (ws % 16 = 0..15 drives the byte funnel and the position of
+    """Register-history kernel: window sizes around its default range and every remainder (ws % 16 = 0..15 drives the byte funnel and the position of
     the first full window inside a piece), lengths around ws and every 16/64-byte boundary, arbitrary bytes (bank-private
     tables: reads with bytes >= 128 take the redo path), batches that are not a multiple of 64, both processing orders."""
     select_kernel(monkeypatch, kernel)
@@ -118,6 +118,90 @@ def test_regs_kernel_every_window_remainder(ctx, kernel, monkeypatch):
             assert_same_f64(o["mean_q"], np.array([w["mean_q"] for w in want]), "ws %d mean_q" % ws)
             assert_same_f64(o["window_q"], np.array([w["window_q"] for w in want]), "ws %d window_q" % ws)
             assert (o["passed"] == np.array([w["passed"] for w in want], dtype=np.uint8)).all()
+
+
+def _instantiation_reads(ws, rng):
+    """A small read set built around one window size: lengths at ws and around it, at the 16/64/128-byte boundaries behind
+    it (ring piece, LDS-DMA chunk, cache line), one and several ring revolutions later, and a few long ones; bytes from the
+    synthetic profile, the FASTQ alphabet, any byte value (>= 128: redo path of the bank-private tables) and the top of the
+    7-bit range."""
+    lens = {0, 1, 15, 16, 17, max(ws - 1, 0), ws, ws + 1, ws + 2, ws + 15, ws + 16, ws + 17, ws + 31, ws + 33, ws + 63, ws + 64,
+            ws + 65, ws + 127, ws + 128, ws + 129, 2 * ws - 1, 2 * ws, 2 * ws + 1, 2 * ws + 16, 3 * ws + 5,
+            (ws // 16 + 4) * 16 - 1, (ws // 16 + 4) * 16, (ws // 16 + 4) * 16 + 1, 2 * (ws // 16 + 4) * 16 + 3,
+            ((ws + 127) // 128) * 128, ((ws + 127) // 128) * 128 + 128}
+    lens = sorted(lens) + [int(x) for x in rng.randint(ws + 1, ws + 700, 10)] + [int(x) for x in rng.randint(2 * ws + 200, 4 * ws + 3000, 8)]
+    reads = []
+    for i, L in enumerate(lens):
+        kind = i % 7
+        if kind == 0:
+            q = rng.randint(0, 256, size=L).astype(np.uint8)
+        elif kind == 1:
+            q = rng.randint(33, 127, size=L).astype(np.uint8)
+        elif kind == 2 and L > 2:
+            q = rng.randint(120, 128, size=L).astype(np.uint8)
+            q[(L * 2) // 3] = 0xff if i % 2 else 127
+        else:
+            q = synth.qual_read(90_000 + 131 * ws + i, int(L), 17 if kind == 3 else 5)
+        reads.append(("w%d_%d" % (ws, i), b"", q.tobytes()))
+    return reads
+
+
+def _instantiation_window_sizes():
+    """Every instantiation A = ws / 16 = 0..62 of flx_score_phred_regs with the remainders B = ws % 16 in {0, 1, 15}, the
+    switch points of the wave occupancy classes (A = 7|8, 15|16, 38|39) with every remainder, and the end of the kernel's range."""
+    wss = set()
+    for A in range(63):
+        for B in (0, 1, 15):
+            if 16 * A + B >= 1:
+                wss.add(16 * A + B)
+    for A in (7, 8, 15, 16, 31, 32, 38, 39, 62):
+        wss.update(range(16 * A, 16 * A + 16))
+    wss.discard(0)
+    return sorted(wss)
+
+
+@pytest.mark.parametrize("part", range(8))
+def test_regs_kernel_every_instantiation(ctx, part, monkeypatch):
+    """All 63 instantiations of the register-history kernel: each A is its own unroll / ring-index /
+    register-allocation product of the compiler, incl. the VGPR+AGPR rings for ws >= 624.  For every window size of
+    `_instantiation_window_sizes()`: one oracle pass, then the plain and (A < 32) the bank-private tables, both processing
+    orders — and the test asserts that the register-history kernel is what ran.  ws 1008 (first LDS-ring size) rides along."""
+    wss = _instantiation_window_sizes() + [1008]
+    mine = wss[part::8]
+    rng = np.random.RandomState(4000 + part)
+    seen_a = set()
+    for ws in mine:
+        reads = _instantiation_reads(ws, rng)
+        pkw = dict(window_size=ws)
+        p = _oracle.make_params(**pkw)
+        want = [_oracle.score_read(None, q, p) for _, _, q in reads]
+        wm = np.array([w["mean_q"] for w in want])
+        ww = np.array([w["window_q"] for w in want])
+        wp = np.array([w["passed"] for w in want], dtype=np.uint8)
+        layouts = ("plain", "private") if ws < 512 else ("plain",)
+        for li, layout in enumerate(layouts):
+            monkeypatch.setenv("FLX_PHRED_TABLES", layout)
+            for use_order in ((True, False) if li == 0 else (True,)):
+                o = score_hip(ctx, reads, pkw, use_order)
+                k = ctx.last_phred_kernel()
+                if ws <= 1007:
+                    assert k == ("flx_score_phred_regs_private" if layout == "private" else "flx_score_phred_regs"), (ws, k)
+                else:
+                    assert k == "flx_score_phred_ring", (ws, k)
+                tag = "ws %d (A %d, B %d) %s order=%s" % (ws, ws // 16, ws % 16, layout, use_order)
+                assert_same_f64(o["mean_q"], wm, tag + " mean_q")
+                assert_same_f64(o["window_q"], ww, tag + " window_q")
+                assert (o["passed"] == wp).all(), tag
+        seen_a.add(ws // 16)
+    assert len(mine) > 0 and seen_a
+
+
+def test_regs_instantiation_list_is_complete():
+    wss = _instantiation_window_sizes()
+    for A in range(63):
+        have = {w % 16 for w in wss if w // 16 == A}
+        assert {1, 15} <= have and (A == 0 or 0 in have), A
+    assert 1007 in wss and max(wss) == 1007
 
 
 @pytest.mark.parametrize("ws", [250, 7, 64, 333])
