@@ -354,6 +354,9 @@ class Context:
     def last_phred_kernel(self):
         return self.L.flx_last_phred_kernel(self.h).decode()
 
+    def last_kmer_locus(self):
+        return bool(self.L.flx_last_kmer_locus(self.h))
+
     def synth_qual_dev(self, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n, profile=0):
         self._check(self.L.flx_synth_qual_profile_dev(self.h, seed, profile, d_plane, plane_bytes, d_offsets, d_lengths,
                                                       d_read_ids, n))

@@ -28,6 +28,7 @@ extern "C" int flx_device_count(void) {
 extern "C" const char *flx_version(void) { return "filtlong-amd 0.1 (hot path of Filtlong v0.3.1; gfx950)"; }
 
 extern "C" const char *flx_last_phred_kernel(const flx_ctx *ctx) { return ctx ? ctx->last_phred_kernel : ""; }
+extern "C" int flx_last_kmer_locus(const flx_ctx *ctx) { return ctx && ctx->last_kmer_locus ? 1 : 0; }
 
 extern "C" const char *flx_last_error(const flx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 

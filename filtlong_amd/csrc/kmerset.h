@@ -53,6 +53,41 @@ __host__ __device__ inline flx_pre11_slot flx_pre11(uint32_t c, uint32_t x, uint
 const uint8_t *flx_kmerset_pre11(const flx_kmerset *set);    // 2 MiB or NULL (no prefilter: saturated, or switched off)
 const uint8_t *flx_kmerset_exact15(const flx_kmerset *set);  // 1 GiB
 
+// ---- the assembly as a text: members confirmed along a read's locus (round 4) -------------------------------------------------
+// A far request to exact15 answers two positions; 64 bytes of the 2-bit packed assembly answer 256.  When the set was built from
+// an assembly (src/kmers.cpp:61-72), finalize keeps the sequences as `text`: for every contig of at least 16 bases its forward
+// strand in the forward encoder's codes (src/kmers.cpp:176-196), then its reverse strand in the codes the reverse encoder puts on
+// top of its k-mers (src/kmers.cpp:199-219: A 3, C 2, G 1, T 0, anything else 0) in reversed order — so every 16-base window of
+// `text` that lies inside one strand copy IS one of the two k-mers src/kmers.cpp:106-121 inserted at that position, non-ACGT quirk
+// included.  If 16 consecutive bases of a read carry the codes of such a window, that 16-mer is a member: a locus match is
+// SUFFICIENT (not necessary — the 16-mer may occur elsewhere, so windows with a mismatch go through the usual search).
+//   text  uint2 per 16 bases: .x = the codes (first base in the top two bits), .y = bit k set when base k of the word is the
+//         FIRST base of a strand copy (a window must not run across such a base behind its first); kLocusPad words of padding with
+//         every .y bit set in front of the data and at least 68 behind, so that an index clamped to [0, n_alloc) is never a match
+//   seed  open addressing, key = a 16-mer of the text, value = the text position of its first base (the smallest one for a
+//         repeated 16-mer), 0xFFFFFFFF = empty; a slot is verified by comparing the text there with the key
+constexpr uint32_t kLocusPad = 2;
+constexpr uint32_t kLocusEmpty = 0xFFFFFFFFu;
+struct flx_locus {
+    const uint2 *text;
+    uint32_t n_alloc;    // words in `text`, padding included
+    uint64_t n_text;     // text positions (bases of both strand copies)
+    const uint32_t *seed;
+    uint32_t seed_mask;  // slots - 1
+    int seed_shift;      // 32 - log2(slots)
+};
+__host__ __device__ inline uint32_t flx_locus_hash(uint32_t kmer, int shift) { return (kmer * 0x9E3779B1u) >> shift; }
+#if defined(__HIPCC__)
+// the 16 codes of the text from position t on (t + 16 <= n_text is the caller's business: padding follows the data)
+__device__ __forceinline__ uint32_t flx_locus_kmer_at(const uint2 *text, uint32_t t) {
+    const uint32_t w = (t >> 4) + kLocusPad, s = t & 15u;
+    const uint32_t a = text[w].x;
+    if (s == 0) return a;
+    return __builtin_amdgcn_alignbit(a, text[w + 1].x, 32 - 2 * s);
+}
+#endif
+const flx_locus *flx_kmerset_locus(const flx_kmerset *set);  // NULL: no assembly, too large, or switched off at build time
+
 int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_plane, uint64_t plane_bytes,
                        const uint64_t *d_offsets, const int32_t *d_lengths, const uint32_t *d_order,
                        uint64_t n_reads, const flx_params *params, flx_scores *out);

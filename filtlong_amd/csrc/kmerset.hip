@@ -212,6 +212,8 @@ __global__ void __launch_bounds__(256) k_contains(const uint32_t *present, const
     if (i < n) out[i] = test_bit(present, kmers[i]) ? 1 : 0;
 }
 
+__global__ void k_set_word_bits(uint32_t *word, uint32_t bits) { *word |= bits; }
+
 __global__ void __launch_bounds__(256) k_set_bits(uint32_t *bm, const uint32_t *kmers, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) set_bit(bm, kmers[i]);
@@ -270,6 +272,63 @@ __global__ void __launch_bounds__(256) k_first_sightings(const uint8_t *bases, c
     }
 }
 
+// ---- the assembly as a text + seed table (kmerset.h: flx_locus) ----------------------------------------------------------
+// one thread per base of the batch's sequences (those of at least 16 bases; cum[i] = bases of the sequences before i)
+__global__ void __launch_bounds__(256) k_locus_text(const uint8_t *bases, const uint64_t *offsets, const uint64_t *pos_base,
+                                                    uint64_t n_seqs, uint64_t n_pos, uint64_t text_base, uint32_t *text_words) {
+    const uint64_t n_bases = n_pos + 15 * n_seqs;
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_bases) return;
+    uint64_t lo = 0, hi = n_seqs;
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (pos_base[mid] + 15 * mid <= g) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t cum = pos_base[lo] + 15 * lo;
+    const uint64_t len = (lo + 1 < n_seqs ? pos_base[lo + 1] : n_pos) - pos_base[lo] + 15;
+    const uint64_t o = g - cum;
+    const uint8_t c = bases[offsets[lo] + o];
+    const uint64_t tf = text_base + 2 * cum + o, tr = text_base + 2 * cum + len + (len - 1 - o);
+    auto put = [&](uint64_t t, uint32_t code, bool starts_copy) {
+        uint32_t *w = text_words + 2 * ((t >> 4) + kLocusPad);
+        if (code) atomicOr(w, code << (30 - 2 * (uint32_t)(t & 15)));
+        if (starts_copy) atomicOr(w + 1, 1u << (uint32_t)(t & 15));
+    };
+    put(tf, base_fwd(c), o == 0);
+    put(tr, base_rev_code(c), o == len - 1);
+}
+
+// one thread per 16-mer start of the batch's sequences, both strand copies: the smallest text position of every distinct 16-mer
+__global__ void __launch_bounds__(256) k_locus_seed(const uint64_t *pos_base, uint64_t n_seqs, uint64_t n_pos, uint64_t text_base,
+                                                    const uint2 *text, uint32_t *seed, uint32_t mask, int shift) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_pos) return;
+    uint64_t lo = 0, hi = n_seqs;
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (pos_base[mid] <= g) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t p = g - pos_base[lo];
+    const uint64_t cum = pos_base[lo] + 15 * lo;
+    const uint64_t len = (lo + 1 < n_seqs ? pos_base[lo + 1] : n_pos) - pos_base[lo] + 15;
+    for (int strand = 0; strand < 2; ++strand) {
+        const uint32_t t = (uint32_t)(text_base + 2 * cum + (strand ? len : 0) + p);
+        const uint32_t k = flx_locus_kmer_at(text, t);
+        uint32_t h = flx_locus_hash(k, shift);
+        for (;;) {
+            const uint32_t old = atomicCAS(&seed[h], kLocusEmpty, t);
+            if (old == kLocusEmpty) break;
+            if (flx_locus_kmer_at(text, old) == k) {  // (whoever holds the slot, its text is final: the slot's key cannot change)
+                atomicMin(&seed[h], t);
+                break;
+            }
+            h = (h + 1) & mask;
+        }
+    }
+}
+
 }  // namespace
 
 struct flx_kmerset {
@@ -291,6 +350,10 @@ struct flx_kmerset {
         uint64_t n_seqs, n_pos;
     };
     std::vector<Batch> short_batches;
+    std::vector<Batch> asm_batches;     // the assembly's sequences, kept until finalize builds the locus text from them (kmerset.h)
+    uint32_t *locus_text = nullptr, *locus_seed = nullptr;
+    flx_locus locus;
+    bool has_locus = false;
     uint64_t bloom_candidates = 0;
     uint64_t bloom_false_positives = 0;
 };
@@ -300,6 +363,7 @@ const uint32_t *flx_kmerset_bitmap(const flx_kmerset *set) { return set->present
 const uint32_t *flx_kmerset_prefilter(const flx_kmerset *set) { return set->prefilter; }
 const uint8_t *flx_kmerset_pre11(const flx_kmerset *set) { return (const uint8_t *)set->pre11; }
 const uint8_t *flx_kmerset_exact15(const flx_kmerset *set) { return (const uint8_t *)set->exact15; }
+const flx_locus *flx_kmerset_locus(const flx_kmerset *set) { return set->has_locus ? &set->locus : nullptr; }
 
 extern "C" int flx_kmerset_create(flx_ctx *ctx, flx_kmerset **out) {
     if (!ctx || !out) return FLX_ERR_INVALID;
@@ -316,21 +380,23 @@ extern "C" int flx_kmerset_create(flx_ctx *ctx, flx_kmerset **out) {
     return FLX_OK;
 }
 
-static void free_batches(flx_kmerset *s) {
-    for (auto &b : s->short_batches) {
+static void free_batches(std::vector<flx_kmerset::Batch> &batches) {
+    for (auto &b : batches) {
         (void)hipFree(b.bases);
         (void)hipFree(b.offsets);
         (void)hipFree(b.pos_base);
     }
-    s->short_batches.clear();
+    batches.clear();
 }
+static void free_batches(flx_kmerset *s) { free_batches(s->short_batches); }
 
 extern "C" void flx_kmerset_destroy(flx_kmerset *s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     free_batches(s);
-    for (uint32_t *p : {s->present, s->asm_only, s->seen1, s->seen2, s->seen3, s->prefilter, s->pre11, s->exact15})
+    free_batches(s->asm_batches);
+    for (uint32_t *p : {s->present, s->asm_only, s->seen1, s->seen2, s->seen3, s->prefilter, s->pre11, s->exact15, s->locus_text, s->locus_seed})
         if (p) (void)hipFree(p);
     delete s;
 }
@@ -393,9 +459,7 @@ extern "C" int flx_kmerset_add_assembly(flx_kmerset *s, const uint8_t *bases, co
         flx_time_end(ctx);
         FLX_HIP(ctx, hipGetLastError());
         FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(b.bases);
-        (void)hipFree(b.offsets);
-        (void)hipFree(b.pos_base);
+        s->asm_batches.push_back(b);  // finalize builds the locus text from them (kmerset.h), then they go
     }
     return FLX_OK;
 }
@@ -602,6 +666,71 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
         FLX_HIP(ctx, hipMemsetAsync(s->exact15, 0, (size_t)1 << 30, st));
         hipLaunchKernelGGL(k_build_exact15, dim3(8192), dim3(256), 0, st, s->present, kBitmapWords, s->exact15);
         FLX_HIP(ctx, hipStreamSynchronize(st));
+    }
+    // the assembly as a text + seed table (kmerset.h).  Worth its memory while the 16-mer space is sparse: up to 2^28 text
+    // positions (a 128 Mbp assembly; the seed table is then 4 GiB); FLX_KMER_LOCUS_BUILD=0 leaves it out.
+    {
+        uint64_t n_text = 0, n_windows = 0;
+        for (auto &b : s->asm_batches) {
+            n_text += 2 * (b.n_pos + 15 * b.n_seqs);
+            n_windows += 2 * b.n_pos;
+        }
+        const char *lb = getenv("FLX_KMER_LOCUS_BUILD");
+        if (n_windows > 0 && n_text <= (1ull << 28) && !(lb && lb[0] == '0')) {
+            const uint64_t n_words = (n_text + 15) / 16;
+            const uint64_t n_alloc = n_words + kLocusPad + 68;
+            int bits = 10;
+            while ((1ull << bits) < n_windows * 5 / 2) ++bits;
+            const uint64_t slots = 1ull << bits;
+            hipError_t e1 = hipMalloc((void **)&s->locus_text, n_alloc * 8);
+            hipError_t e2 = e1 == hipSuccess ? hipMalloc((void **)&s->locus_seed, slots * 4) : e1;
+            if (e1 == hipSuccess && e2 == hipSuccess) {
+                FLX_HIP(ctx, hipMemsetAsync(s->locus_text, 0, n_alloc * 8, st));
+                // padding: no window may start or end there
+                std::vector<uint32_t> pad_front(2 * kLocusPad), pad_back(2 * 68);
+                for (size_t i = 0; i < pad_front.size(); i += 2) { pad_front[i] = 0; pad_front[i + 1] = 0xffffu; }
+                for (size_t i = 0; i < pad_back.size(); i += 2) { pad_back[i] = 0; pad_back[i + 1] = 0xffffu; }
+                FLX_HIP(ctx, hipMemcpyAsync(s->locus_text, pad_front.data(), pad_front.size() * 4, hipMemcpyHostToDevice, st));
+                FLX_HIP(ctx, hipMemcpyAsync(s->locus_text + 2 * (kLocusPad + n_words), pad_back.data(), pad_back.size() * 4, hipMemcpyHostToDevice, st));
+                FLX_HIP(ctx, hipMemsetAsync(s->locus_seed, 0xff, slots * 4, st));
+                flx_time_begin(ctx, "flx_kmerset_locus_build");
+                uint64_t tb = 0;
+                for (auto &b : s->asm_batches) {
+                    const uint64_t nb_bases = b.n_pos + 15 * b.n_seqs;
+                    if (nb_bases)
+                        hipLaunchKernelGGL(k_locus_text, dim3((unsigned)((nb_bases + 255) / 256)), dim3(256), 0, st, b.bases, b.offsets, b.pos_base,
+                                           b.n_seqs, b.n_pos, tb, s->locus_text);
+                    tb += 2 * nb_bases;
+                }
+                // the last word's bases behind the text must not look like the start of anything: a copy "starts" at n_text
+                if (n_text % 16) {
+                    const uint32_t tail_bits = 0xffffu & ~((1u << (n_text % 16)) - 1u);
+                    hipLaunchKernelGGL(k_set_word_bits, dim3(1), dim3(1), 0, st, s->locus_text + 2 * (kLocusPad + n_words - 1) + 1, tail_bits);
+                }
+                tb = 0;
+                for (auto &b : s->asm_batches) {
+                    if (b.n_pos)
+                        hipLaunchKernelGGL(k_locus_seed, dim3((unsigned)((b.n_pos + 255) / 256)), dim3(256), 0, st, b.pos_base, b.n_seqs, b.n_pos, tb,
+                                           (const uint2 *)s->locus_text, s->locus_seed, (uint32_t)(slots - 1), 32 - bits);
+                    tb += 2 * (b.n_pos + 15 * b.n_seqs);
+                }
+                flx_time_end(ctx);
+                FLX_HIP(ctx, hipGetLastError());
+                FLX_HIP(ctx, hipStreamSynchronize(st));
+                s->locus.text = (const uint2 *)s->locus_text;
+                s->locus.n_alloc = (uint32_t)n_alloc;
+                s->locus.n_text = n_text;
+                s->locus.seed = s->locus_seed;
+                s->locus.seed_mask = (uint32_t)(slots - 1);
+                s->locus.seed_shift = 32 - bits;
+                s->has_locus = true;
+            } else {  // not enough memory for it: the scoring path works without
+                if (s->locus_text) (void)hipFree(s->locus_text);
+                s->locus_text = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+        free_batches(s->asm_batches);
     }
     s->final_ = true;
     return FLX_OK;

@@ -270,10 +270,20 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
 //     down until the first member, and from the bottom up (not at all if the left neighbour's last position is a member),
 //     one pair per side and round; a clean stretch costs one request per 16 positions, a false candidate costs one only
 //     when it lies outside the confirmed span.  Rounds repeat until no lane of the wave has an open question.
-template <bool HAS_PREFILTER>
+//
+// LOCUS (round 4, assembly references — kmerset.h: flx_locus): the wave carries a DIAGONAL, the text position its read's base 0
+// would have in the assembly.  Every lane compares its 16 bases with the text along the diagonal (one coalesced 8-byte load per
+// lane and span, prefetched a span ahead); 16 matching bases inside one strand copy ARE a member, without any request — `known`.
+// The known members enter the search as confirmed hits: a lane whose own last 16-mer and whose left neighbour's are known is
+// settled before anything is asked, a lane with a mismatch looks up only the prefilter pairs outside [lowest hit - 4, highest
+// hit] and asks the exact table only outside its confirmed span, exactly as before (a 16-mer with a mismatch against the locus
+// may still occur elsewhere).  The diagonal comes from the seed table: eight lanes look their own 16 bases up (one far request
+// each) when the wave has none or the last 16 lanes of the previous span matched nowhere; a seed that fails leaves the old
+// diagonal in place as a hypothesis that costs nothing to test.
+template <bool HAS_PREFILTER, bool LOCUS>
 __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_t *plane, const uint64_t *offsets, const int32_t *lengths,
                                                       const uint32_t *order, uint64_t n_reads, const uint8_t *exact15,
-                                                      const uint8_t *pre11, uint32_t *cov, const uint64_t *cov_off,
+                                                      const uint8_t *pre11, const flx_locus loc, uint32_t *cov, const uint64_t *cov_off,
                                                       int32_t *count, int32_t *first, int32_t *last) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -290,6 +300,17 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
         uint32_t c_lo = 0, c_p12 = 0, c_cand15 = 0, c_hit15 = 0;
         uint32_t prev_hits = 0;  // hits of the previous span, waiting for their right neighbour's
         bool far_first = false;  // this span asks the exact table BEFORE the prefilter (decided by the previous span, below)
+        // LOCUS: the diagonal (wave-uniform), whether a seed is due, the text of this span / the next one, lane 63's carry
+        long long diag = 0;
+        bool have_diag = false, want_seed = true, carry_ok = false;
+        uint32_t c_mml = 0xffffu, c_bnd = 0xffffu, c_known15 = 0, c_twx = 0, c_twy = 0xffffu;
+        uint2 tw = make_uint2(0, 0xffffu), tw_next = make_uint2(0, 0xffffu);
+        // the text word that holds the LAST base of the lane's 16 at this diagonal (index clamped into the padded array)
+        auto text_word = [&](long long dg, int p0) -> uint2 {
+            long long w = ((dg + p0 + 15) >> 4) + (long long)kLocusPad;
+            w = w < 0 ? 0 : (w >= (long long)loc.n_alloc ? (long long)loc.n_alloc - 1 : w);
+            return loc.text[w];
+        };
 
         auto finalize = [&](int sp, uint32_t h, uint32_t right_of_63) {  // hits of span sp -> coverage bits, counts, row words
             const int p0 = (sp << 10) + lane * 16;
@@ -319,6 +340,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
             const int p0 = (sp << 10) + lane * 16;
             uint4 raw_next = make_uint4(0, 0, 0, 0);
             if (p0 + 1024 < L) raw_next = *reinterpret_cast<const uint4 *>(seq + p0 + 1024);
+            if (LOCUS && have_diag && sp + 1 < n_spans) tw_next = text_word(diag, p0 + 1024);
             // 2 bits per base, earliest base on top: lo = my 16 bases, hi = the 16 before them
             const uint32_t lo = (codes4(raw.x) << 24) | (codes4(raw.y) << 16) | (codes4(raw.z) << 8) | codes4(raw.w);
             uint32_t hi = __shfl_up(lo, 1, 64);
@@ -334,11 +356,82 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
                     valid16 &= (1u << (L - p0)) - 1u;
                 }
             }
+            // ---- LOCUS: members known from the text along the diagonal ----
+            uint32_t known = 0;
+            if (LOCUS) {
+                if (want_seed) {  // (wave-uniform) eight lanes look their own 16 bases up in the seed table
+                    const bool tries = (lane & 7) == 3 && (valid16 >> 15);
+                    uint32_t tpos = kLocusEmpty;
+                    if (tries) {
+                        uint32_t h = flx_locus_hash(lo, loc.seed_shift);
+#pragma unroll 1
+                        for (int probe_no = 0; probe_no < 4; ++probe_no) {
+                            const uint32_t v = loc.seed[h];
+                            if (v == kLocusEmpty) break;
+                            if (flx_locus_kmer_at(loc.text, v) == lo) { tpos = v; break; }
+                            h = (h + 1) & loc.seed_mask;
+                        }
+                    }
+                    const unsigned long long found = __ballot(tpos != kLocusEmpty);
+                    if (found) {
+                        const int src = __ffsll(found) - 1;
+                        const long long nd = (long long)__builtin_amdgcn_readlane(tpos, src) - (long long)((sp << 10) + src * 16);
+                        if (!have_diag || nd != diag) {
+                            diag = nd;
+                            have_diag = true;
+                            carry_ok = false;
+                            tw = text_word(diag, p0);
+                            if (sp + 1 < n_spans) tw_next = text_word(diag, p0 + 1024);
+                        }
+                    }
+                    want_seed = false;
+                }
+                if (have_diag) {
+                    // my 16 bases of the text: the tail of the left lane's word and the head of mine (e = index of my last base in my word)
+                    const int e = (int)((diag + p0 + 15) & 15);
+                    uint2 twl;
+                    twl.x = __shfl_up(tw.x, 1, 64);
+                    twl.y = __shfl_up(tw.y, 1, 64);
+                    if (lane == 0) twl = carry_ok ? make_uint2(c_twx, c_twy) : text_word(diag, p0 - 16);  // (a load only behind a new seed)
+                    const uint32_t t_own = __builtin_amdgcn_alignbit(twl.x, tw.x, 2 * (15 - e));
+                    uint32_t b_own = ((twl.y >> (e + 1)) | (tw.y << (15 - e))) & 0xffffu;  // bit j: my base j is the first of a strand copy
+                    const uint32_t x = lo ^ t_own;
+                    uint32_t m = (x | (x >> 1)) & 0x55555555u;  // even bit 2k: the base k places from the END differs
+                    m = (m | (m >> 1)) & 0x33333333u;
+                    m = (m | (m >> 2)) & 0x0f0f0f0fu;
+                    m = (m | (m >> 4)) & 0x00ff00ffu;
+                    m = (m | (m >> 8)) & 0xffffu;
+                    uint32_t mml = __brev(m) >> 16;  // bit j: my base j differs from the text
+                    uint32_t mmh = __shfl_up(mml, 1, 64), bh = __shfl_up(b_own, 1, 64);
+                    if (lane == 0) { mmh = carry_ok ? c_mml : 0xffffu; bh = carry_ok ? c_bnd : 0xffffu; }
+                    const uint32_t z = ~(mmh | (mml << 16));  // bit i: base i of the window [p0 - 16, p0 + 16) matches
+                    uint32_t r = z & (z >> 1);
+                    r &= r >> 2;
+                    r &= r >> 4;
+                    r &= r >> 8;  // bit i: bases i .. i + 15 match
+                    uint32_t q = ~(bh | (b_own << 16)) >> 1;  // bit i: no copy starts at base i + 1
+                    q &= q >> 1;
+                    q &= q >> 2;
+                    q &= q >> 4;
+                    q &= q >> 7;  // bit i: none at i + 1 .. i + 15 — the 16 bases from i on lie in one strand copy
+                    known = ((r & q) >> 1) & valid16;  // the 16-mer ending at my position j starts at base j + 1 of the window
+                    c_mml = __builtin_amdgcn_readlane(mml, 63);
+                    c_bnd = __builtin_amdgcn_readlane(b_own, 63);
+                    c_twx = __builtin_amdgcn_readlane(tw.x, 63);
+                    c_twy = __builtin_amdgcn_readlane(tw.y, 63);
+                    carry_ok = true;
+                    // a tail without any match: junk, an indel, the wrong copy of a repeat — the next span seeds again
+                    want_seed = (__ballot(known != 0) >> 48) == 0;
+                } else {
+                    want_seed = true;
+                }
+            }
+
             // ---- exact membership: one byte of exact15 answers the pair of positions (a, a + 1), any a in 0..14 — the 15 bases
             // ending at a are the byte's index, the base before them picks the bit of position a, the base after them the bit of
             // a + 1.  A question from ABOVE (top-down search) takes the pair that ENDS at the asked position, one from below the
             // pair that starts there: either way the request also settles the next candidate in the direction of the search. ----
-            uint32_t hits = 0, probed = 0;
+            uint32_t hits = known, probed = known;
             auto probe = [&](int top, int bot, uint32_t keep) {  // positions asked from above / from below, -1 = none
                 const int a0 = top > 0 ? top - 1 : 0, a1 = bot < 14 ? bot : 14;
                 uint32_t g0 = 0, g1 = 0;
@@ -371,10 +464,23 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
             bool settled = false;
             uint32_t ltop = 0;  // far first: is the left neighbour's last 16-mer a member
             if (far_first) {
-                if (__any((valid16 >> 15) != 0)) probe((valid16 >> 15) ? 15 : -1, -1, valid16);
+                const bool ask15 = (valid16 >> 15) != 0 && (known >> 15) == 0;
+                if (__any(ask15)) probe(ask15 ? 15 : -1, -1, valid16);
                 ltop = __shfl_up(hits >> 15, 1, 64);
                 if (lane == 0) ltop = c_hit15;
                 settled = (hits >> 15) && ltop;
+            } else if (LOCUS) {
+                ltop = __shfl_up(known >> 15, 1, 64);
+                if (lane == 0) ltop = c_hit15;
+                settled = (known >> 15) && ltop;
+            }
+            // LOCUS: the 12-mers ending at [lowest hit - 4, highest hit] need no lookup — those inside a member are present, the
+            // others only make candidates between two confirmed members, which are never asked
+            uint32_t need12 = 0xffffu;
+            if (LOCUS && hits) {
+                const int a = __ffs(hits) - 1, b = 31 - __clz(hits);
+                const int from = a > 4 ? a - 4 : 0;
+                need12 = ~(((2u << b) - 1u) & ~((1u << from) - 1u)) & 0xffffu;
             }
 
             // ---- 12-mer prefilter: pair m = positions p0 + 2m, p0 + 2m + 1; x.C.y = the 13 bases ending at p0 + 2m + 1 ----
@@ -388,7 +494,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
 #ifdef FLX_ABL_NOL2
                     byte[m] = 0xffu;  // ablation: no prefilter lookups (every 12-mer "present")
 #else
-                    byte[m] = pre11[q.index];
+                    byte[m] = (!LOCUS || ((need12 >> (2 * m)) & 3u)) ? pre11[q.index] : 0xffu;
 #endif
                     sel[m] = q.even_bit | (q.odd_bit << 8);
                 }
@@ -396,6 +502,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
 #pragma unroll
                 for (int m = 0; m < 8; ++m)
                     p12 |= (((byte[m] >> (sel[m] & 0xffu)) & 1u) | (((byte[m] >> (sel[m] >> 8)) & 1u) << 1)) << (2 * m);
+                if (LOCUS) p12 |= ~need12 & 0xffffu;
             }
             p12 &= valid12;
             uint32_t p12_left = __shfl_up(p12 >> 11, 1, 64);  // the left lane's 12-mers ending at its positions 11..15 = mine at -5..-1
@@ -445,7 +552,14 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
 
             // far first for the next span?  Per lane the skipped prefilter lines are worth 8 x 3.8 ps, a wasted request 18 ps
             // (tools/tabench): worth it from about half the lanes settled.
-            far_first = __popcll(__ballot((hits >> 15) && lhit)) >= FLX_FARFIRST_LANES;
+            if (LOCUS) {  // lanes the text settles anyway do not count: they ask nothing either way
+                uint32_t lknown = __shfl_up(known >> 15, 1, 64);
+                if (lane == 0) lknown = c_known15;
+                far_first = __popcll(__ballot((hits >> 15) && lhit && !((known >> 15) && lknown))) >= FLX_FARFIRST_LANES;
+                c_known15 = __builtin_amdgcn_readlane(known >> 15, 63);
+            } else {
+                far_first = __popcll(__ballot((hits >> 15) && lhit)) >= FLX_FARFIRST_LANES;
+            }
 
             // ---- coverage of the previous span (its lane 63 needed my lane 0's hits), then carry ----
             if (sp > 0) finalize(sp - 1, prev_hits, __builtin_amdgcn_readfirstlane(hits));
@@ -455,6 +569,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
             c_cand15 = __builtin_amdgcn_readlane(cand >> 15, 63);
             c_hit15 = __builtin_amdgcn_readlane(hits >> 15, 63);
             raw = raw_next;
+            if (LOCUS) tw = tw_next;
         }
         if (n_spans > 0) finalize(n_spans - 1, prev_hits, 0u);
         for (int wd = n_spans * 32 + lane; wd < row_words; wd += 64) row[wd] = 0;  // (only L == 0 leaves words unwritten)
@@ -994,13 +1109,26 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
         flx_time_begin(ctx, "flx_score_kmer_cover");
         if (!old_cover) {
             const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + FLX_COVER_THREADS / 64 - 1) / (FLX_COVER_THREADS / 64), 1u << 22);
-            if (flx_kmerset_pre11(set))
-                hipLaunchKernelGGL(k_kmer_cover_w<true>, dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
-                                   flx_kmerset_exact15(set), flx_kmerset_pre11(set), (uint32_t *)d_cov, (const uint64_t *)d_covoff,
+            const char *locus_env = getenv("FLX_KMER_LOCUS");  // "0": without the assembly text (the round-3 kernel; tests, A/B)
+            const flx_locus *lp = (locus_env && locus_env[0] == '0') ? nullptr : flx_kmerset_locus(set);
+            flx_locus none;
+            memset(&none, 0, sizeof none);
+            ctx->last_kmer_locus = lp != nullptr;
+            if (flx_kmerset_pre11(set) && lp)
+                hipLaunchKernelGGL((k_kmer_cover_w<true, true>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
+                                   flx_kmerset_exact15(set), flx_kmerset_pre11(set), *lp, (uint32_t *)d_cov, (const uint64_t *)d_covoff,
+                                   d_cnt, first, last);
+            else if (flx_kmerset_pre11(set))
+                hipLaunchKernelGGL((k_kmer_cover_w<true, false>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
+                                   flx_kmerset_exact15(set), flx_kmerset_pre11(set), none, (uint32_t *)d_cov, (const uint64_t *)d_covoff,
+                                   d_cnt, first, last);
+            else if (lp)
+                hipLaunchKernelGGL((k_kmer_cover_w<false, true>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
+                                   flx_kmerset_exact15(set), (const uint8_t *)nullptr, *lp, (uint32_t *)d_cov, (const uint64_t *)d_covoff,
                                    d_cnt, first, last);
             else
-                hipLaunchKernelGGL(k_kmer_cover_w<false>, dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
-                                   flx_kmerset_exact15(set), (const uint8_t *)nullptr, (uint32_t *)d_cov, (const uint64_t *)d_covoff,
+                hipLaunchKernelGGL((k_kmer_cover_w<false, false>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
+                                   flx_kmerset_exact15(set), (const uint8_t *)nullptr, none, (uint32_t *)d_cov, (const uint64_t *)d_covoff,
                                    d_cnt, first, last);
         } else {
         hipLaunchKernelGGL(k_kmer_cover<256>, dim3(grid), dim3(256), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,

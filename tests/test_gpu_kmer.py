@@ -415,3 +415,143 @@ def test_cover_kernel_boundaries_vs_oracle(be, synth):
                 assert w["child_ranges"] == o["child_ranges"], (name, pf, pkw)
                 for wc, oc in zip(w["children"], o["children"]):
                     assert wc["mean_q"] == oc["mean_q"] and wc["window_q"] == oc["window_q"] and wc["passed"] == oc["passed"], (name, pf, pkw)
+
+
+def _text_codes(contigs):
+    """The assembly as the locus text sees it (filtlong_amd/csrc/kmerset.h: flx_locus): per contig of >= 16 bases its forward
+    strand in forward codes, then its reverse strand in the reverse encoder's codes, reversed.  Returns (codes, copy starts)."""
+    fwd = {ord("C"): 1, ord("c"): 1, ord("G"): 2, ord("g"): 2, ord("T"): 3, ord("t"): 3}
+    rev = {ord("G"): 1, ord("g"): 1, ord("C"): 2, ord("c"): 2, ord("A"): 3, ord("a"): 3}
+    codes, starts = [], []
+    for c in contigs:
+        if len(c) < 16:
+            continue
+        starts.append(len(codes))
+        codes += [fwd.get(b, 0) for b in c]
+        starts.append(len(codes))
+        codes += [rev.get(b, 0) for b in reversed(c)]
+    return codes, starts
+
+
+def test_locus_path_vs_oracle(ctx, be, synth, monkeypatch):
+    """Members confirmed along the read's locus in the assembly text (round 4): a locus match is sufficient, never necessary, so
+    every field must equal the oracle's whatever the read looks like — clean, reverse strand, across two contigs, hanging over a
+    contig's end, with indels (the diagonal is lost and found again), junk in front, N runs on either strand, a 16-mer that occurs
+    only at ANOTHER locus, repeats (the seed points at the wrong copy), chimeras, and reads that follow the TEXT across the seam
+    between two strand copies (those windows are in no contig).  The same with FLX_KMER_LOCUS=0 and with round 2's kernel."""
+    rng = np.random.RandomState(404)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rnd(n):
+        return acgt[rng.randint(0, 4, n)].tobytes()
+
+    c0 = synth["contigs"][0]
+    # a contig that holds one 16-mer of c0 with its 9th base changed: the only other place where that 16-mer occurs
+    w = bytearray(c0[5000:5016]); w[8] = ord("ACGT"[("ACGT".index(chr(w[8])) + 1) % 4])
+    c_second = rnd(700) + bytes(w) + rnd(900)
+    c_n = bytearray(rnd(4000)); c_n[1000:1040] = b"N" * 40; c_n[2000] = ord("N"); c_n[2500:2503] = b"nRY"; c_n = bytes(c_n)
+    c_rep = rnd(300) + b"A" * 200 + rnd(100) + b"AC" * 150 + rnd(100) + (rnd(23) * 40) + rnd(300)
+    c_low = rnd(1500).lower()
+    contigs = list(synth["contigs"]) + [c_second, c_n, b"ACGTACGTACGTACG", c_rep, c_low, rnd(16), rnd(17)]
+    codes, starts = _text_codes(contigs)
+    dec = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = []
+
+    def add(name, seq):
+        reads.append((name, bytes(seq), b"I" * len(seq)))
+
+    def mutate(seq, rate):
+        r = np.frombuffer(bytes(seq), dtype=np.uint8).copy()
+        sub = rng.random_sample(len(r)) < rate
+        r[sub] = acgt[rng.randint(0, 4, int(sub.sum()))]
+        return r.tobytes()
+
+    add("clean", c0[300:7300])
+    add("clean_rev", _cases.revcomp(c0[1000:6000]))
+    add("errors_3pct", mutate(c0[2000:12000], 0.03))
+    add("errors_10pct_rev", mutate(_cases.revcomp(c0[2000:9000]), 0.10))
+    add("two_contigs", c0[-1500:] + contigs[1][:1500] if len(contigs[1]) >= 1500 else c0[-1500:] + c_second)
+    add("over_the_start", rnd(700) + c0[:2500])
+    add("over_the_end", c0[-2500:] + rnd(700))
+    add("whole_contig", c_second)
+    add("whole_contig_rev", _cases.revcomp(c_second))
+    r = bytearray(c0[3000:9000])
+    for at in sorted(rng.randint(50, len(r) - 50, 25), reverse=True):  # indels of 1-3 bases
+        if rng.rand() < 0.5:
+            del r[at:at + int(rng.randint(1, 4))]
+        else:
+            r[at:at] = rnd(int(rng.randint(1, 4)))
+    add("indels", r)
+    add("deletion_37", c0[1000:3100] + c0[3137:6000])
+    add("junk_first", rnd(2300) + c0[4000:8000])
+    add("junk_middle", c0[1000:2500] + rnd(800) + c0[3300:6000])
+    add("junk_only", rnd(5000))
+    add("n_runs", c_n[500:3500])
+    add("n_runs_rev", _cases.revcomp(c_n[500:3500]))
+    add("n_as_a", c_n[500:3500].replace(b"N", b"A"))                       # on the forward strand N codes like A ...
+    add("n_as_t_rev", _cases.revcomp(c_n[500:3500].replace(b"N", b"T")))   # ... in the reverse k-mers like T (src/kmers.cpp:199-219)
+    r = bytearray(c0[4000:6500]); r[1008] = w[8]
+    add("second_locus_only", r)                                            # [1000, 1016) is a member only through c_second
+    add("second_locus_rev", _cases.revcomp(bytes(r)))
+    add("repeats", c_rep)
+    add("repeats_rev", _cases.revcomp(c_rep))
+    add("homopolymer", b"A" * 3000)
+    add("lowercase", c_low[100:1400].upper())
+    add("lowercase_as_is", c_low[100:1400])
+    add("chimera", c0[100:1800] + _cases.revcomp(c_n[200:1900]) + c0[9000:10500])
+    add("sixteen", c0[77:93])
+    add("fifteen", c0[77:92])
+    add("seventeen_rev", _cases.revcomp(c0[77:94]))
+    for k, t0 in enumerate(starts[1:8]):  # follow the text across the seam between two strand copies
+        lo_, hi_ = max(0, t0 - 700 - 16 * k), min(len(codes), t0 + 900 + k)
+        add("across_seam_%d" % k, dec[np.array(codes[lo_:hi_], dtype=np.int64)].tobytes())
+        add("across_seam_short_%d" % k, dec[np.array(codes[max(0, t0 - 15 - k):t0 + 17], dtype=np.int64)].tobytes())
+    add("long_mixed", mutate(c0[:15000], 0.02) + rnd(1200) + mutate(_cases.revcomp(c0[3000:14000]), 0.06))
+
+    orc = _oracle.KmerSet(); orc.add_assembly(contigs)
+    ks = be.kmers(assembly=contigs)
+    assert len(ks) == len(orc)
+
+    def bits(v):
+        if isinstance(v, float):
+            return np.float64(v).view(np.uint64).item()
+        if isinstance(v, dict):
+            return {k: bits(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [bits(x) for x in v]
+        return v
+
+    for pkw in (dict(), dict(trim=True, split=20), dict(trim=True, split=250, window_size=100)):
+        got = be.score(reads, pkw, ks)
+        assert ctx.last_kmer_locus()
+        p = _oracle.make_params(**pkw)
+        for (name, seq, q), o in zip(reads, got):
+            wnt = _oracle.score_read(seq, q, p, orc, cap=65536)
+            assert wnt["mean_q"] == o["mean_q"] or (np.isnan(wnt["mean_q"]) and np.isnan(o["mean_q"])), (name, pkw, wnt["mean_q"], o["mean_q"])
+            assert wnt["window_q"] == o["window_q"] or (np.isnan(wnt["window_q"]) and np.isnan(o["window_q"])), (name, pkw)
+            assert (wnt["first"], wnt["last"], wnt["passed"]) == (o["first"], o["last"], o["passed"]), (name, pkw)
+            assert wnt["child_ranges"] == o["child_ranges"], (name, pkw)
+            for wc, oc in zip(wnt["children"], o["children"]):
+                assert wc["mean_q"] == oc["mean_q"] and wc["window_q"] == oc["window_q"] and wc["passed"] == oc["passed"], (name, pkw)
+        monkeypatch.setenv("FLX_KMER_LOCUS", "0")
+        plain = be.score(reads, pkw, ks)
+        assert not ctx.last_kmer_locus()
+        monkeypatch.delenv("FLX_KMER_LOCUS")
+        monkeypatch.setenv("FLX_KMER_COVER", "v2")
+        v2 = be.score(reads, pkw, ks)
+        monkeypatch.delenv("FLX_KMER_COVER")
+        for (name, _s, _q), a, b, c in zip(reads, got, plain, v2):
+            assert bits(a) == bits(b), (name, pkw, "FLX_KMER_LOCUS=0")
+            assert bits(a) == bits(c), (name, pkw, "v2")
+    # the synthetic set, every read, three ways; and a set of assembly + short reads keeps the assembly's text
+    sreads = _cases.kmer_reads(synth["contigs"])
+    for ks2 in (synth["asm"], synth["both"]):
+        a = be.score(sreads, dict(trim=True, split=100), ks2)
+        assert ctx.last_kmer_locus()
+        monkeypatch.setenv("FLX_KMER_LOCUS", "0")
+        b = be.score(sreads, dict(trim=True, split=100), ks2)
+        monkeypatch.delenv("FLX_KMER_LOCUS")
+        for (name, _s, _q), x, y in zip(sreads, a, b):
+            assert bits(x) == bits(y), name
+    be.score(sreads, {}, synth["short"])
+    assert not ctx.last_kmer_locus()  # a short-read set has no text
