@@ -64,6 +64,11 @@ const uint8_t *flx_kmerset_exact15(const flx_kmerset *set);  // 1 GiB
 //   text  uint2 per 16 bases: .x = the codes (first base in the top two bits), .y = bit k set when base k of the word is the
 //         FIRST base of a strand copy (a window must not run across such a base behind its first); kLocusPad words of padding with
 //         every .y bit set in front of the data and at least 68 behind, so that an index clamped to [0, n_alloc) is never a match
+//         .y bit 16 + k set when the 13 bases from base k of the word on lie in one strand copy and occur NOWHERE ELSE in the text
+//         (U13).  A 16-mer that contains such a 13-mer can only be a member as the window of the text around it — so a window
+//         of a read that holds a text-matching unique 13-mer and is not itself a text match is NOT a member, without any lookup:
+//         this settles most of the false candidates the 12-mer prefilter lets through next to a mismatch (they share 15, 14 or
+//         13 bases with a member, which is exactly why their 12-mers are present)
 //   seed  open addressing, key = a 16-mer of the text, value = the text position of its first base (the smallest one for a
 //         repeated 16-mer), 0xFFFFFFFF = empty; a slot is verified by comparing the text there with the key
 constexpr uint32_t kLocusPad = 2;

@@ -299,6 +299,34 @@ __global__ void __launch_bounds__(256) k_locus_text(const uint8_t *bases, const 
     put(tr, base_rev_code(c), o == len - 1);
 }
 
+// U13 (kmerset.h), two passes over every 13-base window inside a strand copy: count its value (saturating at 2: two bitmaps of
+// 4^13 bits), then mark the windows whose value was seen once
+template <int PASS>
+__global__ void __launch_bounds__(256) k_locus_u13(const uint64_t *pos_base, uint64_t n_seqs, uint64_t n_pos, uint64_t text_base,
+                                                   uint32_t *text_words, uint32_t *seen1, uint32_t *seen2) {
+    const uint64_t n_win = n_pos + 3 * n_seqs;  // 13-windows per strand copy: len - 12 = (len - 15) + 3
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_win) return;
+    uint64_t lo = 0, hi = n_seqs;
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (pos_base[mid] + 3 * mid <= g) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t p = g - (pos_base[lo] + 3 * lo);
+    const uint64_t cum = pos_base[lo] + 15 * lo;
+    const uint64_t len = (lo + 1 < n_seqs ? pos_base[lo + 1] : n_pos) - pos_base[lo] + 15;
+    for (int strand = 0; strand < 2; ++strand) {
+        const uint64_t t = text_base + 2 * cum + (strand ? len : 0) + p;
+        const uint32_t v = flx_locus_kmer_at((const uint2 *)text_words, (uint32_t)t) >> 6;  // the first 13 of the 16 codes from t on
+        if (PASS == 0) {
+            if (set_bit(seen1, v)) set_bit(seen2, v);
+        } else if (!test_bit(seen2, v)) {
+            atomicOr(text_words + 2 * ((t >> 4) + kLocusPad) + 1, 0x10000u << (uint32_t)(t & 15));
+        }
+    }
+}
+
 // one thread per 16-mer start of the batch's sequences, both strand copies: the smallest text position of every distinct 16-mer
 __global__ void __launch_bounds__(256) k_locus_seed(const uint64_t *pos_base, uint64_t n_seqs, uint64_t n_pos, uint64_t text_base,
                                                     const uint2 *text, uint32_t *seed, uint32_t mask, int shift) {
@@ -706,6 +734,27 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
                 if (n_text % 16) {
                     const uint32_t tail_bits = 0xffffu & ~((1u << (n_text % 16)) - 1u);
                     hipLaunchKernelGGL(k_set_word_bits, dim3(1), dim3(1), 0, st, s->locus_text + 2 * (kLocusPad + n_words - 1) + 1, tail_bits);
+                }
+                if (!s->has_short) {  // U13: the 13-mers that occur once (only while the text's windows ARE the set: short reads add members)
+                    flx_dbuf seen;
+                    const size_t plane = (size_t)1 << (26 - 3);
+                    FLX_CHECK(flx_dalloc(ctx, seen, 2 * plane));
+                    FLX_HIP(ctx, hipMemsetAsync(seen.p, 0, 2 * plane, st));
+                    uint32_t *seen1 = seen.as<uint32_t>(), *seen2 = seen1 + plane / 4;
+                    for (int pass = 0; pass < 2; ++pass) {
+                        tb = 0;
+                        for (auto &b : s->asm_batches) {
+                            const uint64_t n_win = b.n_pos + 3 * b.n_seqs;
+                            if (n_win && pass == 0)
+                                hipLaunchKernelGGL(k_locus_u13<0>, dim3((unsigned)((n_win + 255) / 256)), dim3(256), 0, st, b.pos_base, b.n_seqs,
+                                                   b.n_pos, tb, s->locus_text, seen1, seen2);
+                            else if (n_win)
+                                hipLaunchKernelGGL(k_locus_u13<1>, dim3((unsigned)((n_win + 255) / 256)), dim3(256), 0, st, b.pos_base, b.n_seqs,
+                                                   b.n_pos, tb, s->locus_text, seen1, seen2);
+                            tb += 2 * (b.n_pos + 15 * b.n_seqs);
+                        }
+                    }
+                    FLX_HIP(ctx, hipStreamSynchronize(st));  // (the counters go out of scope)
                 }
                 tb = 0;
                 for (auto &b : s->asm_batches) {

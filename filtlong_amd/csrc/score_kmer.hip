@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
         // LOCUS: the diagonal (wave-uniform), whether a seed is due, the text of this span / the next one, lane 63's carry
         long long diag = 0;
         bool have_diag = false, want_seed = true, carry_ok = false;
-        uint32_t c_mml = 0xffffu, c_bnd = 0xffffu, c_known15 = 0, c_twx = 0, c_twy = 0xffffu;
+        uint32_t c_mml = 0xffffu, c_bnd = 0xffffu, c_u13 = 0, c_known15 = 0, c_twx = 0, c_twy = 0xffffu;
         uint2 tw = make_uint2(0, 0xffffu), tw_next = make_uint2(0, 0xffffu);
         // the text word that holds the LAST base of the lane's 16 at this diagonal (index clamped into the padded array)
         auto text_word = [&](long long dg, int p0) -> uint2 {
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
                 }
             }
             // ---- LOCUS: members known from the text along the diagonal ----
-            uint32_t known = 0;
+            uint32_t known = 0, refuted = 0;  // refuted: not a text match, but holds a text-matching 13-mer that occurs nowhere else
             if (LOCUS) {
                 if (want_seed) {  // (wave-uniform) eight lanes look their own 16 bases up in the seed table
                     const bool tries = (lane & 7) == 3 && (valid16 >> 15);
@@ -394,7 +394,8 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
                     twl.y = __shfl_up(tw.y, 1, 64);
                     if (lane == 0) twl = carry_ok ? make_uint2(c_twx, c_twy) : text_word(diag, p0 - 16);  // (a load only behind a new seed)
                     const uint32_t t_own = __builtin_amdgcn_alignbit(twl.x, tw.x, 2 * (15 - e));
-                    uint32_t b_own = ((twl.y >> (e + 1)) | (tw.y << (15 - e))) & 0xffffu;  // bit j: my base j is the first of a strand copy
+                    uint32_t b_own = (((twl.y & 0xffffu) >> (e + 1)) | (tw.y << (15 - e))) & 0xffffu;  // bit j: my base j is the first of a strand copy
+                    const uint32_t u_own = (((twl.y >> 16) >> (e + 1)) | ((tw.y >> 16) << (15 - e))) & 0xffffu;  // bit j: a unique 13-mer of the text starts at my base j
                     const uint32_t x = lo ^ t_own;
                     uint32_t m = (x | (x >> 1)) & 0x55555555u;  // even bit 2k: the base k places from the END differs
                     m = (m | (m >> 1)) & 0x33333333u;
@@ -415,6 +416,22 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
                     q &= q >> 4;
                     q &= q >> 7;  // bit i: none at i + 1 .. i + 15 — the 16 bases from i on lie in one strand copy
                     known = ((r & q) >> 1) & valid16;  // the 16-mer ending at my position j starts at base j + 1 of the window
+                    {
+                        uint32_t uh = __shfl_up(u_own, 1, 64);
+                        if (lane == 0) uh = carry_ok ? c_u13 : 0u;
+                        uint32_t g = z & (z >> 1);
+                        g &= g >> 2;
+                        g &= g >> 4;
+                        g &= g >> 5;  // bit i: bases i .. i + 12 match the text
+                        g &= uh | (u_own << 16);  // ... and that 13-mer occurs nowhere else (U13 is only set inside one strand copy)
+                        g |= g >> 1;
+                        g |= g >> 2;  // bit i: such a 13-mer starts at base i, i + 1, i + 2 or i + 3: inside the 16 bases from i on
+                        refuted = ((g & ~(r & q)) >> 1) & valid16;
+                        // (lane 0 behind a new seed knows nothing about the 16 bases in front of it — taken for mismatches above, which is
+                        // safe for `known` and would be wrong here: only the window made of its own 16 bases can be refuted)
+                        if (lane == 0 && !carry_ok) refuted &= 0x8000u;
+                        c_u13 = __builtin_amdgcn_readlane(u_own, 63);
+                    }
                     c_mml = __builtin_amdgcn_readlane(mml, 63);
                     c_bnd = __builtin_amdgcn_readlane(b_own, 63);
                     c_twx = __builtin_amdgcn_readlane(tw.x, 63);
@@ -464,7 +481,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
             bool settled = false;
             uint32_t ltop = 0;  // far first: is the left neighbour's last 16-mer a member
             if (far_first) {
-                const bool ask15 = (valid16 >> 15) != 0 && (known >> 15) == 0;
+                const bool ask15 = (valid16 >> 15) != 0 && ((known | refuted) >> 15) == 0;
                 if (__any(ask15)) probe(ask15 ? 15 : -1, -1, valid16);
                 ltop = __shfl_up(hits >> 15, 1, 64);
                 if (lane == 0) ltop = c_hit15;
@@ -510,6 +527,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
             if (!HAS_PREFILTER) p12_left = 0x1fu;
             const uint32_t m12 = (p12_left >> 1) | (p12 << 4);  // bit i: the 12-mer ending at p0 - 4 + i
             uint32_t cand = m12 & (m12 >> 1) & (m12 >> 2) & (m12 >> 3) & (m12 >> 4) & valid16;  // all five 12-mers present
+            if (LOCUS) cand &= ~refuted;
             if (settled) cand = hits;  // nothing open: the confirmed members are all this lane contributes
             uint32_t lcand = __shfl_up(cand >> 15, 1, 64);
             if (lane == 0) lcand = c_cand15;
