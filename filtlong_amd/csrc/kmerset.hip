@@ -704,7 +704,12 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
             n_windows += 2 * b.n_pos;
         }
         const char *lb = getenv("FLX_KMER_LOCUS_BUILD");
-        if (n_windows > 0 && n_text <= (1ull << 28) && !(lb && lb[0] == '0')) {
+        if (s->has_short && sz > 0 && !(lb && lb[0] == '0')) {
+            // a set with short reads in it: the members themselves as a text (pathtext.hip) — every member is a window of it, so
+            // U13 holds there too; an assembly underneath is part of the same graph
+            FLX_CHECK(flx_build_path_text(ctx, s->present, (const uint8_t *)s->exact15, sz, &s->locus_text, &s->locus_seed, &s->locus));
+            s->has_locus = s->locus_text != nullptr;
+        } else if (n_windows > 0 && n_text <= (1ull << 28) && !(lb && lb[0] == '0')) {
             const uint64_t n_words = (n_text + 15) / 16;
             const uint64_t n_alloc = n_words + kLocusPad + 68;
             int bits = 10;
@@ -735,7 +740,7 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
                     const uint32_t tail_bits = 0xffffu & ~((1u << (n_text % 16)) - 1u);
                     hipLaunchKernelGGL(k_set_word_bits, dim3(1), dim3(1), 0, st, s->locus_text + 2 * (kLocusPad + n_words - 1) + 1, tail_bits);
                 }
-                if (!s->has_short) {  // U13: the 13-mers that occur once (only while the text's windows ARE the set: short reads add members)
+                {  // U13: the 13-mers that occur once
                     flx_dbuf seen;
                     const size_t plane = (size_t)1 << (26 - 3);
                     FLX_CHECK(flx_dalloc(ctx, seen, 2 * plane));

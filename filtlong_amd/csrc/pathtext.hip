@@ -1,0 +1,261 @@
+// pathtext.hip — a 16-mer set without an assembly (short reads, src/kmers.cpp:142-166) as a TEXT for the locus path of the cover
+// kernel (kmerset.h: flx_locus; score_kmer.hip: k_kmer_cover_w<.., LOCUS>).
+//
+// The locus path needs a text in which every 16-base window inside one piece is a member, and — for the refutation by unique
+// 13-mers — in which every member IS such a window.  An assembly is that text for its own 16-mers.  For any other set the
+// members are the edges of a de Bruijn graph over 15-mers (member x.C enters node C, member C.y leaves it; exact15 holds both
+// nibbles per node), and a decomposition of the edges into PATHS gives the pieces: at every node the i-th entering member (in
+// the order of its first base) is continued by the i-th leaving member (in the order of its last base), entering members
+// without a partner end their path, leaving members without one start a path.  Every member lies on exactly one path (or on
+// a cycle: every member of a cycle becomes a path of its own), a path of m members is a piece of m + 15 bases, and along a
+// genome the pairing is wrong only where a 15-mer repeats — about every 200 bases of a 5 Mbp genome, where the cover kernel
+// seeds again inside the span.  Everything runs on the device: ranks from a popcount index of the bitmap, predecessor links,
+// pointer jumping to (head, distance), lengths, offsets by an exclusive scan, the text, U13, the seed table.
+#include <vector>
+
+#include "flx_internal.h"
+#include "kmerset.h"
+#include "rank_internal.h"
+
+namespace {
+
+__device__ __forceinline__ bool pt_test_bit(const uint32_t *bm, uint32_t k) { return (bm[k >> 5] >> (k & 31)) & 1u; }
+__device__ __forceinline__ bool pt_set_bit(uint32_t *bm, uint32_t k) {
+    const uint32_t m = 1u << (k & 31);
+    return (atomicOr(&bm[k >> 5], m) & m) != 0;
+}
+
+// members per 256 bits of the bitmap (2^24 blocks)
+__global__ void __launch_bounds__(256) k_pt_count256(const uint32_t *bm, int64_t *cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 a = reinterpret_cast<const uint4 *>(bm)[2 * (size_t)i], b = reinterpret_cast<const uint4 *>(bm)[2 * (size_t)i + 1];
+    cnt[i] = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+}
+
+// index of member v among the members in increasing order
+__device__ __forceinline__ uint32_t pt_rank(const uint32_t *bm, const int64_t *pre256, uint32_t v) {
+    const uint32_t w = v >> 5;
+    uint32_t r = (uint32_t)pre256[v >> 8];
+    for (uint32_t k = w & ~7u; k < w; ++k) r += __popc(bm[k]);
+    return r + __popc(bm[w] & ((1u << (v & 31)) - 1u));
+}
+
+__global__ void __launch_bounds__(256) k_pt_members(const uint32_t *bm, const int64_t *pre256, uint32_t *members) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t at = (uint32_t)pre256[i];
+    for (uint32_t k = 0; k < 8; ++k) {
+        uint32_t w = bm[8 * (size_t)i + k];
+        while (w) {
+            const int b = __ffs(w) - 1;
+            w &= w - 1;
+            members[at++] = ((8u * i + k) << 5) | (uint32_t)b;
+        }
+    }
+}
+
+// predecessor on the path of every member (itself: the member starts a path)
+__global__ void __launch_bounds__(256) k_pt_pred(const uint32_t *bm, const int64_t *pre256, const uint8_t *exact15, const uint32_t *members,
+                                                 uint32_t n, uint32_t *link, uint32_t *dist) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t e = members[i];
+    const uint32_t node = e >> 2, y = e & 3u;  // e leaves the node of its first 15 bases with its last base y
+    const uint32_t byte = exact15[node];
+    const uint32_t out_rank = __popc((byte >> 4) & ((1u << y) - 1u));
+    uint32_t in_mask = byte & 15u;
+    uint32_t p = i;
+    if (out_rank < (uint32_t)__popc(in_mask)) {
+        for (uint32_t k = 0; k < out_rank; ++k) in_mask &= in_mask - 1;
+        const uint32_t x = (uint32_t)(__ffs(in_mask) - 1);
+        const uint32_t pe = (x << 30) | node;  // the entering member x.node
+        if (pe != e) p = pt_rank(bm, pre256, pe);
+    }
+    link[i] = p;
+    dist[i] = p == i ? 0u : 1u;
+}
+
+__global__ void __launch_bounds__(256) k_pt_jump(uint32_t n, const uint32_t *link_in, const uint32_t *dist_in, uint32_t *link_out, uint32_t *dist_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = link_in[i];
+    dist_out[i] = dist_in[i] + dist_in[p];
+    link_out[i] = link_in[p];
+}
+
+// after the jumps link[i] is the head of i's path — unless i lies on a cycle, where no member points at itself: such members become
+// paths of their own.  Then the longest distance per head.
+__global__ void __launch_bounds__(256) k_pt_heads(uint32_t n, uint32_t *link, uint32_t *dist, uint32_t *len) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = link[i];
+    if (link[h] != h) {  // (reads its neighbours' links of the jump phase: the rewrite goes to `len`'s kernel below, not here)
+        dist[i] = 0x80000000u;  // marked; resolved in k_pt_lengths
+    }
+}
+__global__ void __launch_bounds__(256) k_pt_lengths(uint32_t n, uint32_t *link, uint32_t *dist, uint32_t *len) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (dist[i] & 0x80000000u) {
+        link[i] = i;
+        dist[i] = 0;
+    }
+    atomicMax(&len[link[i]], dist[i] + 1u);
+}
+__global__ void __launch_bounds__(256) k_pt_piece_bases(uint32_t n, const uint32_t *link, const uint32_t *len, int64_t *bases) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bases[i] = link[i] == i ? (int64_t)len[i] + 15 : 0;
+}
+
+__device__ __forceinline__ void pt_put(uint32_t *text_words, uint64_t t, uint32_t code, bool starts_piece) {
+    uint32_t *w = text_words + 2 * ((t >> 4) + kLocusPad);
+    if (code) atomicOr(w, code << (30 - 2 * (uint32_t)(t & 15)));
+    if (starts_piece) atomicOr(w + 1, 1u << (uint32_t)(t & 15));
+}
+
+__global__ void __launch_bounds__(256) k_pt_text(uint32_t n, const uint32_t *members, const uint32_t *link, const uint32_t *dist, const int64_t *off,
+                                                 uint32_t *text_words) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t e = members[i];
+    const uint64_t o = (uint64_t)off[link[i]];
+    pt_put(text_words, o + 15 + dist[i], e & 3u, false);
+    if (dist[i] == 0) {
+        for (int j = 0; j < 15; ++j) pt_put(text_words, o + j, (e >> (30 - 2 * j)) & 3u, j == 0);
+    }
+}
+
+// U13 (kmerset.h): every member's first 13 bases, and behind the last member of a piece the three 13-mers that follow
+template <int PASS>
+__global__ void __launch_bounds__(256) k_pt_u13(uint32_t n, const uint32_t *members, const uint32_t *link, const uint32_t *dist, const uint32_t *len,
+                                                const int64_t *off, uint32_t *text_words, uint32_t *seen1, uint32_t *seen2) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t e = members[i], h = link[i];
+    const uint64_t t = (uint64_t)off[h] + dist[i];
+    const int extra = dist[i] + 1 == len[h] ? 3 : 0;
+    for (int k = 0; k <= extra; ++k) {
+        const uint32_t v = (e >> (6 - 2 * k)) & 0x3FFFFFFu;
+        if (PASS == 0) {
+            if (pt_set_bit(seen1, v)) pt_set_bit(seen2, v);
+        } else if (!pt_test_bit(seen2, v)) {
+            atomicOr(text_words + 2 * (((t + k) >> 4) + kLocusPad) + 1, 0x10000u << (uint32_t)((t + k) & 15));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_pt_seed(uint32_t n, const uint32_t *members, const uint32_t *link, const uint32_t *dist, const int64_t *off,
+                                                 const uint2 *text, uint32_t *seed, uint32_t mask, int shift) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = members[i];
+    const uint32_t t = (uint32_t)((uint64_t)off[link[i]] + dist[i]);
+    uint32_t h = flx_locus_hash(k, shift);
+    for (;;) {
+        const uint32_t old = atomicCAS(&seed[h], kLocusEmpty, t);
+        if (old == kLocusEmpty) break;
+        if (flx_locus_kmer_at(text, old) == k) {  // (cannot happen: every member is the window of one text position)
+            atomicMin(&seed[h], t);
+            break;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+__global__ void k_pt_set_word_bits(uint32_t *word, uint32_t bits) { *word |= bits; }
+
+}  // namespace
+
+// Builds text + seed table for the members of `present` (n_members of them; exact15 is their pair table).  On success the caller
+// owns *text_out / *seed_out (hipFree) and `loc` describes them; returns FLX_OK with *text_out == nullptr when the set is too
+// large for it or the device memory is not there (the scoring path works without).
+int flx_build_path_text(flx_ctx *ctx, const uint32_t *present, const uint8_t *exact15, uint64_t n_members, uint32_t **text_out,
+                        uint32_t **seed_out, flx_locus *loc) {
+    *text_out = nullptr;
+    *seed_out = nullptr;
+    if (n_members == 0 || n_members > (1ull << 27)) return FLX_OK;
+    hipStream_t st = ctx->stream;
+    const uint32_t n = (uint32_t)n_members;
+    const uint32_t nb = (n + 255) / 256;
+    const uint64_t n_blocks = 1ull << 24;
+    flx_dbuf d_cnt, d_pre, d_members, d_link0, d_link1, d_dist0, d_dist1, d_len, d_bases, d_off, d_ws;
+    const size_t ws_bytes = std::max(flx_radix_sort_workspace(n_blocks + 1), flx_radix_sort_workspace((uint64_t)n + 1));
+    auto alloc = [&](flx_dbuf &b, size_t bytes) { return hipMalloc(&b.p, bytes) == hipSuccess; };
+    if (!alloc(d_cnt, (n_blocks + 1) * 8) || !alloc(d_pre, (n_blocks + 1) * 8) || !alloc(d_members, (size_t)n * 4) || !alloc(d_link0, (size_t)n * 4) ||
+        !alloc(d_link1, (size_t)n * 4) || !alloc(d_dist0, (size_t)n * 4) || !alloc(d_dist1, (size_t)n * 4) || !alloc(d_len, (size_t)n * 4) ||
+        !alloc(d_bases, ((size_t)n + 1) * 8) || !alloc(d_off, ((size_t)n + 1) * 8) || !alloc(d_ws, ws_bytes)) {
+        (void)hipGetLastError();
+        return FLX_OK;
+    }
+    flx_time_begin(ctx, "flx_kmerset_locus_build");
+    FLX_HIP(ctx, hipMemsetAsync(d_cnt.p, 0, (n_blocks + 1) * 8, st));
+    hipLaunchKernelGGL(k_pt_count256, dim3((unsigned)(n_blocks / 256)), dim3(256), 0, st, present, d_cnt.as<int64_t>());
+    FLX_CHECK(flx_exclusive_scan_i64(ctx, n_blocks + 1, d_cnt.as<int64_t>(), d_pre.as<int64_t>(), d_ws.p, ws_bytes));
+    hipLaunchKernelGGL(k_pt_members, dim3((unsigned)(n_blocks / 256)), dim3(256), 0, st, present, d_pre.as<int64_t>(), d_members.as<uint32_t>());
+    hipLaunchKernelGGL(k_pt_pred, dim3(nb), dim3(256), 0, st, present, d_pre.as<int64_t>(), exact15, d_members.as<uint32_t>(), n, d_link0.as<uint32_t>(),
+                       d_dist0.as<uint32_t>());
+    uint32_t *link = d_link0.as<uint32_t>(), *link2 = d_link1.as<uint32_t>(), *dist = d_dist0.as<uint32_t>(), *dist2 = d_dist1.as<uint32_t>();
+    int rounds = 1;
+    while ((1ull << rounds) < (uint64_t)n + 1) ++rounds;
+    for (int r = 0; r < rounds; ++r) {
+        hipLaunchKernelGGL(k_pt_jump, dim3(nb), dim3(256), 0, st, n, link, dist, link2, dist2);
+        std::swap(link, link2);
+        std::swap(dist, dist2);
+    }
+    FLX_HIP(ctx, hipMemsetAsync(d_len.p, 0, (size_t)n * 4, st));
+    hipLaunchKernelGGL(k_pt_heads, dim3(nb), dim3(256), 0, st, n, link, dist, d_len.as<uint32_t>());
+    hipLaunchKernelGGL(k_pt_lengths, dim3(nb), dim3(256), 0, st, n, link, dist, d_len.as<uint32_t>());
+    FLX_HIP(ctx, hipMemsetAsync(d_bases.p, 0, ((size_t)n + 1) * 8, st));
+    hipLaunchKernelGGL(k_pt_piece_bases, dim3(nb), dim3(256), 0, st, n, link, d_len.as<uint32_t>(), d_bases.as<int64_t>());
+    FLX_CHECK(flx_exclusive_scan_i64(ctx, (uint64_t)n + 1, d_bases.as<int64_t>(), d_off.as<int64_t>(), d_ws.p, ws_bytes));
+    int64_t n_text = 0;
+    FLX_HIP(ctx, hipMemcpyAsync(&n_text, d_off.as<int64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    FLX_HIP(ctx, hipStreamSynchronize(st));
+    if (n_text <= 0 || (uint64_t)n_text > (1ull << 28)) {
+        flx_time_end(ctx);
+        return FLX_OK;
+    }
+    const uint64_t n_words = ((uint64_t)n_text + 15) / 16;
+    const uint64_t n_alloc = n_words + kLocusPad + 68;
+    int bits = 10;
+    while ((1ull << bits) < (uint64_t)n * 5 / 2) ++bits;
+    const uint64_t slots = 1ull << bits;
+    uint32_t *text = nullptr, *seed = nullptr;
+    flx_dbuf seen;
+    const size_t plane = (size_t)1 << (26 - 3);
+    if (hipMalloc((void **)&text, n_alloc * 8) != hipSuccess || hipMalloc((void **)&seed, slots * 4) != hipSuccess || !alloc(seen, 2 * plane)) {
+        if (text) (void)hipFree(text);
+        if (seed) (void)hipFree(seed);
+        (void)hipGetLastError();
+        flx_time_end(ctx);
+        return FLX_OK;
+    }
+    FLX_HIP(ctx, hipMemsetAsync(text, 0, n_alloc * 8, st));
+    std::vector<uint32_t> pad_front(2 * kLocusPad), pad_back(2 * 68);
+    for (size_t i = 0; i < pad_front.size(); i += 2) { pad_front[i] = 0; pad_front[i + 1] = 0xffffu; }
+    for (size_t i = 0; i < pad_back.size(); i += 2) { pad_back[i] = 0; pad_back[i + 1] = 0xffffu; }
+    FLX_HIP(ctx, hipMemcpyAsync(text, pad_front.data(), pad_front.size() * 4, hipMemcpyHostToDevice, st));
+    FLX_HIP(ctx, hipMemcpyAsync(text + 2 * (kLocusPad + n_words), pad_back.data(), pad_back.size() * 4, hipMemcpyHostToDevice, st));
+    FLX_HIP(ctx, hipMemsetAsync(seed, 0xff, slots * 4, st));
+    FLX_HIP(ctx, hipMemsetAsync(seen.p, 0, 2 * plane, st));
+    hipLaunchKernelGGL(k_pt_text, dim3(nb), dim3(256), 0, st, n, d_members.as<uint32_t>(), link, dist, d_off.as<int64_t>(), text);
+    if (n_text % 16)
+        hipLaunchKernelGGL(k_pt_set_word_bits, dim3(1), dim3(1), 0, st, text + 2 * (kLocusPad + n_words - 1) + 1, 0xffffu & ~((1u << (n_text % 16)) - 1u));
+    uint32_t *seen1 = seen.as<uint32_t>(), *seen2 = seen1 + plane / 4;
+    hipLaunchKernelGGL(k_pt_u13<0>, dim3(nb), dim3(256), 0, st, n, d_members.as<uint32_t>(), link, dist, d_len.as<uint32_t>(), d_off.as<int64_t>(), text, seen1, seen2);
+    hipLaunchKernelGGL(k_pt_u13<1>, dim3(nb), dim3(256), 0, st, n, d_members.as<uint32_t>(), link, dist, d_len.as<uint32_t>(), d_off.as<int64_t>(), text, seen1, seen2);
+    hipLaunchKernelGGL(k_pt_seed, dim3(nb), dim3(256), 0, st, n, d_members.as<uint32_t>(), link, dist, d_off.as<int64_t>(), (const uint2 *)text, seed,
+                       (uint32_t)(slots - 1), 32 - bits);
+    flx_time_end(ctx);
+    FLX_HIP(ctx, hipGetLastError());
+    FLX_HIP(ctx, hipStreamSynchronize(st));
+    loc->text = (const uint2 *)text;
+    loc->n_alloc = (uint32_t)n_alloc;
+    loc->n_text = (uint64_t)n_text;
+    loc->seed = seed;
+    loc->seed_mask = (uint32_t)(slots - 1);
+    loc->seed_shift = 32 - bits;
+    *text_out = text;
+    *seed_out = seed;
+    return FLX_OK;
+}

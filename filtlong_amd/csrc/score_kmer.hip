@@ -25,6 +25,9 @@
 #ifndef FLX_COVER_THREADS
 #define FLX_COVER_THREADS 256  // threads per workgroup of k_kmer_cover_w (its waves are independent)
 #endif
+#ifndef FLX_LOCUS_SEEDS
+#define FLX_LOCUS_SEEDS 4  // seed attempts per span of the locus path (score_kmer.hip, below)
+#endif
 #ifndef FLX_FARFIRST_LANES
 #define FLX_FARFIRST_LANES 16  // settled lanes of a span from which the next span asks the exact table first (score_kmer.hip, below)
 #endif
@@ -302,7 +305,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
         bool far_first = false;  // this span asks the exact table BEFORE the prefilter (decided by the previous span, below)
         // LOCUS: the diagonal (wave-uniform), whether a seed is due, the text of this span / the next one, lane 63's carry
         long long diag = 0;
-        bool have_diag = false, want_seed = true, carry_ok = false;
+        bool have_diag = false, carry_ok = false;
         uint32_t c_mml = 0xffffu, c_bnd = 0xffffu, c_u13 = 0, c_known15 = 0, c_twx = 0, c_twy = 0xffffu;
         uint2 tw = make_uint2(0, 0xffffu), tw_next = make_uint2(0, 0xffffu);
         // the text word that holds the LAST base of the lane's 16 at this diagonal (index clamped into the padded array)
@@ -359,8 +362,74 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
             // ---- LOCUS: members known from the text along the diagonal ----
             uint32_t known = 0, refuted = 0;  // refuted: not a text match, but holds a text-matching 13-mer that occurs nowhere else
             if (LOCUS) {
-                if (want_seed) {  // (wave-uniform) eight lanes look their own 16 bases up in the seed table
-                    const bool tries = (lane & 7) == 3 && (valid16 >> 15);
+                // my 16 bases against the text along `diag` (tw = the word that holds the last of them): adds to known / refuted
+                auto compare = [&]() {
+                    const int e = (int)((diag + p0 + 15) & 15);  // index of my last base in my word
+                    uint2 twl;
+                    twl.x = __shfl_up(tw.x, 1, 64);
+                    twl.y = __shfl_up(tw.y, 1, 64);
+                    if (lane == 0) twl = carry_ok ? make_uint2(c_twx, c_twy) : text_word(diag, p0 - 16);  // (a load only behind a new seed)
+                    const uint32_t t_own = __builtin_amdgcn_alignbit(twl.x, tw.x, 2 * (15 - e));
+                    const uint32_t b_own = (((twl.y & 0xffffu) >> (e + 1)) | (tw.y << (15 - e))) & 0xffffu;  // bit j: my base j is the first of a piece
+                    const uint32_t u_own = (((twl.y >> 16) >> (e + 1)) | ((tw.y >> 16) << (15 - e))) & 0xffffu;  // bit j: a unique 13-mer starts at my base j
+                    const uint32_t x = lo ^ t_own;
+                    uint32_t m = (x | (x >> 1)) & 0x55555555u;  // even bit 2k: the base k places from the END differs
+                    m = (m | (m >> 1)) & 0x33333333u;
+                    m = (m | (m >> 2)) & 0x0f0f0f0fu;
+                    m = (m | (m >> 4)) & 0x00ff00ffu;
+                    m = (m | (m >> 8)) & 0xffffu;
+                    const uint32_t mml = __brev(m) >> 16;  // bit j: my base j differs from the text
+                    uint32_t mmh = __shfl_up(mml, 1, 64), bh = __shfl_up(b_own, 1, 64), uh = __shfl_up(u_own, 1, 64);
+                    if (lane == 0) { mmh = carry_ok ? c_mml : 0xffffu; bh = carry_ok ? c_bnd : 0xffffu; uh = carry_ok ? c_u13 : 0u; }
+                    const uint32_t z = ~(mmh | (mml << 16));  // bit i: base i of the window [p0 - 16, p0 + 16) matches
+                    uint32_t r = z & (z >> 1);
+                    r &= r >> 2;
+                    r &= r >> 4;
+                    r &= r >> 8;  // bit i: bases i .. i + 15 match
+                    uint32_t q = ~(bh | (b_own << 16)) >> 1;  // bit i: no piece starts at base i + 1
+                    q &= q >> 1;
+                    q &= q >> 2;
+                    q &= q >> 4;
+                    q &= q >> 7;  // bit i: none at i + 1 .. i + 15 — the 16 bases from i on lie in one piece of the text
+                    r &= q;
+                    known |= (r >> 1) & valid16;  // the 16-mer ending at my position j starts at base j + 1 of the window
+                    uint32_t g = z & (z >> 1);
+                    g &= g >> 2;
+                    g &= g >> 4;
+                    g &= g >> 5;  // bit i: bases i .. i + 12 match the text
+                    g &= uh | (u_own << 16);  // ... and that 13-mer occurs nowhere else (U13 is only set inside one piece)
+                    g |= g >> 1;
+                    g |= g >> 2;  // bit i: such a 13-mer starts at base i, i + 1, i + 2 or i + 3: inside the 16 bases from i on
+                    uint32_t rf = ((g & ~r) >> 1) & valid16;
+                    // (lane 0 behind a new seed knows nothing about the 16 bases in front of it — taken for mismatches above, which is
+                    // safe for `known` and would be wrong here: only the window made of its own 16 bases can be refuted)
+                    if (lane == 0 && !carry_ok) rf &= 0x8000u;
+                    refuted |= rf;
+                    c_u13 = __builtin_amdgcn_readlane(u_own, 63);
+                    c_mml = __builtin_amdgcn_readlane(mml, 63);
+                    c_bnd = __builtin_amdgcn_readlane(b_own, 63);
+                    c_twx = __builtin_amdgcn_readlane(tw.x, 63);
+                    c_twy = __builtin_amdgcn_readlane(tw.y, 63);
+                    carry_ok = true;
+                };
+                // The carried diagonal is tested for nothing.  Then, while at least three lanes behind the last lane with a known
+                // member hold 16-mers nothing is known about (junk, an indel, the end of a piece of the text, the wrong copy of a
+                // repeat), two of them look their own 16 bases up in the seed table — eight lanes spread over the span when nothing
+                // is known at all; a seed on another diagonal is compared in turn, what it confirms adds to what is known.
+                const unsigned long long whole = __ballot((valid16 >> 15) != 0);  // lanes that hold a whole 16-mer of the read
+                bool again = have_diag;
+                for (int seeds_left = FLX_LOCUS_SEEDS;;) {
+                    if (again) compare();
+                    const unsigned long long kn = __ballot(known != 0);
+                    const unsigned long long tail = kn ? whole & ~((2ull << (63 - __clzll(kn))) - 1ull) : whole;
+                    if (seeds_left-- == 0 || __popcll(tail) < 3) break;
+                    bool tries;
+                    if (kn) {
+                        const unsigned long long t1 = tail & (tail - 1), t2 = t1 & (t1 - 1);  // without its first lane / first two lanes
+                        tries = lane == __ffsll(t1) - 1 || lane == __ffsll(t2) - 1;
+                    } else {
+                        tries = (lane & 7) == 3 && ((whole >> lane) & 1ull);
+                    }
                     uint32_t tpos = kLocusEmpty;
                     if (tries) {
                         uint32_t h = flx_locus_hash(lo, loc.seed_shift);
@@ -373,74 +442,16 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
                         }
                     }
                     const unsigned long long found = __ballot(tpos != kLocusEmpty);
-                    if (found) {
-                        const int src = __ffsll(found) - 1;
-                        const long long nd = (long long)__builtin_amdgcn_readlane(tpos, src) - (long long)((sp << 10) + src * 16);
-                        if (!have_diag || nd != diag) {
-                            diag = nd;
-                            have_diag = true;
-                            carry_ok = false;
-                            tw = text_word(diag, p0);
-                            if (sp + 1 < n_spans) tw_next = text_word(diag, p0 + 1024);
-                        }
-                    }
-                    want_seed = false;
-                }
-                if (have_diag) {
-                    // my 16 bases of the text: the tail of the left lane's word and the head of mine (e = index of my last base in my word)
-                    const int e = (int)((diag + p0 + 15) & 15);
-                    uint2 twl;
-                    twl.x = __shfl_up(tw.x, 1, 64);
-                    twl.y = __shfl_up(tw.y, 1, 64);
-                    if (lane == 0) twl = carry_ok ? make_uint2(c_twx, c_twy) : text_word(diag, p0 - 16);  // (a load only behind a new seed)
-                    const uint32_t t_own = __builtin_amdgcn_alignbit(twl.x, tw.x, 2 * (15 - e));
-                    uint32_t b_own = (((twl.y & 0xffffu) >> (e + 1)) | (tw.y << (15 - e))) & 0xffffu;  // bit j: my base j is the first of a strand copy
-                    const uint32_t u_own = (((twl.y >> 16) >> (e + 1)) | ((tw.y >> 16) << (15 - e))) & 0xffffu;  // bit j: a unique 13-mer of the text starts at my base j
-                    const uint32_t x = lo ^ t_own;
-                    uint32_t m = (x | (x >> 1)) & 0x55555555u;  // even bit 2k: the base k places from the END differs
-                    m = (m | (m >> 1)) & 0x33333333u;
-                    m = (m | (m >> 2)) & 0x0f0f0f0fu;
-                    m = (m | (m >> 4)) & 0x00ff00ffu;
-                    m = (m | (m >> 8)) & 0xffffu;
-                    uint32_t mml = __brev(m) >> 16;  // bit j: my base j differs from the text
-                    uint32_t mmh = __shfl_up(mml, 1, 64), bh = __shfl_up(b_own, 1, 64);
-                    if (lane == 0) { mmh = carry_ok ? c_mml : 0xffffu; bh = carry_ok ? c_bnd : 0xffffu; }
-                    const uint32_t z = ~(mmh | (mml << 16));  // bit i: base i of the window [p0 - 16, p0 + 16) matches
-                    uint32_t r = z & (z >> 1);
-                    r &= r >> 2;
-                    r &= r >> 4;
-                    r &= r >> 8;  // bit i: bases i .. i + 15 match
-                    uint32_t q = ~(bh | (b_own << 16)) >> 1;  // bit i: no copy starts at base i + 1
-                    q &= q >> 1;
-                    q &= q >> 2;
-                    q &= q >> 4;
-                    q &= q >> 7;  // bit i: none at i + 1 .. i + 15 — the 16 bases from i on lie in one strand copy
-                    known = ((r & q) >> 1) & valid16;  // the 16-mer ending at my position j starts at base j + 1 of the window
-                    {
-                        uint32_t uh = __shfl_up(u_own, 1, 64);
-                        if (lane == 0) uh = carry_ok ? c_u13 : 0u;
-                        uint32_t g = z & (z >> 1);
-                        g &= g >> 2;
-                        g &= g >> 4;
-                        g &= g >> 5;  // bit i: bases i .. i + 12 match the text
-                        g &= uh | (u_own << 16);  // ... and that 13-mer occurs nowhere else (U13 is only set inside one strand copy)
-                        g |= g >> 1;
-                        g |= g >> 2;  // bit i: such a 13-mer starts at base i, i + 1, i + 2 or i + 3: inside the 16 bases from i on
-                        refuted = ((g & ~(r & q)) >> 1) & valid16;
-                        // (lane 0 behind a new seed knows nothing about the 16 bases in front of it — taken for mismatches above, which is
-                        // safe for `known` and would be wrong here: only the window made of its own 16 bases can be refuted)
-                        if (lane == 0 && !carry_ok) refuted &= 0x8000u;
-                        c_u13 = __builtin_amdgcn_readlane(u_own, 63);
-                    }
-                    c_mml = __builtin_amdgcn_readlane(mml, 63);
-                    c_bnd = __builtin_amdgcn_readlane(b_own, 63);
-                    c_twx = __builtin_amdgcn_readlane(tw.x, 63);
-                    c_twy = __builtin_amdgcn_readlane(tw.y, 63);
-                    carry_ok = true;
-                    // a tail without any match: junk, an indel, the wrong copy of a repeat — the next span seeds again
-                    want_seed = (__ballot(known != 0) >> 48) == 0;
-                } else {
-                    want_seed = true;
+                    if (!found) break;
+                    const int src = __ffsll(found) - 1;
+                    const long long nd = (long long)__builtin_amdgcn_readlane(tpos, src) - (long long)((sp << 10) + src * 16);
+                    if (have_diag && nd == diag) break;  // the same locus: what is missing are mismatches, not the diagonal
+                    diag = nd;
+                    have_diag = true;
+                    carry_ok = false;
+                    tw = text_word(diag, p0);
+                    if (sp + 1 < n_spans) tw_next = text_word(diag, p0 + 1024);
+                    again = true;
                 }
             }
 

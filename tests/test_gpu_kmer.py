@@ -554,4 +554,92 @@ def test_locus_path_vs_oracle(ctx, be, synth, monkeypatch):
         for (name, _s, _q), x, y in zip(sreads, a, b):
             assert bits(x) == bits(y), name
     be.score(sreads, {}, synth["short"])
-    assert not ctx.last_kmer_locus()  # a short-read set has no text
+    assert ctx.last_kmer_locus()  # a short-read set is a text too: its de Bruijn graph cut into paths (pathtext.hip)
+
+
+def test_path_text_of_short_read_sets_vs_oracle(ctx, be, monkeypatch):
+    """A set without an assembly becomes a text by cutting the members' de Bruijn graph into paths (csrc/pathtext.hip): every
+    member is a window of exactly one piece — also at branching 15-mers (a segment that occurs three times, so the pairing of
+    entering and leaving members is wrong for some passages and the diagonal must be found again inside the span), on cycles
+    (tandem repeats: AC.., a 23-mer unit) and on the self-loop of a homopolymer.  Reads through all of that, every field against
+    the oracle and against the kernel without the text and round 2's kernel; assembly + short reads in one set as well."""
+    rng = np.random.RandomState(808)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rnd(n):
+        return acgt[rng.randint(0, 4, n)].tobytes()
+
+    seg = rnd(300)
+    unit23 = rnd(23)
+    genome = (rnd(3000) + seg + rnd(2500) + seg + rnd(1200) + b"AC" * 120 + rnd(800) + b"A" * 90 + rnd(700) + unit23 * 12 + rnd(1500) +
+              _cases.revcomp(seg) + rnd(2000))
+    # 100-mers at every 7th position, alternately as they are and reverse-complemented, split over two files: every inner 16-mer
+    # is seen about a dozen times
+    files = [[], []]
+    for k, at in enumerate(range(0, len(genome) - 100, 7)):
+        piece = genome[at:at + 100]
+        files[k % 2].append(piece if k % 3 else _cases.revcomp(piece))
+    orc = _oracle.KmerSet(); orc.add_short_reads(files[0]); orc.add_short_reads(files[1])
+    ks = be.kmers(short_files=files)
+    assert len(ks) == len(orc) and len(ks) > 20000
+
+    def mutate(seq, rate):
+        r = np.frombuffer(bytes(seq), dtype=np.uint8).copy()
+        sub = rng.random_sample(len(r)) < rate
+        r[sub] = acgt[rng.randint(0, 4, int(sub.sum()))]
+        return r.tobytes()
+
+    reads = []
+
+    def add(name, seq):
+        reads.append((name, bytes(seq), b"I" * len(seq)))
+
+    add("whole", genome)
+    add("whole_rev", _cases.revcomp(genome))
+    add("inner", genome[150:-150])
+    add("errors_2pct", mutate(genome[100:-100], 0.02))
+    add("errors_8pct_rev", mutate(_cases.revcomp(genome[100:-100]), 0.08))
+    for k, at in enumerate((2900, 3250, 5700, 6050, 7200, 7450, 8300, 9100, 9400)):  # in and out of the repeats
+        add("piece_%d" % k, genome[at:at + 1100 + 37 * k])
+        add("piece_rev_%d" % k, _cases.revcomp(genome[at + 5:at + 900 + 11 * k]))
+    add("repeat_only", seg + seg + seg)
+    add("ac", b"AC" * 700)
+    add("poly_a", b"A" * 1500)
+    add("poly_t", b"T" * 1500)
+    add("unit23", unit23 * 60)
+    add("junk", rnd(3000))
+    add("junk_then_genome", rnd(1100) + genome[1000:4000])
+    add("sixteen", genome[5000:5016])
+
+    def bits(v):
+        if isinstance(v, float):
+            return np.float64(v).view(np.uint64).item()
+        if isinstance(v, dict):
+            return {k: bits(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [bits(x) for x in v]
+        return v
+
+    both = be.kmers(assembly=[genome[:6000]], short_files=files)
+    orc_both = _oracle.KmerSet(); orc_both.add_assembly([genome[:6000]]); orc_both.add_short_reads(files[0]); orc_both.add_short_reads(files[1])
+    assert len(both) == len(orc_both)
+    for kset, oset in ((ks, orc), (both, orc_both)):
+        for pkw in (dict(), dict(trim=True, split=40), dict(trim=True, split=300, window_size=64)):
+            got = be.score(reads, pkw, kset)
+            assert ctx.last_kmer_locus()
+            p = _oracle.make_params(**pkw)
+            for (name, seq, q), o in zip(reads, got):
+                w = _oracle.score_read(seq, q, p, oset, cap=65536)
+                assert w["mean_q"] == o["mean_q"] and w["window_q"] == o["window_q"], (name, pkw, w["mean_q"], o["mean_q"])
+                assert (w["first"], w["last"], w["passed"]) == (o["first"], o["last"], o["passed"]), (name, pkw)
+                assert w["child_ranges"] == o["child_ranges"], (name, pkw)
+            monkeypatch.setenv("FLX_KMER_LOCUS", "0")
+            plain = be.score(reads, pkw, kset)
+            assert not ctx.last_kmer_locus()
+            monkeypatch.delenv("FLX_KMER_LOCUS")
+            monkeypatch.setenv("FLX_KMER_COVER", "v2")
+            v2 = be.score(reads, pkw, kset)
+            monkeypatch.delenv("FLX_KMER_COVER")
+            for (name, _s, _q), a, b, c in zip(reads, got, plain, v2):
+                assert bits(a) == bits(b), (name, pkw, "FLX_KMER_LOCUS=0")
+                assert bits(a) == bits(c), (name, pkw, "v2")
