@@ -92,8 +92,13 @@ __device__ __forceinline__ uint32_t flx_locus_kmer_at(const uint2 *text, uint32_
 }
 #endif
 // pathtext.hip: the same for a set without an assembly (its de Bruijn graph cut into paths)
-int flx_build_path_text(flx_ctx *ctx, const uint32_t *present, const uint8_t *exact15, uint64_t n_members, uint32_t **text_out,
-                        uint32_t **seed_out, flx_locus *loc);
+struct flx_seq_batch {  // sequences on the device as k_add_reference indexes them (those of at least 16 bases)
+    const uint8_t *bases;
+    const uint64_t *offsets, *pos_base;
+    uint64_t n_seqs, n_pos;
+};
+int flx_build_path_text(flx_ctx *ctx, const uint32_t *present, const uint8_t *exact15, uint64_t n_members, const flx_seq_batch *batches,
+                        size_t n_batches, uint32_t **text_out, uint32_t **seed_out, flx_locus *loc);
 const flx_locus *flx_kmerset_locus(const flx_kmerset *set);  // NULL: no assembly, too large, or switched off at build time
 
 int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_plane, uint64_t plane_bytes,

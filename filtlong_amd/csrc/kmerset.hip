@@ -660,7 +660,7 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
                 FLX_HIP(ctx, hipStreamSynchronize(st));
             }
         }
-        free_batches(s);
+        // (the sequences stay until the locus text is built, below: their 17-mers are its witnesses)
         for (uint32_t **p : {&s->seen1, &s->seen2, &s->seen3, &s->asm_only}) {
             (void)hipFree(*p);
             *p = nullptr;
@@ -707,7 +707,10 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
         if (s->has_short && sz > 0 && !(lb && lb[0] == '0')) {
             // a set with short reads in it: the members themselves as a text (pathtext.hip) — every member is a window of it, so
             // U13 holds there too; an assembly underneath is part of the same graph
-            FLX_CHECK(flx_build_path_text(ctx, s->present, (const uint8_t *)s->exact15, sz, &s->locus_text, &s->locus_seed, &s->locus));
+            std::vector<flx_seq_batch> wb;
+            for (auto *list : {&s->asm_batches, &s->short_batches})
+                for (auto &b : *list) wb.push_back({b.bases, b.offsets, b.pos_base, b.n_seqs, b.n_pos});
+            FLX_CHECK(flx_build_path_text(ctx, s->present, (const uint8_t *)s->exact15, sz, wb.data(), wb.size(), &s->locus_text, &s->locus_seed, &s->locus));
             s->has_locus = s->locus_text != nullptr;
         } else if (n_windows > 0 && n_text <= (1ull << 28) && !(lb && lb[0] == '0')) {
             const uint64_t n_words = (n_text + 15) / 16;
@@ -785,6 +788,7 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
             }
         }
         free_batches(s->asm_batches);
+        free_batches(s);
     }
     s->final_ = true;
     return FLX_OK;

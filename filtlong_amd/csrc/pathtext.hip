@@ -6,7 +6,11 @@
 // members are the edges of a de Bruijn graph over 15-mers (member x.C enters node C, member C.y leaves it; exact15 holds both
 // nibbles per node), and a decomposition of the edges into PATHS gives the pieces: at every node the i-th entering member (in
 // the order of its first base) is continued by the i-th leaving member (in the order of its last base), entering members
-// without a partner end their path, leaving members without one start a path.  Every member lies on exactly one path (or on
+// without a partner end their path, leaving members without one start a path.  Where a node has more than one entering or
+// leaving member the SEQUENCES the set was built from say which belong together: every 17-mer x.C.y of theirs whose two
+// 16-mers are members is a witness for "x.C is continued by C.y" (kept in a small hash table of the branching nodes only), and
+// witnessed pairs are matched first — then a path follows the genome through a repeated 15-mer and only ends where a whole
+// 16-mer repeats (a wrong or missing witness costs speed, never exactness: any pairing gives a valid text).  Every member lies on exactly one path (or on
 // a cycle: every member of a cycle becomes a path of its own), a path of m members is a piece of m + 15 bases, and along a
 // genome the pairing is wrong only where a 15-mer repeats — about every 200 bases of a 5 Mbp genome, where the cover kernel
 // seeds again inside the span.  Everything runs on the device: ranks from a popcount index of the bitmap, predecessor links,
@@ -53,20 +57,104 @@ __global__ void __launch_bounds__(256) k_pt_members(const uint32_t *bm, const in
     }
 }
 
+// ---- witnesses at branching nodes: bit 4 x + y of a node's entry = "a sequence holds x.C.y" ----
+struct PtWitness {
+    uint32_t *keys;  // node + 1, 0 = empty
+    uint32_t *vals;
+    uint32_t mask;
+};
+__device__ __forceinline__ uint32_t pt_node_hash(uint32_t node, uint32_t mask) { return ((node * 0x9E3779B1u) >> 7) & mask; }
+__device__ __forceinline__ bool pt_branching(uint32_t byte) { return (byte & 15u) && (byte >> 4) && (__popc(byte & 15u) > 1 || __popc(byte >> 4) > 1); }
+
+__global__ void __launch_bounds__(256) k_pt_witness(const uint8_t *bases, const uint64_t *offsets, const uint64_t *pos_base, uint64_t n_seqs,
+                                                    uint64_t n_pos, const uint8_t *exact15, PtWitness w) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_pos) return;
+    uint64_t lo = 0, hi = n_seqs;
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (pos_base[mid] <= g) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t p = g - pos_base[lo];
+    const uint64_t len = (lo + 1 < n_seqs ? pos_base[lo + 1] : n_pos) - pos_base[lo] + 15;
+    if (p + 17 > len) return;
+    const uint8_t *sq = bases + offsets[lo] + p;
+    // the 17 codes of both strands (src/kmers.cpp:176-219): forward as they come, reverse from the other end in the reverse encoder's codes
+    uint64_t f = 0, r = 0;
+    for (int j = 0; j < 17; ++j) {
+        uint32_t cf = 0, cr = 0;
+        switch (sq[j]) {
+            case 'A': case 'a': cr = 3; break;
+            case 'C': case 'c': cf = 1; cr = 2; break;
+            case 'G': case 'g': cf = 2; cr = 1; break;
+            case 'T': case 't': cf = 3; break;
+            default: break;
+        }
+        f = (f << 2) | cf;
+        r |= (uint64_t)cr << (2 * j);
+    }
+    const uint64_t two[2] = {f, r};
+    for (int q = 0; q < 2; ++q) {
+        const uint64_t v = two[q];  // 34 bits: x . C (30 bits) . y
+        const uint32_t x = (uint32_t)(v >> 32) & 3u, node = (uint32_t)(v >> 2) & 0x3FFFFFFFu, y = (uint32_t)v & 3u;
+        const uint32_t byte = exact15[node];
+        if (!pt_branching(byte) || !((byte >> x) & 1u) || !((byte >> (4 + y)) & 1u)) continue;
+        uint32_t h = pt_node_hash(node, w.mask);
+        for (int probe = 0; probe < 64; ++probe) {
+            const uint32_t old = atomicCAS(&w.keys[h], 0u, node + 1u);
+            if (old == 0u || old == node + 1u) {
+                atomicOr(&w.vals[h], 1u << (4 * x + y));
+                break;
+            }
+            h = (h + 1) & w.mask;
+        }
+    }
+}
+
+// Which entering member (first base x) is continued by the leaving member with last base y at this node: witnessed pairs first
+// (entering members in the order of x, each takes the smallest witnessed partner still free), then the rest in order.  4 = none.
+__device__ __forceinline__ uint32_t pt_partner_of_out(uint32_t byte, uint32_t wit, uint32_t y) {
+    const uint32_t in_mask = byte & 15u, out_mask = byte >> 4;
+    uint32_t taken_out = 0, matched_in = 0, answer = 4;
+    for (uint32_t x = 0; x < 4; ++x) {
+        if (!((in_mask >> x) & 1u)) continue;
+        const uint32_t c = out_mask & ((wit >> (4 * x)) & 15u) & ~taken_out;
+        if (!c) continue;
+        const uint32_t yy = (uint32_t)(__ffs(c) - 1);
+        taken_out |= 1u << yy;
+        matched_in |= 1u << x;
+        if (yy == y) answer = x;
+    }
+    if ((taken_out >> y) & 1u) return answer;
+    uint32_t free_in = in_mask & ~matched_in, free_out = out_mask & ~taken_out;
+    const uint32_t rank = __popc(free_out & ((1u << y) - 1u));
+    if (rank >= (uint32_t)__popc(free_in)) return 4;
+    for (uint32_t k = 0; k < rank; ++k) free_in &= free_in - 1;
+    return (uint32_t)(__ffs(free_in) - 1);
+}
+
 // predecessor on the path of every member (itself: the member starts a path)
 __global__ void __launch_bounds__(256) k_pt_pred(const uint32_t *bm, const int64_t *pre256, const uint8_t *exact15, const uint32_t *members,
-                                                 uint32_t n, uint32_t *link, uint32_t *dist) {
+                                                 uint32_t n, PtWitness w, uint32_t *link, uint32_t *dist) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t e = members[i];
     const uint32_t node = e >> 2, y = e & 3u;  // e leaves the node of its first 15 bases with its last base y
     const uint32_t byte = exact15[node];
-    const uint32_t out_rank = __popc((byte >> 4) & ((1u << y) - 1u));
-    uint32_t in_mask = byte & 15u;
+    uint32_t wit = 0;
+    if (pt_branching(byte)) {
+        uint32_t h = pt_node_hash(node, w.mask);
+        for (int probe = 0; probe < 64; ++probe) {
+            const uint32_t k = w.keys[h];
+            if (k == 0u) break;
+            if (k == node + 1u) { wit = w.vals[h]; break; }
+            h = (h + 1) & w.mask;
+        }
+    }
+    const uint32_t x = pt_partner_of_out(byte, wit, y);
     uint32_t p = i;
-    if (out_rank < (uint32_t)__popc(in_mask)) {
-        for (uint32_t k = 0; k < out_rank; ++k) in_mask &= in_mask - 1;
-        const uint32_t x = (uint32_t)(__ffs(in_mask) - 1);
+    if (x < 4) {
         const uint32_t pe = (x << 30) | node;  // the entering member x.node
         if (pe != e) p = pt_rank(bm, pre256, pe);
     }
@@ -169,8 +257,8 @@ __global__ void k_pt_set_word_bits(uint32_t *word, uint32_t bits) { *word |= bit
 // Builds text + seed table for the members of `present` (n_members of them; exact15 is their pair table).  On success the caller
 // owns *text_out / *seed_out (hipFree) and `loc` describes them; returns FLX_OK with *text_out == nullptr when the set is too
 // large for it or the device memory is not there (the scoring path works without).
-int flx_build_path_text(flx_ctx *ctx, const uint32_t *present, const uint8_t *exact15, uint64_t n_members, uint32_t **text_out,
-                        uint32_t **seed_out, flx_locus *loc) {
+int flx_build_path_text(flx_ctx *ctx, const uint32_t *present, const uint8_t *exact15, uint64_t n_members, const flx_seq_batch *batches,
+                        size_t n_batches, uint32_t **text_out, uint32_t **seed_out, flx_locus *loc) {
     *text_out = nullptr;
     *seed_out = nullptr;
     if (n_members == 0 || n_members > (1ull << 27)) return FLX_OK;
@@ -178,12 +266,14 @@ int flx_build_path_text(flx_ctx *ctx, const uint32_t *present, const uint8_t *ex
     const uint32_t n = (uint32_t)n_members;
     const uint32_t nb = (n + 255) / 256;
     const uint64_t n_blocks = 1ull << 24;
-    flx_dbuf d_cnt, d_pre, d_members, d_link0, d_link1, d_dist0, d_dist1, d_len, d_bases, d_off, d_ws;
+    flx_dbuf d_cnt, d_pre, d_members, d_link0, d_link1, d_dist0, d_dist1, d_len, d_bases, d_off, d_ws, d_wkeys, d_wvals;
+    const uint32_t wit_slots = 1u << 22;  // (a 5 Mbp genome has ~1e5 branching 15-mers; what does not fit is paired by order)
     const size_t ws_bytes = std::max(flx_radix_sort_workspace(n_blocks + 1), flx_radix_sort_workspace((uint64_t)n + 1));
     auto alloc = [&](flx_dbuf &b, size_t bytes) { return hipMalloc(&b.p, bytes) == hipSuccess; };
     if (!alloc(d_cnt, (n_blocks + 1) * 8) || !alloc(d_pre, (n_blocks + 1) * 8) || !alloc(d_members, (size_t)n * 4) || !alloc(d_link0, (size_t)n * 4) ||
         !alloc(d_link1, (size_t)n * 4) || !alloc(d_dist0, (size_t)n * 4) || !alloc(d_dist1, (size_t)n * 4) || !alloc(d_len, (size_t)n * 4) ||
-        !alloc(d_bases, ((size_t)n + 1) * 8) || !alloc(d_off, ((size_t)n + 1) * 8) || !alloc(d_ws, ws_bytes)) {
+        !alloc(d_bases, ((size_t)n + 1) * 8) || !alloc(d_off, ((size_t)n + 1) * 8) || !alloc(d_ws, ws_bytes) || !alloc(d_wkeys, (size_t)wit_slots * 4) ||
+        !alloc(d_wvals, (size_t)wit_slots * 4)) {
         (void)hipGetLastError();
         return FLX_OK;
     }
@@ -192,7 +282,17 @@ int flx_build_path_text(flx_ctx *ctx, const uint32_t *present, const uint8_t *ex
     hipLaunchKernelGGL(k_pt_count256, dim3((unsigned)(n_blocks / 256)), dim3(256), 0, st, present, d_cnt.as<int64_t>());
     FLX_CHECK(flx_exclusive_scan_i64(ctx, n_blocks + 1, d_cnt.as<int64_t>(), d_pre.as<int64_t>(), d_ws.p, ws_bytes));
     hipLaunchKernelGGL(k_pt_members, dim3((unsigned)(n_blocks / 256)), dim3(256), 0, st, present, d_pre.as<int64_t>(), d_members.as<uint32_t>());
-    hipLaunchKernelGGL(k_pt_pred, dim3(nb), dim3(256), 0, st, present, d_pre.as<int64_t>(), exact15, d_members.as<uint32_t>(), n, d_link0.as<uint32_t>(),
+    PtWitness wit;
+    wit.keys = d_wkeys.as<uint32_t>();
+    wit.vals = d_wvals.as<uint32_t>();
+    wit.mask = wit_slots - 1;
+    FLX_HIP(ctx, hipMemsetAsync(wit.keys, 0, (size_t)wit_slots * 4, st));
+    FLX_HIP(ctx, hipMemsetAsync(wit.vals, 0, (size_t)wit_slots * 4, st));
+    for (size_t b = 0; b < n_batches; ++b)
+        if (batches[b].n_pos)
+            hipLaunchKernelGGL(k_pt_witness, dim3((unsigned)((batches[b].n_pos + 255) / 256)), dim3(256), 0, st, batches[b].bases, batches[b].offsets,
+                               batches[b].pos_base, batches[b].n_seqs, batches[b].n_pos, exact15, wit);
+    hipLaunchKernelGGL(k_pt_pred, dim3(nb), dim3(256), 0, st, present, d_pre.as<int64_t>(), exact15, d_members.as<uint32_t>(), n, wit, d_link0.as<uint32_t>(),
                        d_dist0.as<uint32_t>());
     uint32_t *link = d_link0.as<uint32_t>(), *link2 = d_link1.as<uint32_t>(), *dist = d_dist0.as<uint32_t>(), *dist2 = d_dist1.as<uint32_t>();
     int rounds = 1;
