@@ -306,6 +306,66 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
     return out
 
 
+def verify_ranks(ctx, torch, dist, dev, rank, world, args, backend_is_nccl):
+    """Self-check of the N-rank path, behind the timed steps: every rank scores `--verify-reads` reads of
+    its own id range and takes part in the same global stage as the timed steps; rank 0 then scores ALL of those reads alone and
+    runs the single-GPU stage — pass flags, kept bases and the target must be identical.  A few seconds; outside every timing."""
+    from filtlong_amd import api, synth
+    from filtlong_amd import dist as fdist
+    nv = args.verify_reads
+    params = api.make_params(window_size=args.window_size)
+
+    def scored(n, first):
+        b = Batch(ctx, torch, dev, n, first, args.fixed_len)
+        rec = fdist.alloc_records(n, dev)
+        base = rec.data_ptr()
+        views = fdist.record_views(rec, n)
+        views[2].copy_(b.d_len)
+        torch.cuda.synchronize()
+        ctx.synth_qual_dev(synth.SEED, b.d_plane.data_ptr(), b.plane_bytes, b.d_off.data_ptr(), b.d_len.data_ptr(), b.d_ids.data_ptr(), n, profile=0)
+        ctx.score_reads_dev(b.d_plane.data_ptr(), b.plane_bytes, b.d_off.data_ptr(), b.d_len.data_ptr(), b.d_ord.data_ptr(), n, params,
+                            base, base + 8 * n, base + 20 * n)
+        return b, rec, base, views
+
+    b, rec, base, (t_mean, t_win, t_len, t_pass) = scored(nv, rank * nv)
+    cdev = dev if backend_is_nccl else "cpu"
+    tb = torch.tensor([b.bases], dtype=torch.int64, device=cdev)
+    dist.all_reduce(tb)
+    total = int(tb.item())
+    target = int(total * args.target_frac)
+    if args.global_stage == "rccl":
+        rep = ctx.rank_and_cut_comm_dev(nv, base, base + 8 * nv, base + 16 * nv, base + 20 * nv, target_bases=target, total_bases=total)
+    elif args.global_stage == "sharded":
+        rep = fdist.sharded_rank_and_cut(ctx, t_mean, t_win, t_len, t_pass, target_bases=target, total_bases=total)
+    else:
+        g_mean, g_win, g_len, g_pass, _ = fdist.gather_records(rec, nv)
+        torch.cuda.synchronize()
+        rep = ctx.rank_and_cut_dev(nv * world, g_mean.data_ptr(), g_win.data_ptr(), g_len.data_ptr(), g_pass.data_ptr(), target_bases=target,
+                                   total_bases=total)
+        t_pass.copy_(g_pass[rank * nv:(rank + 1) * nv])
+    torch.cuda.synchronize()
+    mine = t_pass.to(cdev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    out = None
+    if rank == 0:
+        flags_ranks = torch.cat([p.cpu() for p in parts]).numpy()
+        del b, rec
+        torch.cuda.empty_cache()
+        b1, rec1, base1, v1 = scored(nv * world, 0)
+        n1 = nv * world
+        rep1 = ctx.rank_and_cut_dev(n1, base1, base1 + 8 * n1, base1 + 16 * n1, base1 + 20 * n1, target_bases=target, total_bases=total)
+        torch.cuda.synchronize()
+        flags_one = v1[3].cpu().numpy()
+        bad = int((flags_ranks != flags_one).sum())
+        ok = bad == 0 and b1.bases == total and int(rep.kept_bases) == int(rep1.kept_bases) and int(rep.target_bases) == int(rep1.target_bases)
+        out = {"ok": bool(ok), "reads": n1, "ranks": world, "bases": total, "flags_differing": bad, "kept_bases_ranks": int(rep.kept_bases),
+               "kept_bases_one_gpu": int(rep1.kept_bases), "passed_reads": int(flags_one.sum()),
+               "what": "pass flags of %d reads scored and cut by %d ranks == the same reads on rank 0 alone" % (n1, world)}
+    dist.barrier()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,6 +391,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, collectives) even "
                                                               "with one rank: exercises the RCCL calls on a 1-GPU box")
     ap.add_argument("--dump-flags", default="", help="write this rank's final pass flags to <path>.rank<r>.npy (tests)")
+    ap.add_argument("--verify", action="store_true", help="N = 1: run the self-check of the N > 1 path anyway (needs --force-dist)")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the self-check behind the timed steps")
+    ap.add_argument("--verify-reads", type=int, default=200_000, help="reads per rank of the self-check")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -482,6 +545,12 @@ def main():
     if args.dump_flags:
         torch.cuda.synchronize()
         np.save("%s.rank%d.npy" % (args.dump_flags, rank), t_pass.cpu().numpy())
+    verify = None
+    if multi and not args.no_verify and (world > 1 or args.verify):
+        try:
+            verify = verify_ranks(ctx, torch, dist, dev, rank, world, args, args.backend == "nccl")
+        except Exception as e:  # (the check must not cost the line; a failure is reported in it)
+            verify = {"ok": False, "error": repr(e)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -518,6 +587,7 @@ def main():
                 "workload": "%s synthetic reads per GPU x %s, Phred-only%s, --target_bases %d (%.0f%% of bases)%s" % (
                     "{:,}".format(n), ("fixed %d bp" % args.fixed_len) if args.fixed_len else "gamma(k=4) mean 10 kbp",
                     " (wide quality profile)" if profile else "", target, args.target_frac * 100,
+                    "; C5 (80 M reads over 8 GPUs)" if (n == 10_000_000 and world == 8 and not args.fixed_len and not profile) else
                     "; C2" if (n == 10_000_000 and not args.fixed_len and not profile) else ""),
                 "reads_total": total_n, "bases_total": total_bases, "window_size": args.window_size,
                 "parallelism": ("1 GPU" if not multi else
@@ -528,6 +598,8 @@ def main():
                                 "reads sharded by count; 1 all-gather of per-read records, global stage replicated"),
                 "device": info["name"], "gpus_visible": n_dev, "launch_backend": args.backend if multi else None,
                 "rccl_ranks": ctx.L.flx_comm_world(ctx.h) if multi and args.global_stage == "rccl" else None,
+                # the one array every rank needs from every other: the mean qualities, 8 bytes per read
+                "allgather_bytes_per_rank": {"sent": 8 * n, "received": 8 * n * world} if multi else None,
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -541,6 +613,8 @@ def main():
                     "outcome": int(rep.outcome), "audited": int(rep.audited), "exact_fallback": int(rep.exact_fallback)},
             "setup_s": round(setup_s, 1),
         }
+        if verify is not None:
+            out["verify"] = verify
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_phred(args.cpu_sample_reads)
 

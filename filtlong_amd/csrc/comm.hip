@@ -33,6 +33,7 @@ struct RcclApi {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -57,6 +58,7 @@ int load_rccl(flx_ctx *ctx) {
     FLX_SYM(CommDestroy, "ncclCommDestroy")
     FLX_SYM(AllReduce, "ncclAllReduce")
     FLX_SYM(AllGather, "ncclAllGather")
+    FLX_SYM(Broadcast, "ncclBroadcast")
     FLX_SYM(GroupStart, "ncclGroupStart")
     FLX_SYM(GroupEnd, "ncclGroupEnd")
     FLX_SYM(GetErrorString, "ncclGetErrorString")
@@ -327,17 +329,40 @@ extern "C" int flx_rank_and_cut_comm_dev(flx_ctx *ctx, uint64_t n_local, const v
                                        keep_percent, total_bases, d_final_score, c->rank, c->world, passed_bases, rep);
     if (rc != FLX_NEED_REPLICATED) return rc;
 
-    // the reference's own std::sort order over ALL reads decides: every record to every rank, single-GPU stage replicated
+    // The reference's own std::sort order over ALL reads decides (NaN scores, an order-dependent tie at the cut).  The records
+    // are gathered and RANK 0 ALONE runs the single-GPU stage — its host part is a std::sort of every record on all host
+    // threads (rank.hip: exact_host_cut), and the ranks of one node share that host: eight identical sorts side by side took
+    // eight times the threads for the same answer — then the flags, the report and (if asked for) the scores are broadcast.
     flx_time_begin(ctx, "flx_comm_allgather_records");
     rc = allgather_v(ctx, d_window_q, g_win, g_padded, g_sendpad, counts, 8);
     if (rc == FLX_OK) rc = allgather_v(ctx, d_length, g_len, g_padded, g_sendpad, counts, 4);
     if (rc == FLX_OK) rc = allgather_v(ctx, d_passed, g_pass, g_padded, g_sendpad, counts, 1);
     flx_time_end(ctx);
     FLX_CHECK(rc);
-    flx_dbuf d_fs;
+    flx_dbuf d_fs, d_rep;
     if (d_final_score) FLX_CHECK(flx_dalloc(ctx, d_fs, n_total * 8));
-    FLX_CHECK(flx_rank_and_cut_dev(ctx, n_total, g_mean, g_win, g_len, g_pass, lw, mw, ww, target_bases_set, target_bases,
-                                   keep_percent_set, keep_percent, total_bases, d_final_score ? d_fs.p : nullptr, rep));
+    FLX_CHECK(flx_dalloc(ctx, d_rep, sizeof(flx_cut_report) + 8));
+    int stage_rc = FLX_OK;
+    if (c->rank == 0) {
+        stage_rc = flx_rank_and_cut_dev(ctx, n_total, g_mean, g_win, g_len, g_pass, lw, mw, ww, target_bases_set, target_bases,
+                                        keep_percent_set, keep_percent, total_bases, d_final_score ? d_fs.p : nullptr, rep);
+        int64_t head[1] = {stage_rc};
+        FLX_HIP(ctx, hipMemcpyAsync(d_rep.p, head, 8, hipMemcpyHostToDevice, st));
+        FLX_HIP(ctx, hipMemcpyAsync((char *)d_rep.p + 8, rep, sizeof(flx_cut_report), hipMemcpyHostToDevice, st));
+    }
+    flx_time_begin(ctx, "flx_comm_broadcast_outcome");
+    FLX_NCCL(ctx, g_rccl.Broadcast(d_rep.p, d_rep.p, sizeof(flx_cut_report) + 8, ncclUint8, 0, c->comm, st));
+    if (n_total) FLX_NCCL(ctx, g_rccl.Broadcast(g_pass, g_pass, n_total, ncclUint8, 0, c->comm, st));
+    if (d_final_score && n_total) FLX_NCCL(ctx, g_rccl.Broadcast(d_fs.p, d_fs.p, n_total * 8, ncclUint8, 0, c->comm, st));
+    flx_time_end(ctx);
+    {
+        int64_t head[1] = {0};
+        FLX_HIP(ctx, hipMemcpyAsync(head, d_rep.p, 8, hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipMemcpyAsync(rep, (char *)d_rep.p + 8, sizeof(flx_cut_report), hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipStreamSynchronize(st));
+        if (c->rank == 0 && stage_rc != FLX_OK) return stage_rc;
+        if (head[0] != FLX_OK) return flx_fail(ctx, (int)head[0], "the global stage failed on rank 0");
+    }
     if (n_local) {
         FLX_HIP(ctx, hipMemcpyAsync(d_passed, g_pass + first, n_local, hipMemcpyDeviceToDevice, st));
         if (d_final_score)

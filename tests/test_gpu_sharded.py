@@ -185,6 +185,10 @@ def test_bench_two_processes_one_gpu(tmp_path, stage):
     assert j["n_gpus"] == 2 and j["config"]["reads_total"] == 40000 and j["scaling"] == "weak"
     if stage == "rccl":
         assert "library-owned RCCL communicator" in j["config"]["parallelism"]
+    # the self-check behind the timed steps: 2 x 200 000 fresh reads through the same stage == rank 0 alone
+    assert j["verify"]["ok"] is True and j["verify"]["ranks"] == 2 and j["verify"]["flags_differing"] == 0, j["verify"]
+    assert 0 < j["verify"]["passed_reads"] < j["verify"]["reads"]
+    assert j["config"]["allgather_bytes_per_rank"] == {"sent": 8 * 20000, "received": 16 * 20000}
     want = np.load(one + ".rank0.npy")
     got = np.concatenate([np.load(two + ".rank%d.npy" % k) for k in range(2)])
     assert want.shape == got.shape and (want == got).all()
@@ -205,6 +209,14 @@ def test_bench_rccl_stage_single_rank(tmp_path):
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         outs.append(np.load(path + ".rank0.npy"))
     assert (outs[0] == outs[1]).all() and 0 < int(outs[0].sum()) < len(outs[0])
+    # --verify with one rank: real RCCL (ncclCommInitRank, all-gather, device all-reduces) against the plain stage on fresh reads
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--reads", "50000", "--no-cpu-baseline",
+                        "--no-extras", "--force-dist", "--global-stage", "rccl", "--verify", "--verify-reads", "60000"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert j["verify"]["ok"] is True and j["verify"]["reads"] == 60000, j["verify"]
 
 
 @pytest.mark.parametrize("shim", [True, False], ids=["library-communicator", "torch-sharded"])
@@ -234,6 +246,7 @@ def test_bench_starts_its_own_ranks(tmp_path, shim):
     assert j["config"]["launch_backend"] == "gloo" and "comm" in j["stage_ms_per_step"]
     if shim:
         assert j["config"]["rccl_ranks"] == 2 and "library-owned RCCL communicator" in j["config"]["parallelism"]
+    assert j["verify"]["ok"] is True and j["verify"]["reads"] == 400000, j.get("verify")
     want = np.load(one + ".rank0.npy")
     got = np.concatenate([np.load(two + ".rank%d.npy" % k) for k in range(2)])
     assert want.shape == got.shape and (want == got).all() and 0 < int(want.sum()) < len(want)
