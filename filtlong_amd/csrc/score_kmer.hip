@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
 
             // ---- 12-mer prefilter: pair m = positions p0 + 2m, p0 + 2m + 1; x.C.y = the 13 bases ending at p0 + 2m + 1 ----
             uint32_t p12 = 0xffffu;  // (a settled lane: every 12-mer of its last 16-mer is present, the others are not needed)
-            if (HAS_PREFILTER && !settled) {
+            if (HAS_PREFILTER && !LOCUS && !settled) {
                 uint32_t byte[8], sel[8];
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
 #ifdef FLX_ABL_NOL2
                     byte[m] = 0xffu;  // ablation: no prefilter lookups (every 12-mer "present")
 #else
-                    byte[m] = (!LOCUS || ((need12 >> (2 * m)) & 3u)) ? pre11[q.index] : 0xffu;
+                    byte[m] = pre11[q.index];
 #endif
                     sel[m] = q.even_bit | (q.odd_bit << 8);
                 }
@@ -530,7 +530,53 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
 #pragma unroll
                 for (int m = 0; m < 8; ++m)
                     p12 |= (((byte[m] >> (sel[m] & 0xffu)) & 1u) | (((byte[m] >> (sel[m] >> 8)) & 1u) << 1)) << (2 * m);
-                if (LOCUS) p12 |= ~need12 & 0xffffu;
+            }
+            if (HAS_PREFILTER && LOCUS) {
+                // In TWO rounds: a 16-mer is out as soon as ONE of its five 12-mers is absent, and what is left to look up holds a
+                // mismatch against the text, so it is absent more often than not.  Round 1 fetches the even pairs (positions 0 1,
+                // 4 5, 8 9, 12 13) where needed; every 16-mer holds two or three of those positions, so most are out after it.
+                // Round 2 fetches an odd pair only if one of the six 16-mers that hold its 12-mers — five of them may be the right
+                // neighbour's — is still alive under the assumption that every 12-mer not yet seen is present.  A pair that is
+                // skipped keeps that assumption: it only concerns 16-mers that are out anyway.
+                auto fetch = [&](uint32_t want, int parity) -> uint32_t {  // actual bits of the pairs m = parity, parity + 2, .. that hold a wanted position; 1 elsewhere
+                    uint32_t byte[4], sel[4], got = 0xffffu;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int m = 2 * k + parity;
+                        const uint32_t a = __builtin_amdgcn_alignbit(hi, lo, 28 - 4 * m);
+                        const flx_pre11_slot q = flx_pre11((a >> 2) & 0x3FFFFFu, (a >> 24) & 3u, a & 3u);
+#ifdef FLX_ABL_NOL2
+                        byte[k] = 0xffu;
+#else
+                        byte[k] = ((want >> (2 * m)) & 3u) ? pre11[q.index] : 0xffu;
+#endif
+                        sel[k] = q.even_bit | (q.odd_bit << 8);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int m = 2 * k + parity;
+                        const uint32_t two = ((byte[k] >> (sel[k] & 0xffu)) & 1u) | (((byte[k] >> (sel[k] >> 8)) & 1u) << 1);
+                        if ((want >> (2 * m)) & 3u) got &= ~(3u << (2 * m)) | (two << (2 * m));
+                    }
+                    return got;
+                };
+                const uint32_t want = settled ? 0u : (need12 & valid12);
+                p12 = fetch(want & 0x3333u, 0);
+                {
+                    const uint32_t v1 = p12 & valid12;
+                    uint32_t l1 = __shfl_up(v1 >> 11, 1, 64);
+                    if (lane == 0) l1 = c_p12;
+                    const uint32_t m1 = (l1 >> 1) | (v1 << 4);
+                    uint32_t alive = m1 & (m1 >> 1) & (m1 >> 2) & (m1 >> 3) & (m1 >> 4) & valid16 & ~refuted;
+                    if (settled) alive = 0;  // (a settled lane asks nothing; its neighbours' 16-mers that reach into it count below)
+                    uint32_t right = __shfl_down(alive, 1, 64);
+                    if (lane == 63) right = 0xffffu;  // the next span's first lane is not known yet
+                    uint32_t dep = alive | (right << 16);
+                    dep |= dep >> 1;
+                    dep |= dep >> 2;
+                    dep |= dep >> 1;  // bit q: one of the 16-mers ending at q .. q + 4 (those that hold the 12-mer ending at q) is alive
+                    p12 &= fetch(want & 0xCCCCu & dep, 1);
+                }
             }
             p12 &= valid12;
             uint32_t p12_left = __shfl_up(p12 >> 11, 1, 64);  // the left lane's 12-mers ending at its positions 11..15 = mine at -5..-1
