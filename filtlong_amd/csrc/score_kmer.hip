@@ -678,6 +678,7 @@ struct FoldArgs {
     const int32_t *last;
     int ws;
     int ring_words;  // RING kernels: words per lane in the LDS ring (a power of two)
+    int events;      // FLX_KMER_FOLD_EVENTS=1: the steady state walks the positions where the window's edges differ (measured: not faster)
     double ws_d;
     double delta;  // fl(1.0 / ws): the value of q/ws for a covered base (src/read.cpp:228-229)
     double clamp;  // 0.5 / ws
@@ -984,6 +985,41 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
               tw = sh ? __builtin_amdgcn_alignbit(trail_word(twi + 1), t0, (unsigned)sh) : t0;
           }
           P.cnt += __popc(lead_w);
+          if (a.events) {
+              // Round-3 review, item 5: only the positions where the two edges DIFFER change w for certain (one exact step each);
+              // where both are 0 nothing happens, and where both are 1 the step is fl(fl(w - d) + d), which is w itself unless the
+              // subtraction leaves w's binade — checked once per stretch of such positions, with the 32-step loop below as the
+              // fallback for a word where it fails.  Lanes diverge (a wave runs as many rounds as its busiest lane has events).
+              const double w0 = P.w, mn0 = P.mn;
+              const uint32_t both = lead_w & tw;
+              uint32_t ev = lead_w ^ tw, handled = 0;
+              bool slow = false;
+              for (;;) {
+                  const int i = ev ? __ffs(ev) - 1 : 32;
+                  const uint32_t upto = i == 32 ? 0xffffffffu : ((1u << i) - 1u);
+                  if (both & upto & ~handled) {
+                      double t = P.w - delta;
+                      t = t + delta;
+                      if (t != P.w) { slow = true; break; }
+                  }
+                  if (i == 32) break;
+                  if ((lead_w >> i) & 1u) {
+                      P.w = P.w + delta;
+                  } else {
+                      P.w = P.w - delta;
+                      P.mn = fmin(P.mn, P.w);
+                  }
+                  handled = upto | (1u << i);
+                  ev &= ev - 1;
+              }
+              if (!__any(slow)) continue;
+              if (!slow) {
+                  lead_w = tw = 0;  // (this lane is done with the word: 32 exact no-ops below)
+              } else {
+                  P.w = w0;
+                  P.mn = mn0;
+              }
+          }
 #pragma unroll
           for (int i = 0; i < 32; ++i) {
 #if FLX_FOLD_FMA
@@ -1180,8 +1216,9 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     {
         const unsigned grid = (unsigned)std::min<uint64_t>(n_reads, 1u << 20);
         const char *cover_env = getenv("FLX_KMER_COVER");  // "v2": round 2's workgroup-per-read kernel (second implementation)
-        const bool old_cover = cover_env && strcmp(cover_env, "v2") == 0;
+        const bool old_cover = (cover_env && strcmp(cover_env, "v2") == 0) || !flx_kmerset_exact15(set);  // (no pair table: finalize found no room for it)
         flx_time_begin(ctx, "flx_score_kmer_cover");
+        ctx->last_kmer_locus = false;
         if (!old_cover) {
             const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + FLX_COVER_THREADS / 64 - 1) / (FLX_COVER_THREADS / 64), 1u << 22);
             const char *locus_env = getenv("FLX_KMER_LOCUS");  // "0": without the assembly text (the round-3 kernel; tests, A/B)
@@ -1234,6 +1271,10 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
         a.clamp = half / wsd;
     }
     a.p = *params;
+    {
+        const char *ev_env = getenv("FLX_KMER_FOLD_EVENTS");
+        a.events = ev_env && ev_env[0] == '1';
+    }
     a.mean_q = out->mean_q;
     a.window_q = out->window_q;
     a.passed = out->passed;

@@ -287,6 +287,11 @@ def test_prefilter_and_fold_variants_give_identical_results(be, synth, monkeypat
             monkeypatch.setenv("FLX_KMER_FOLD_STREAMS", "global")
             glob_ = be.score(reads, pk, ks)
             monkeypatch.delenv("FLX_KMER_FOLD_STREAMS")
+            monkeypatch.setenv("FLX_KMER_FOLD_EVENTS", "1")  # the steady state by events (positions where the window's edges differ)
+            events = be.score(reads, pk, ks)
+            monkeypatch.delenv("FLX_KMER_FOLD_EVENTS")
+            for (name, _s, _q), a, b in zip(reads, ring, events):
+                assert bits(a) == bits(b), (name, ws, split, "events")
             monkeypatch.setenv("FLX_KMER_FOLD", "words")
             words = be.score(reads, pk, ks)
             monkeypatch.setenv("FLX_KMER_FOLD", "bits")
@@ -643,3 +648,29 @@ def test_path_text_of_short_read_sets_vs_oracle(ctx, be, monkeypatch):
             for (name, _s, _q), a, b, c in zip(reads, got, plain, v2):
                 assert bits(a) == bits(b), (name, pkw, "FLX_KMER_LOCUS=0")
                 assert bits(a) == bits(c), (name, pkw, "v2")
+
+
+def test_set_without_room_for_the_pair_table(ctx, be, synth, monkeypatch):
+    """flx_kmerset_finalize without the 1 GiB pair table (the allocation failed; FLX_KMER_PAIRTABLE=0 plays that): no error, the
+    set scores through the kernel that asks the bitmap, every field the same (advisor, round 3)."""
+    reads = _cases.kmer_reads(synth["contigs"])
+    pkw = dict(trim=True, split=100)
+    want = be.score(reads, pkw, synth["asm"])
+    monkeypatch.setenv("FLX_KMER_PAIRTABLE", "0")
+    ks = be.kmers(assembly=synth["contigs"])
+    ks2 = be.kmers(short_files=synth["sr"])
+    monkeypatch.delenv("FLX_KMER_PAIRTABLE")
+    assert len(ks) == len(synth["asm"]) and len(ks2) == len(synth["short"])
+    got = be.score(reads, pkw, ks)
+    assert not ctx.last_kmer_locus()
+
+    def key(o):
+        return (np.float64(o["mean_q"]).view(np.uint64).item(), np.float64(o["window_q"]).view(np.uint64).item(), o["first"], o["last"], o["passed"],
+                o["child_ranges"])
+
+    for (name, _s, _q), a, b in zip(reads, want, got):
+        assert key(a) == key(b), name
+    want2 = be.score(reads, pkw, synth["short"])
+    got2 = be.score(reads, pkw, ks2)
+    for (name, _s, _q), a, b in zip(reads, want2, got2):
+        assert key(a) == key(b), name
