@@ -415,13 +415,16 @@ int flx_launch_score_phred(flx_ctx *ctx, const uint8_t *d_plane, uint64_t plane_
     const bool force_direct = env && strcmp(env, "direct") == 0;
     const bool force_ring = env && strcmp(env, "ring") == 0;
     const bool force_stream = env && strcmp(env, "stream") == 0;
+    const bool force_dual = env && strcmp(env, "dual") == 0;
     if (force_stream) return flx_launch_score_phred_stream(ctx, a);
-    if (!force_direct && !force_ring) {  // default: the register-history kernel, where the window size has an instantiation
+    if (force_dual) return flx_launch_score_phred_dual(ctx, a);
+    if (!force_direct && !force_ring) {  // default: the register-history kernel, where the window size has an instantiation ...
         bool launched = false;
         a.n_slots = 0;
         a.stride = 0;
         FLX_CHECK(flx_launch_score_phred_regs(ctx, a, &launched));
         if (launched) return FLX_OK;
+        return flx_launch_score_phred_dual(ctx, a);  // ... and the dual-slot kernel beyond (window sizes from 624 on, any size)
     }
 
     if (waves >= 1 && !force_direct) {

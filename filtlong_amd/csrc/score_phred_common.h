@@ -96,3 +96,5 @@ __device__ __forceinline__ void finish_read(const PhredArgs &a, uint32_t rid, in
 int flx_launch_score_phred_regs(flx_ctx *ctx, flx_phred::PhredArgs a, bool *launched);
 // score_phred_regs.hip: any window size, both window edges streamed from global memory (used where the LDS ring does not fit)
 int flx_launch_score_phred_stream(flx_ctx *ctx, flx_phred::PhredArgs a);
+// score_phred_regs.hip: any window size, the trailing edge as a second LDS-DMA stream (nothing of the window stays on chip)
+int flx_launch_score_phred_dual(flx_ctx *ctx, flx_phred::PhredArgs a);

@@ -487,6 +487,198 @@ __global__ void __launch_bounds__(1024) flx_score_phred_stream(const PhredArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dual-slot kernel (round 4): ANY window size at one price.  The register-history kernel keeps the last window_size bytes of
+// every read on chip, which costs occupancy from ws = 640 on (one wave per SIMD: 0.21-0.23 of the roofline) and stops at 1007;
+// the LDS ring behind it falls to 0.16 and the stream kernel to 0.06.  Here NOTHING of the window stays on chip: the trailing
+// edge is a second LDS-DMA stream over the same bytes, `ws` behind the leading one (served by the L2 / Infinity Cache, the
+// plane still crosses the HBM once).  Per wave: the leading slot of the register-history kernel (one 128-byte chunk of each
+// of its 64 reads, 8 KiB) and a ring of four 4-KiB half slots for the trailing stream (64 bytes of every read each): the two
+// halves a round of 64 bases reads from, and the next two already on their way.  24 KiB per wave -> 6 waves per CU whatever
+// the window.  Same arithmetic, same table gathers, plain tables.
+//
+// DMA bookkeeping (vmcnt counts DMA instructions in order): every round issues its trailing half FIRST (4 instructions,
+// always — a half that does not exist reads offset 0 and is never used), every odd round ends with the next leading chunk
+// (8 instructions).  An even round needs the chunk issued at the end of the round before it: all but the 4 youngest
+// instructions done.  An odd round needs the half issued two rounds earlier: all but the 8 youngest.
+// ---------------------------------------------------------------------------------------------------------------------
+// NH = half slots of the trailing ring: 4 (the next two halves on their way, 24 KiB per wave, 6 waves per CU) or 3 (one half
+// ahead, 20 KiB, 7 waves)
+#ifndef FLX_DUAL_NH
+#define FLX_DUAL_NH 3
+#endif
+constexpr int DUAL_NH = FLX_DUAL_NH;
+constexpr int DUAL_WAVES = DUAL_NH == 4 ? 6 : 7;
+__global__ void __launch_bounds__(DUAL_WAVES * 64) flx_score_phred_dual(const PhredArgs a) {
+    using T = Tab<false>;
+    constexpr int LEAD_BYTES = 8192, TRAIL_BYTES = 4096 * DUAL_NH, WAVE_BYTES = LEAD_BYTES + TRAIL_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    for (int i = threadIdx.x; i < 257; i += DUAL_WAVES * 64) {
+        *reinterpret_cast<double *>(smem + T::QOFF + i * 8) = a.lut_q[i];
+        *reinterpret_cast<double *>(smem + T::DOFF + i * 8) = a.lut_d[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    unsigned char *lead_slot = smem + T::SLOT0 + wave * WAVE_BYTES;
+    unsigned char *trail_ring = lead_slot + LEAD_BYTES;
+    const uint32_t lead_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(T::SLOT0 + wave * WAVE_BYTES));
+    const uint32_t trail_lds = lead_lds + LEAD_BYTES;
+    const int rot = lane >> 2;
+    const uint32_t zaddr = (uint32_t)(T::ZIDX * T::ROW);
+    const int ws = a.ws;
+    const int A = ws >> 4, B = ws & 15;
+    const int fD = (16 - B) >> 2;
+    const uint32_t fsh = (uint32_t)(16 - B) & 3u;
+    const double ws_d = a.ws_d;
+    const int t0 = ((3 - A) >> 2) + DUAL_NH - 2;  // the trailing half round 0 issues (round r: t0 + r); halves below it go out before the loop
+
+    for (;;) {
+        unsigned int group = 0;
+        if (lane == 0) group = atomicAdd(a.ticket, 1u);
+        group = (unsigned int)__builtin_amdgcn_readfirstlane((int)group);
+        if (group >= a.n_groups) break;
+        const uint64_t gslot = (uint64_t)group * 64 + lane;
+        const bool live = gslot < a.n_reads;
+        uint32_t rid = 0;
+        int L = 0;
+        uint64_t base = 0;
+        if (live) {
+            rid = a.order ? a.order[gslot] : (uint32_t)gslot;
+            L = a.lengths[rid];
+            base = a.offsets[rid];
+        }
+        const int Lmax = wave_max(L);
+        const int Lmin = wave_min(L);
+        if (Lmax == 0) {
+            if (live) finish_read(a, rid, L, 0.0, 0.0);
+            continue;
+        }
+        const int n_rounds = (Lmax + 63) >> 6;
+        // DMA map of this lane (as in the register-history kernel): for m = 0..3 piece `dq` of read 16 m + (lane >> 2)
+        const int dq = ((lane & 3) - (lane >> 4)) & 3;
+        const uint8_t *gsrc[4];
+        int lim[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int r = m * 16 + (lane >> 2);
+            const uint32_t lo = __shfl((uint32_t)base, r, 64);
+            const uint32_t hi = __shfl((uint32_t)(base >> 32), r, 64);
+            const int Lr = __shfl(L, r, 64);
+            // a read without bytes (or no read at all) points at the start of the plane: every DMA instruction is issued by every
+            // lane, so that the instruction counts behind the vmcnt waits hold
+            gsrc[m] = Lr > 0 ? a.plane + ((((uint64_t)hi << 32) | lo) + (uint64_t)(dq * 16)) : a.plane;
+            lim[m] = Lr > 0 ? ((Lr + 15) & ~15) - dq * 16 : 0;
+        }
+        auto lds_idle = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+        auto issue_lead = [&](int c) {  // 8 instructions
+            lds_idle();
+            const int o = c * 128;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                dma16(gsrc[m] + (o < lim[m] ? o : 0), lead_lds + m * 1024);
+                dma16(gsrc[m] + (o + 64 < lim[m] ? o + 64 : 0), lead_lds + 4096 + m * 1024);
+            }
+        };
+        auto issue_trail = [&](int h) {  // 4 instructions; h < 0 or behind the reads: a harmless fetch of offset 0
+            lds_idle();
+            const int o = h * 64;
+            const uint32_t dst = trail_lds + (uint32_t)(((h % DUAL_NH) + DUAL_NH) % DUAL_NH) * 4096u;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) dma16(gsrc[m] + ((o >= 0 && o < lim[m]) ? o : 0), dst + m * 1024);
+        };
+
+        double s = 0.0, w = 0.0, mn = 0.0;
+        uint32_t carry[4] = {0, 0, 0, 0};  // the trailing piece in front of the round's four
+        issue_lead(0);
+        for (int h = 0; h < t0; ++h) issue_trail(h);
+        for (int r = 0; r < n_rounds; ++r) {
+            issue_trail(t0 + r);
+            if (DUAL_NH == 3 || (r & 1) == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (NH = 3: the half this round reads was issued one round ago)
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // the round's four leading pieces and four trailing pieces (stream pieces 4 r - A .. 4 r - A + 3; below 0: nothing yet)
+            uint32_t lw[4][4], tr[5][4];
+            const unsigned char *lrow = lead_slot + (r & 1) * 4096 + lane * 64;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(lrow + (((k + rot) & 3) << 4));
+                lw[k][0] = v.x; lw[k][1] = v.y; lw[k][2] = v.z; lw[k][3] = v.w;
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) tr[0][d] = carry[d];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = 4 * r - A + k;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (q >= 0) v = *reinterpret_cast<const uint4 *>(trail_ring + ((q >> 2) % DUAL_NH) * 4096 + lane * 64 + ((((q & 3) + rot) & 3) << 4));
+                tr[k + 1][0] = v.x; tr[k + 1][1] = v.y; tr[k + 1][2] = v.z; tr[k + 1][3] = v.w;
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) carry[d] = tr[4][d];
+            if ((r & 1) && r + 1 < n_rounds) issue_lead((r + 1) >> 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int Tp = 4 * r + k;
+                if (16 * Tp >= Lmax) break;
+                const bool masked = 16 * (Tp + 1) > Lmin;
+                const int rem = L - 16 * Tp;
+                if (Tp < A) {  // all 16 positions < window_size: only the running sum
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        uint32_t aj[4];
+                        aj[0] = tab_addr<false, 0>(lw[k][d], 0); aj[1] = tab_addr<false, 1>(lw[k][d], 0);
+                        aj[2] = tab_addr<false, 2>(lw[k][d], 0); aj[3] = tab_addr<false, 3>(lw[k][d], 0);
+                        if (masked) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) aj[i] = (4 * d + i) < rem ? aj[i] : zaddr;
+                        }
+                        head4<T::QOFF>(aj[0], aj[1], aj[2], aj[3], s);
+                    }
+                    if (Tp == A - 1 && B == 0) {
+                        w = s / ws_d;
+                        mn = w;
+                    }
+                    continue;
+                }
+                uint32_t tw[4];
+                funnel(tr[k], tr[k + 1], fD, fsh, tw);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    uint32_t aj[4], ai[4];
+                    aj[0] = tab_addr<false, 0>(lw[k][d], 0); aj[1] = tab_addr<false, 1>(lw[k][d], 0);
+                    aj[2] = tab_addr<false, 2>(lw[k][d], 0); aj[3] = tab_addr<false, 3>(lw[k][d], 0);
+                    ai[0] = tab_addr<false, 0>(tw[d], 0); ai[1] = tab_addr<false, 1>(tw[d], 0);
+                    ai[2] = tab_addr<false, 2>(tw[d], 0); ai[3] = tab_addr<false, 3>(tw[d], 0);
+                    if (masked || Tp == A) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bool act = (4 * d + i) < rem;
+                            aj[i] = act ? aj[i] : zaddr;
+                            ai[i] = act ? ai[i] : zaddr;
+                        }
+                    }
+                    if (Tp > A) {
+                        fold4<T::QOFF, T::DOFF>(aj[0], aj[1], aj[2], aj[3], ai[0], ai[1], ai[2], ai[3], s, w, mn);
+                    } else {  // the piece that holds position window_size (src/read.cpp:219-224)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int kk = 4 * d + i;
+                            if (kk < B) head1<T::QOFF>(aj[i], s);
+                            else fold1<T::QOFF, T::DOFF>(aj[i], ai[i], s, w, mn);
+                            if (kk == B - 1) {
+                                w = s / ws_d;
+                                mn = w;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last rounds' fetches must not land in the next group's slots)
+        if (live) finish_read(a, rid, L, s, mn);
+    }
+}
+
 // reads flagged by the bank-private variant (a byte >= 128): exact re-scoring, one lane per read
 __global__ void __launch_bounds__(256) flx_score_phred_redo(const PhredArgs a) {
     __shared__ double lq[LUT_PAD];
@@ -545,7 +737,7 @@ int launch_one(flx_ctx *ctx, PhredArgs &a) {
 // 256 + 102 registers at ws = 1007); the bank-private tables (66 KB) leave room for 11 slots of 8 KiB
 template <int A, bool PRIV>
 struct WavesFor {
-    static constexpr int plain = A <= 7 ? 16 : A <= 15 ? 12 : A <= 38 ? 8 : 4;
+    static constexpr int plain = A <= 7 ? 16 : A <= 15 ? 12 : 8;
     static constexpr int value = PRIV && plain > 11 ? 11 : plain;
 };
 
@@ -596,12 +788,13 @@ int flx_launch_score_phred_regs_part5(flx_ctx *ctx, PhredArgs &a, bool priv, boo
     switch (a.ws / 16) { FLX_REGS_CASE(28) FLX_REGS_CASE(29) FLX_REGS_CASE(30) FLX_REGS_CASE(31) default: return FLX_OK; }
 }
 #else
-// parts 6..13: four ring sizes each, A = 32 + 4 (part - 6) ..: window sizes 512..1007
+// parts 6 and 7: A = 32..35 and 36..38: window sizes 512..623 (beyond them a ring leaves room for one wave per SIMD only, and the
+// dual-slot kernel is faster)
 int FLX_REGS_WIDE_NAME(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched) {
     constexpr int A0 = 32 + 4 * (FLX_REGS_PART - 6);
     switch (a.ws / 16) {
         FLX_REGS_CASE(A0) FLX_REGS_CASE(A0 + 1) FLX_REGS_CASE(A0 + 2)
-#if FLX_REGS_PART < 13
+#if FLX_REGS_PART < 7
         FLX_REGS_CASE(A0 + 3)
 #endif
         default: return FLX_OK;
@@ -617,7 +810,7 @@ int flx_launch_score_phred_regs_part3(flx_ctx *ctx, PhredArgs &a, bool priv, boo
 int flx_launch_score_phred_regs_part4(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
 int flx_launch_score_phred_regs_part5(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
 #define FLX_REGS_DECL(P) int flx_launch_score_phred_regs_part##P(flx_ctx *ctx, PhredArgs &a, bool priv, bool *launched);
-FLX_REGS_DECL(6) FLX_REGS_DECL(7) FLX_REGS_DECL(8) FLX_REGS_DECL(9) FLX_REGS_DECL(10) FLX_REGS_DECL(11) FLX_REGS_DECL(12) FLX_REGS_DECL(13)
+FLX_REGS_DECL(6) FLX_REGS_DECL(7)
 #undef FLX_REGS_DECL
 
 namespace {
@@ -656,10 +849,27 @@ int flx_launch_score_phred_stream(flx_ctx *ctx, PhredArgs a) {
     return FLX_OK;
 }
 
+int flx_launch_score_phred_dual(flx_ctx *ctx, PhredArgs a) {
+    void *scr;
+    FLX_CHECK(flx_scratch(ctx, 64, &scr));
+    FLX_HIP(ctx, hipMemsetAsync(scr, 0, 8, ctx->stream));
+    a.ticket = (unsigned int *)scr;
+    a.n_groups = (unsigned int)((a.n_reads + 63) / 64);
+    const size_t lds = (size_t)Tab<false>::SLOT0 + (size_t)DUAL_WAVES * (8192 + 4096 * DUAL_NH);  // more than half of the LDS: one workgroup per CU
+    FLX_HIP(ctx, hipFuncSetAttribute((const void *)flx_score_phred_dual, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)a.n_groups + DUAL_WAVES - 1) / DUAL_WAVES, (uint64_t)ctx->prop.multiProcessorCount);
+    ctx->last_phred_kernel = "flx_score_phred_dual";
+    flx_time_begin(ctx, ctx->last_phred_kernel);
+    hipLaunchKernelGGL(flx_score_phred_dual, dim3(grid), dim3(DUAL_WAVES * 64), lds, ctx->stream, a);
+    flx_time_end(ctx);
+    FLX_HIP(ctx, hipGetLastError());
+    return FLX_OK;
+}
+
 int flx_launch_score_phred_regs(flx_ctx *ctx, PhredArgs a, bool *launched) {
     *launched = false;
     const int A = a.ws / 16;
-    if (A > 62) return FLX_OK;
+    if (A > 38) return FLX_OK;  // the register-history kernel serves window sizes 1 .. 623 (A = ws / 16 = 0 .. 38); beyond: the dual-slot kernel
     const char *env = getenv("FLX_PHRED_TABLES");  // "plain" | "private" | unset = decide from a sample of the data
     bool priv = env && strcmp(env, "private") == 0;
     // scratch: [0,4) ticket, [4,8) redo count, [64, 1088) sample histogram, [2048, 2048 + 4 n) redo list
@@ -701,9 +911,7 @@ int flx_launch_score_phred_regs(flx_ctx *ctx, PhredArgs a, bool *launched) {
     else if (A <= 31) FLX_CHECK(flx_launch_score_phred_regs_part5(ctx, a, priv, launched));
     else {
         typedef int (*part_fn)(flx_ctx *, PhredArgs &, bool, bool *);
-        static const part_fn wide[8] = {flx_launch_score_phred_regs_part6, flx_launch_score_phred_regs_part7, flx_launch_score_phred_regs_part8,
-                                        flx_launch_score_phred_regs_part9, flx_launch_score_phred_regs_part10, flx_launch_score_phred_regs_part11,
-                                        flx_launch_score_phred_regs_part12, flx_launch_score_phred_regs_part13};
+        static const part_fn wide[2] = {flx_launch_score_phred_regs_part6, flx_launch_score_phred_regs_part7};
         priv = false;  // big rings come with plain tables only
         FLX_CHECK(wide[(A - 32) / 4](ctx, a, priv, launched));
     }

@@ -45,15 +45,15 @@ def score_hip(ctx, reads, pkw, use_order=True):
 
 
 def select_kernel(monkeypatch, kernel):
-    """default = register-history kernel where the window size has one (1..1007, else LDS ring), table layout chosen from a
+    """default = register-history kernel where the window size has one (1..623, else the dual-slot kernel), table layout chosen from a
     sample of the data; "plain" / "private" force its table layout; "ring" / "direct" force the older kernels."""
-    if kernel in ("ring", "direct", "stream"):
+    if kernel in ("ring", "direct", "stream", "dual"):
         monkeypatch.setenv("FLX_PHRED_KERNEL", kernel)
     elif kernel in ("private", "plain"):
         monkeypatch.setenv("FLX_PHRED_TABLES", kernel)
 
 
-@pytest.mark.parametrize("kernel", ["default", "plain", "private", "ring", "direct", "stream"])
+@pytest.mark.parametrize("kernel", ["default", "plain", "private", "ring", "direct", "stream", "dual"])
 def test_golden_synth_phred(ctx, kernel, monkeypatch):
     select_kernel(monkeypatch, kernel)
     gold = json.load(open(os.path.join(_cases.GOLDEN, "probe_synth_phred.json")))
@@ -146,15 +146,19 @@ def _instantiation_reads(ws, rng):
     return reads
 
 
+REGS_MAX_A = 38  # the register-history kernel serves window sizes 1 .. 623; from 624 on the dual-slot kernel runs (round 4)
+
+
 def _instantiation_window_sizes():
-    """Every instantiation A = ws / 16 = 0..62 of flx_score_phred_regs with the remainders B = ws % 16 in {0, 1, 15}, the
-    switch points of the wave occupancy classes (A = 7|8, 15|16, 38|39) with every remainder, and the end of the kernel's range."""
+    """Every instantiation A = ws / 16 = 0..38 of flx_score_phred_regs with the remainders B = ws % 16 in {0, 1, 15}, the
+    switch points of the wave occupancy classes (A = 7|8, 15|16) and of the plain-only rings (31|32) with every remainder, and
+    the end of the kernel's range (A = 38) — plus the first window sizes of the dual-slot kernel behind it."""
     wss = set()
-    for A in range(63):
+    for A in range(REGS_MAX_A + 1):
         for B in (0, 1, 15):
             if 16 * A + B >= 1:
                 wss.add(16 * A + B)
-    for A in (7, 8, 15, 16, 31, 32, 38, 39, 62):
+    for A in (7, 8, 15, 16, 31, 32, 38, 39):
         wss.update(range(16 * A, 16 * A + 16))
     wss.discard(0)
     return sorted(wss)
@@ -162,11 +166,12 @@ def _instantiation_window_sizes():
 
 @pytest.mark.parametrize("part", range(8))
 def test_regs_kernel_every_instantiation(ctx, part, monkeypatch):
-    """All 63 instantiations of the register-history kernel: each A is its own unroll / ring-index /
-    register-allocation product of the compiler, incl. the VGPR+AGPR rings for ws >= 624.  For every window size of
+    """All 39 instantiations of the register-history kernel (round 3 had 63, the rings for ws >= 624 — VGPR +
+    AGPR, one wave per SIMD — gave way to the dual-slot kernel): each A is its own unroll / ring-index / register-allocation
+    product of the compiler.  For every window size of
     `_instantiation_window_sizes()`: one oracle pass, then the plain and (A < 32) the bank-private tables, both processing
-    orders — and the test asserts that the register-history kernel is what ran.  ws 1008 (first LDS-ring size) rides along."""
-    wss = _instantiation_window_sizes() + [1008]
+    orders — and the test asserts which kernel ran (the dual-slot kernel from ws 624 on; 1007 / 1008 ride along)."""
+    wss = _instantiation_window_sizes() + [1007, 1008]
     mine = wss[part::8]
     rng = np.random.RandomState(4000 + part)
     seen_a = set()
@@ -178,16 +183,16 @@ def test_regs_kernel_every_instantiation(ctx, part, monkeypatch):
         wm = np.array([w["mean_q"] for w in want])
         ww = np.array([w["window_q"] for w in want])
         wp = np.array([w["passed"] for w in want], dtype=np.uint8)
-        layouts = ("plain", "private") if ws < 512 else ("plain",)
+        layouts = ("plain", "private") if ws < 512 else ("plain",)  # (rings from A = 32 on and the dual-slot kernel: plain tables only)
         for li, layout in enumerate(layouts):
             monkeypatch.setenv("FLX_PHRED_TABLES", layout)
             for use_order in ((True, False) if li == 0 else (True,)):
                 o = score_hip(ctx, reads, pkw, use_order)
                 k = ctx.last_phred_kernel()
-                if ws <= 1007:
+                if ws // 16 <= REGS_MAX_A:
                     assert k == ("flx_score_phred_regs_private" if layout == "private" else "flx_score_phred_regs"), (ws, k)
                 else:
-                    assert k == "flx_score_phred_ring", (ws, k)
+                    assert k == "flx_score_phred_dual", (ws, k)
                 tag = "ws %d (A %d, B %d) %s order=%s" % (ws, ws // 16, ws % 16, layout, use_order)
                 assert_same_f64(o["mean_q"], wm, tag + " mean_q")
                 assert_same_f64(o["window_q"], ww, tag + " window_q")
@@ -198,10 +203,10 @@ def test_regs_kernel_every_instantiation(ctx, part, monkeypatch):
 
 def test_regs_instantiation_list_is_complete():
     wss = _instantiation_window_sizes()
-    for A in range(63):
+    for A in range(REGS_MAX_A + 1):
         have = {w % 16 for w in wss if w // 16 == A}
         assert {1, 15} <= have and (A == 0 or 0 in have), A
-    assert 1007 in wss and max(wss) == 1007
+    assert 623 in wss and 624 in wss
 
 
 @pytest.mark.parametrize("ws", [250, 7, 64, 333])
@@ -248,7 +253,7 @@ def test_device_generator_matches_numpy(ctx, profile):
         assert (got[o + L:o + ((L + 15) & ~15)] == 0).all()
 
 
-@pytest.mark.parametrize("kernel", ["default", "stream"])
+@pytest.mark.parametrize("kernel", ["default", "stream", "dual"])
 def test_randomised_configurations_vs_oracle(ctx, kernel, monkeypatch):
     """40 random (window_size, cut-offs, batch shape) configurations: window sizes around every 16/64-byte boundary and up
     to the ring/direct switch, batches smaller than a wave, reads shorter than the window, unsorted order."""
@@ -272,3 +277,28 @@ def test_randomised_configurations_vs_oracle(ctx, kernel, monkeypatch):
         assert_same_f64(o["mean_q"], np.array([w["mean_q"] for w in want]), "trial %d ws %d mean" % (trial, ws))
         assert_same_f64(o["window_q"], np.array([w["window_q"] for w in want]), "trial %d ws %d window" % (trial, ws))
         assert (o["passed"] == np.array([w["passed"] for w in want], dtype=np.uint8)).all(), (trial, pkw)
+
+
+@pytest.mark.parametrize("part", range(4))
+def test_dual_slot_kernel_window_sizes(ctx, part, monkeypatch):
+    """The dual-slot kernel (both window edges as LDS-DMA streams, any window size): window sizes with every remainder mod 16 and
+    mod 64 (the trailing stream's half slots), around the switch points of the other kernels (639 | 640, 1007 | 1008) and far
+    beyond them; the read set of the instantiation test (lengths around ws and every 16 / 64 / 128-byte boundary, any byte)."""
+    monkeypatch.setenv("FLX_PHRED_KERNEL", "dual")
+    wss = sorted(set(list(range(1, 70)) + list(range(120, 136)) + [249, 250, 251, 255, 256, 257, 639, 640, 641, 1000, 1007, 1008, 1009, 1023, 1024,
+                                                                     1025, 1500, 2000, 2047, 2048, 2049, 2500, 3000, 4095, 4096, 5000, 10000]))
+    rng = np.random.RandomState(6000 + part)
+    for ws in wss[part::4]:
+        reads = _instantiation_reads(ws, rng)
+        if ws >= 2000:
+            reads = reads[::2]
+        pkw = dict(window_size=ws)
+        p = _oracle.make_params(**pkw)
+        want = [_oracle.score_read(None, q, p) for _, _, q in reads]
+        for use_order in (True, False):
+            o = score_hip(ctx, reads, pkw, use_order)
+            assert ctx.last_phred_kernel() == "flx_score_phred_dual"
+            tag = "dual ws %d order=%s" % (ws, use_order)
+            assert_same_f64(o["mean_q"], np.array([w["mean_q"] for w in want]), tag + " mean_q")
+            assert_same_f64(o["window_q"], np.array([w["window_q"] for w in want]), tag + " window_q")
+            assert (o["passed"] == np.array([w["passed"] for w in want], dtype=np.uint8)).all(), tag
