@@ -28,6 +28,9 @@
 #ifndef FLX_LOCUS_SEEDS
 #define FLX_LOCUS_SEEDS 4  // seed attempts per span of the locus path (score_kmer.hip, below)
 #endif
+#ifndef FLX_LOCUS_TAIL
+#define FLX_LOCUS_TAIL 3  // lanes without a known member behind the last one that has one, from which the span seeds again
+#endif
 #ifndef FLX_FARFIRST_LANES
 #define FLX_FARFIRST_LANES 16  // settled lanes of a span from which the next span asks the exact table first (score_kmer.hip, below)
 #endif
@@ -422,7 +425,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_
                     if (again) compare();
                     const unsigned long long kn = __ballot(known != 0);
                     const unsigned long long tail = kn ? whole & ~((2ull << (63 - __clzll(kn))) - 1ull) : whole;
-                    if (seeds_left-- == 0 || __popcll(tail) < 3) break;
+                    if (seeds_left-- == 0 || __popcll(tail) < FLX_LOCUS_TAIL) break;
                     bool tries;
                     if (kn) {
                         const unsigned long long t1 = tail & (tail - 1), t2 = t1 & (t1 - 1);  // without its first lane / first two lanes

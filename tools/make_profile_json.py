@@ -10,7 +10,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PFX = sys.argv[1] if len(sys.argv) > 1 else "r03"
+PFX = sys.argv[1] if len(sys.argv) > 1 else "r04"
+KMER_READS = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000  # reads of the k-mer PMC passes
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 
@@ -40,27 +41,32 @@ def counters(path, kernel):
 
 def main():
     # ---- k-mer cover kernel: requests by class
-    bases = json.loads(open(os.path.join(P, PFX + "_kmer_requests.json")).read())["c3"]["bases"]  # 1e6 reads of the synthetic set
+    sys.path.insert(0, ROOT)
+    from filtlong_amd import synth
+    bases = int(synth.lengths(KMER_READS).astype("int64").sum())  # the synthetic set
     req = {}
     for cfg in ("c3", "c4"):
         t, _ = counters(os.path.join(G, "prof_kmer", "t_%s.txt" % cfg), "k_kmer_cover_w")
         f, _ = counters(os.path.join(G, "prof_kmer", "f_%s.txt" % cfg), "k_kmer_cover_w")
         _, ms = counters(os.path.join(G, "prof_kmer", "k_%s.txt" % cfg), "k_kmer_cover_w")
         req[cfg] = {
-            "measured_at_reads": 1000000, "bases": bases, "kernel": "k_kmer_cover_w", "kernel_source_sha16": sha16("score_kmer.hip"),
+            "measured_at_reads": KMER_READS, "bases": bases, "kernel": "k_kmer_cover_w", "kernel_source_sha16": sha16("score_kmer.hip"),
             "kernel_ms": ms, "far_requests": t["TCC_MISS_sum"], "far_requests_per_base": t["TCC_MISS_sum"] / bases,
             "l2_hit_requests": t["TCC_HIT_sum"], "l2_hit_requests_per_base": t["TCC_HIT_sum"] / bases,
             "fetch_size_kib": f["FETCH_SIZE"], "traffic_bytes": f["FETCH_SIZE"] * 1024, "traffic_bytes_per_base": f["FETCH_SIZE"] * 1024 / bases,
-            "source": "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum / FETCH_SIZE (separate passes) of `bench.py --config %s --reads 1000000 --steps 1 "
+            "source": "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum / FETCH_SIZE (separate passes) of `bench.py --config %s --reads %d --steps 1 "
                       "--warmup 0` (tools/prof_kmer.sh); FETCH_SIZE = 64 B x fabric read requests, NOT doubled: these are single 64-byte requests "
-                      "(the x2 of the guide applies to 128-byte streaming requests)" % cfg}
+                      "(the x2 of the guide applies to 128-byte streaming requests)" % (cfg, KMER_READS)}
         for d in "kftsu":
+            if not os.path.exists(os.path.join(G, "prof_kmer", "%s_%s.txt" % (d, cfg))):
+                continue
             shutil.copy(os.path.join(G, "prof_kmer", "%s_%s.txt" % (d, cfg)), os.path.join(P, "%s_kmer_%s_%s.txt" % (PFX, d, cfg)))
     json.dump(req, open(os.path.join(P, PFX + "_kmer_requests.json"), "w"), indent=1)
     # ---- C2 Phred kernel: HBM traffic
     fe, _ = counters(os.path.join(G, "final", "pmc_fetch.txt"), "flx_score_phred_regs")
     wr, _ = counters(os.path.join(G, "final", "pmc_write.txt"), "flx_score_phred_regs")
-    old = json.load(open(os.path.join(P, PFX + "_traffic_c2.json")))
+    prev = os.path.join(P, PFX + "_traffic_c2.json")
+    old = json.load(open(prev if os.path.exists(prev) else os.path.join(P, "r03_traffic_c2.json")))
     traffic = 2 * fe["FETCH_SIZE"] * 1024 + wr["WRITE_SIZE"] * 1024
     old.update({"kernel_source_sha16": sha16("score_phred_regs.hip"), "FETCH_SIZE_KiB": fe["FETCH_SIZE"], "WRITE_SIZE_KiB": wr["WRITE_SIZE"],
                 "traffic_bytes": traffic, "ratio": traffic / old["algorithmic_bytes"]})
