@@ -628,7 +628,16 @@ def test_path_text_of_short_read_sets_vs_oracle(ctx, be, monkeypatch):
     both = be.kmers(assembly=[genome[:6000]], short_files=files)
     orc_both = _oracle.KmerSet(); orc_both.add_assembly([genome[:6000]]); orc_both.add_short_reads(files[0]); orc_both.add_short_reads(files[1])
     assert len(both) == len(orc_both)
-    for kset, oset in ((ks, orc), (both, orc_both)):
+    # the text at order 24 (default: paths of the sequences' 24-mers) and at order 16 (paths of the members themselves)
+    monkeypatch.setenv("FLX_KMER_TEXT_ORDER", "16")
+    ks16 = be.kmers(short_files=files)
+    monkeypatch.delenv("FLX_KMER_TEXT_ORDER")
+    # short sequences (below 24 bases) and a set whose members mostly lie in no 24-mer at all
+    tiny = [genome[a:a + 20] for a in range(0, 4000, 3)] * 2
+    orc_tiny = _oracle.KmerSet(); orc_tiny.add_short_reads(tiny)
+    ks_tiny = be.kmers(short_files=[tiny])
+    assert len(ks_tiny) == len(orc_tiny) > 1000
+    for kset, oset in ((ks, orc), (both, orc_both), (ks16, orc), (ks_tiny, orc_tiny)):
         for pkw in (dict(), dict(trim=True, split=40), dict(trim=True, split=300, window_size=64)):
             got = be.score(reads, pkw, kset)
             assert ctx.last_kmer_locus()
