@@ -43,11 +43,17 @@ L2_LOOKUP_PEAK_G = 261.0     # tools/tabench: cache LINES per second from an L2-
 REF_LEN = 5_000_000
 
 
-def source_sha16(name):
-    """sha256[:16] of a kernel source file: figures quoted from profiles/ carry the hash of the source they were measured on."""
+def source_sha16(*names):
+    """sha256[:16] of kernel source files: figures quoted from profiles/ carry the hash of the sources they were measured on."""
     import hashlib
-    with open(os.path.join(ROOT, "filtlong_amd", "csrc", name), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for name in names:
+        with open(os.path.join(ROOT, "filtlong_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+KMER_SOURCES = ("score_kmer.hip", "kmerset.hip", "kmerset.h", "pathtext.hip")  # what the cover kernel's requests depend on (kernel + the set's tables and text)
 
 
 def _run_ref_bench(argv):
@@ -271,7 +277,7 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
     fpath = os.path.join(ROOT, "profiles", "r04_kmer_requests.json")
     if os.path.exists(fpath):
         rec = json.load(open(fpath)).get(cfg)
-        if rec and rec.get("kernel") == cover_kernel and rec.get("kernel_source_sha16") == source_sha16("score_kmer.hip"):
+        if rec and rec.get("kernel") == cover_kernel and rec.get("kernel_source_sha16") == source_sha16(*KMER_SOURCES):
             req = {"far_requests": rec["far_requests_per_base"] * b.bases, "traffic_bytes": rec["traffic_bytes_per_base"] * b.bases,
                    "l2_hits": rec["l2_hit_requests_per_base"] * b.bases}
             req_src = "profiles/r04_kmer_requests.json (PMC passes of this command at %s reads%s; not this run)" % (

@@ -16,8 +16,14 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 
 
-def sha16(name):
-    return hashlib.sha256(open(os.path.join(ROOT, "filtlong_amd", "csrc", name), "rb").read()).hexdigest()[:16]
+def sha16(*names):
+    h = hashlib.sha256()
+    for name in names:
+        h.update(open(os.path.join(ROOT, "filtlong_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+KMER_SOURCES = ("score_kmer.hip", "kmerset.hip", "kmerset.h", "pathtext.hip")  # as in bench.py
 
 
 def counters(path, kernel):
@@ -50,7 +56,7 @@ def main():
         f, _ = counters(os.path.join(G, "prof_kmer", "f_%s.txt" % cfg), "k_kmer_cover_w")
         _, ms = counters(os.path.join(G, "prof_kmer", "k_%s.txt" % cfg), "k_kmer_cover_w")
         req[cfg] = {
-            "measured_at_reads": KMER_READS, "bases": bases, "kernel": "k_kmer_cover_w", "kernel_source_sha16": sha16("score_kmer.hip"),
+            "measured_at_reads": KMER_READS, "bases": bases, "kernel": "k_kmer_cover_w", "kernel_source_sha16": sha16(*KMER_SOURCES),
             "kernel_ms": ms, "far_requests": t["TCC_MISS_sum"], "far_requests_per_base": t["TCC_MISS_sum"] / bases,
             "l2_hit_requests": t["TCC_HIT_sum"], "l2_hit_requests_per_base": t["TCC_HIT_sum"] / bases,
             "fetch_size_kib": f["FETCH_SIZE"], "traffic_bytes": f["FETCH_SIZE"] * 1024, "traffic_bytes_per_base": f["FETCH_SIZE"] * 1024 / bases,
