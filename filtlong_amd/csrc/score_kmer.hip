@@ -286,8 +286,13 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
 // may still occur elsewhere).  The diagonal comes from the seed table: eight lanes look their own 16 bases up (one far request
 // each) when the wave has none or the last 16 lanes of the previous span matched nowhere; a seed that fails leaves the old
 // diagonal in place as a hypothesis that costs nothing to test.
+// 8 waves per SIMD (63 registers instead of 68): 14.8 -> 14.3 ms per 1e10 positions; 9 and 10 are slower again (profiles/r04_microbench.txt)
+#ifndef FLX_COVER_WAVES_PER_EU
+#define FLX_COVER_WAVES_PER_EU 8
+#endif
+#define FLX_COVER_OCC __attribute__((amdgpu_waves_per_eu(FLX_COVER_WAVES_PER_EU, FLX_COVER_WAVES_PER_EU)))
 template <bool HAS_PREFILTER, bool LOCUS>
-__global__ void __launch_bounds__(FLX_COVER_THREADS) k_kmer_cover_w(const uint8_t *plane, const uint64_t *offsets, const int32_t *lengths,
+__global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_w(const uint8_t *plane, const uint64_t *offsets, const int32_t *lengths,
                                                       const uint32_t *order, uint64_t n_reads, const uint8_t *exact15,
                                                       const uint8_t *pre11, const flx_locus loc, uint32_t *cov, const uint64_t *cov_off,
                                                       int32_t *count, int32_t *first, int32_t *last) {
