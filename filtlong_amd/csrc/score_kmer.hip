@@ -287,6 +287,19 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
 // each) when the wave has none or the last 16 lanes of the previous span matched nowhere; a seed that fails leaves the old
 // diagonal in place as a hypothesis that costs nothing to test.
 // 8 waves per SIMD (63 registers instead of 68): 14.8 -> 14.3 ms per 1e10 positions; 9 and 10 are slower again (profiles/r04_microbench.txt)
+// the read plane is streamed once and the coverage rows are written once: non-temporal, so that they do not push the prefilter out of
+// the L2 (14.26 -> 13.8 ms per 1e10 positions; FLX_COVER_TEMPORAL restores plain accesses)
+__device__ __forceinline__ uint4 flx_plane16(const uint8_t *p) {
+#ifndef FLX_COVER_TEMPORAL
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 v;
+    v.x = __builtin_nontemporal_load(&q->x); v.y = __builtin_nontemporal_load(&q->y);
+    v.z = __builtin_nontemporal_load(&q->z); v.w = __builtin_nontemporal_load(&q->w);
+    return v;
+#else
+    return *reinterpret_cast<const uint4 *>(p);
+#endif
+}
 #ifndef FLX_COVER_WAVES_PER_EU
 #define FLX_COVER_WAVES_PER_EU 8
 #endif
@@ -320,7 +333,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
         auto text_word = [&](long long dg, int p0) -> uint2 {
             long long w = ((dg + p0 + 15) >> 4) + (long long)kLocusPad;
             w = w < 0 ? 0 : (w >= (long long)loc.n_alloc ? (long long)loc.n_alloc - 1 : w);
-            return loc.text[w];
+            return loc.text[w];  // (non-temporal here is slower: 14.2 vs 13.8 ms per 1e10 — a text word is used again by the next span's lane 0 and by reads of the same locus)
         };
 
         auto finalize = [&](int sp, uint32_t h, uint32_t right_of_63) {  // hits of span sp -> coverage bits, counts, row words
@@ -342,15 +355,19 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             }
             const uint32_t up = __shfl_down(c16, 1, 64);
             const int word = p0 >> 5;
+#ifndef FLX_COVER_TEMPORAL
+            if ((lane & 1) == 0 && word < row_words) __builtin_nontemporal_store(c16 | (up << 16), &row[word]);
+#else
             if ((lane & 1) == 0 && word < row_words) row[word] = c16 | (up << 16);
+#endif
         };
 
         uint4 raw = make_uint4(0, 0, 0, 0);
-        if (lane * 16 < L) raw = *reinterpret_cast<const uint4 *>(seq + lane * 16);  // rows are 16-byte aligned and padded
+        if (lane * 16 < L) raw = flx_plane16(seq + lane * 16);  // rows are 16-byte aligned and padded
         for (int sp = 0; sp < n_spans; ++sp) {
             const int p0 = (sp << 10) + lane * 16;
             uint4 raw_next = make_uint4(0, 0, 0, 0);
-            if (p0 + 1024 < L) raw_next = *reinterpret_cast<const uint4 *>(seq + p0 + 1024);
+            if (p0 + 1024 < L) raw_next = flx_plane16(seq + p0 + 1024);
             if (LOCUS && have_diag && sp + 1 < n_spans) tw_next = text_word(diag, p0 + 1024);
             // 2 bits per base, earliest base on top: lo = my 16 bases, hi = the 16 before them
             const uint32_t lo = (codes4(raw.x) << 24) | (codes4(raw.y) << 16) | (codes4(raw.z) << 8) | codes4(raw.w);
