@@ -386,6 +386,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             }
             // ---- LOCUS: members known from the text along the diagonal ----
             uint32_t known = 0, refuted = 0;  // refuted: not a text match, but holds a text-matching 13-mer that occurs nowhere else
+            uint32_t text12 = 0;              // bit j: the 12 bases ending at my position j match the text inside one piece: that 12-mer IS present
             if (LOCUS) {
                 // my 16 bases against the text along `diag` (tw = the word that holds the last of them): adds to known / refuted
                 auto compare = [&]() {
@@ -416,6 +417,18 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     q &= q >> 2;
                     q &= q >> 4;
                     q &= q >> 7;  // bit i: none at i + 1 .. i + 15 — the 16 bases from i on lie in one piece of the text
+                    {
+                        uint32_t m12 = z & (z >> 1);
+                        m12 &= m12 >> 2;
+                        m12 &= m12 >> 4;
+                        m12 &= m12 >> 4;  // bit i: bases i .. i + 11 match
+                        uint32_t q12 = ~(bh | (b_own << 16)) >> 1;
+                        q12 &= q12 >> 1;
+                        q12 &= q12 >> 2;
+                        q12 &= q12 >> 4;
+                        q12 &= q12 >> 3;  // bit i: no piece starts at i + 1 .. i + 11 (a piece has at least 16 bases: the 12-mer lies in one of its 16-mers)
+                        text12 |= ((m12 & q12) >> 5) & 0xffffu;  // the 12-mer ending at my position j starts at base j + 5
+                    }
                     r &= q;
                     known |= (r >> 1) & valid16;  // the 16-mer ending at my position j starts at base j + 1 of the window
                     uint32_t g = z & (z >> 1);
@@ -535,6 +548,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 const int from = a > 4 ? a - 4 : 0;
                 need12 = ~(((2u << b) - 1u) & ~((1u << from) - 1u)) & 0xffffu;
             }
+            if (LOCUS) need12 &= ~text12;  // (12-mers that match the text between two mismatches less than 16 apart: present without a lookup)
 
             // ---- 12-mer prefilter: pair m = positions p0 + 2m, p0 + 2m + 1; x.C.y = the 13 bases ending at p0 + 2m + 1 ----
             uint32_t p12 = 0xffffu;  // (a settled lane: every 12-mer of its last 16-mer is present, the others are not needed)
