@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             if (!HAS_PREFILTER) p12_left = 0x1fu;
             const uint32_t m12 = (p12_left >> 1) | (p12 << 4);  // bit i: the 12-mer ending at p0 - 4 + i
             uint32_t cand = m12 & (m12 >> 1) & (m12 >> 2) & (m12 >> 3) & (m12 >> 4) & valid16;  // all five 12-mers present
-            if (LOCUS) cand &= ~refuted;
+            if (LOCUS) cand &= ~refuted | known;  // (a member known on one diagonal cannot be refuted on another — its 13-mers then occur twice in the text — but nothing is lost by saying so)
             if (settled) cand = hits;  // nothing open: the confirmed members are all this lane contributes
             uint32_t lcand = __shfl_up(cand >> 15, 1, 64);
             if (lane == 0) lcand = c_cand15;
