@@ -184,6 +184,51 @@ def end_to_end_cli(n_reads):
         return out
 
 
+def end_to_end_cli_kmer(n_reads):
+    """The same for k-mer mode: `-a ref.fasta --trim --split 500 --target_bases <half>` on a FASTQ of the synthetic k-mer reads (reads
+    drawn from the 5 Mbp reference with substitutions and junk, filtlong_amd/synth.py), the drop-in binary and the reference binary on
+    the same files, stdout compared by digest.  A small sample: the reference scores 13 Mbases/s and hashes the assembly for seconds."""
+    import hashlib
+    from filtlong_amd import synth
+    ours = os.path.join(ROOT, "filtlong_amd", "bin", "filtlong")
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "filtlong")
+    env = dict(os.environ, LANG="C", LC_ALL="C")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    ref = synth.bases_read(synth.STREAM_REF, 0, 0, REF_LEN)
+    lens = synth.lengths(n_reads)
+    bases = int(lens.astype(np.int64).sum())
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        fa, fq = os.path.join(d, "ref.fasta"), os.path.join(d, "reads.fastq")
+        with open(fa, "wb") as f:
+            f.write(b">ref\n" + ref.tobytes() + b"\n")
+        with open(fq, "wb") as f:
+            for i, L in enumerate(lens):
+                f.write(b"@r%d\n" % i + synth.seq_read(i, int(L), ref).tobytes() + b"\n+\n" + b"I" * int(L) + b"\n")
+        argv = ["-a", fa, "--trim", "--split", "500", "--target_bases", str(bases // 2), fq]
+
+        def run(binary, outp):
+            t = time.perf_counter()
+            with open(outp, "wb") as fo:
+                rc = subprocess.run([binary] + argv, stdout=fo, stderr=subprocess.DEVNULL, env=env).returncode
+            return time.perf_counter() - t, rc
+
+        def sha(path):
+            return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+        run(ours, os.path.join(d, "a.out"))
+        t_ours, rc_ours = min(run(ours, os.path.join(d, "a.out")) for _ in range(2))
+        out = {"measured_in_this_run": True, "flags": "-a ref.fasta (5 Mbp) --trim --split 500 --target_bases <half>", "reads": n_reads, "bases": bases,
+               "seconds": round(t_ours, 3), "exit_code": rc_ours, "stdout_bytes": os.path.getsize(os.path.join(d, "a.out")),
+               "stdout_sha256": sha(os.path.join(d, "a.out")),
+               "note": "the whole command: reading and hashing the assembly (the set, its text and seed table), scoring, trimming / splitting, output"}
+        if os.path.exists(ref_bin):
+            t_ref, rc_ref = run(ref_bin, os.path.join(d, "r.out"))
+            out.update({"reference_seconds": round(t_ref, 2), "reference_exit_code": rc_ref, "speedup": round(t_ref / t_ours, 1),
+                        "stdout_identical_to_reference": sha(os.path.join(d, "r.out")) == out["stdout_sha256"]})
+        return out
+
+
 class Batch:
     """The packed batch of one rank in HBM (layout, processing order, id range)."""
 
@@ -708,6 +753,10 @@ def main():
                 extras["end_to_end_cli"] = end_to_end_cli(100_000)
             except Exception as e:  # an extra must not cost the headline line
                 extras["end_to_end_cli"] = {"measured_in_this_run": False, "error": repr(e)}
+            try:
+                extras["end_to_end_cli_kmer"] = end_to_end_cli_kmer(3000)
+            except Exception as e:
+                extras["end_to_end_cli_kmer"] = {"measured_in_this_run": False, "error": repr(e)}
             # the 20 GB and gzip runs are too long for the default bench: recorded by tools/bench_e2e_big.sh / bench_e2e_gz.sh
             for key, path in (("end_to_end_cli_20GB_recorded", "r03_e2e_big.json"), ("end_to_end_cli_gzip_recorded", "r03_e2e_gz.json")):  # (round 3's runs: the ingest path did not change)
                 fp = os.path.join(ROOT, "profiles", path)
