@@ -502,16 +502,16 @@ __global__ void __launch_bounds__(1024) flx_score_phred_stream(const PhredArgs a
 // (8 instructions).  An even round needs the chunk issued at the end of the round before it: all but the 4 youngest
 // instructions done.  An odd round needs the half issued two rounds earlier: all but the 8 youngest.
 // ---------------------------------------------------------------------------------------------------------------------
-// NH = half slots of the trailing ring: 4 (the next two halves on their way, 24 KiB per wave, 6 waves per CU) or 3 (one half
-// ahead, 20 KiB, 7 waves)
-#ifndef FLX_DUAL_NH
-#define FLX_DUAL_NH 3
-#endif
-constexpr int DUAL_NH = FLX_DUAL_NH;
-constexpr int DUAL_WAVES = DUAL_NH == 4 ? 6 : 7;
+// The trailing stream is read ONE aligned half slot (four 16-byte pieces of every read) per round; which of the five trailing
+// pieces a round needs come from this half and which from the one before it depends on (ws / 16) mod 4 — a template parameter,
+// so that the pieces kept from the previous round are statically indexed registers.  The ring therefore has only TWO half
+// slots (the one being read and the one on its way): 16 KiB per wave, 9 waves per CU.  (Round 4's first form read the five
+// pieces straight out of a ring of three / four halves: 7 / 6 waves, 4.8 / 5.3 ms per 1e10 bases.)
+constexpr int DUAL_WAVES = 9;
+template <int AMOD>
 __global__ void __launch_bounds__(DUAL_WAVES * 64) flx_score_phred_dual(const PhredArgs a) {
     using T = Tab<false>;
-    constexpr int LEAD_BYTES = 8192, TRAIL_BYTES = 4096 * DUAL_NH, WAVE_BYTES = LEAD_BYTES + TRAIL_BYTES;
+    constexpr int LEAD_BYTES = 8192, TRAIL_BYTES = 8192, WAVE_BYTES = LEAD_BYTES + TRAIL_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     for (int i = threadIdx.x; i < 257; i += DUAL_WAVES * 64) {
         *reinterpret_cast<double *>(smem + T::QOFF + i * 8) = a.lut_q[i];
@@ -528,10 +528,10 @@ __global__ void __launch_bounds__(DUAL_WAVES * 64) flx_score_phred_dual(const Ph
     const uint32_t zaddr = (uint32_t)(T::ZIDX * T::ROW);
     const int ws = a.ws;
     const int A = ws >> 4, B = ws & 15;
+    const int A4 = A >> 2;  // round r reads trailing half r - A4 (pieces 4 (r - A4) .. + 3) and issues the next one
     const int fD = (16 - B) >> 2;
     const uint32_t fsh = (uint32_t)(16 - B) & 3u;
     const double ws_d = a.ws_d;
-    const int t0 = ((3 - A) >> 2) + DUAL_NH - 2;  // the trailing half round 0 issues (round r: t0 + r); halves below it go out before the loop
 
     for (;;) {
         unsigned int group = 0;
@@ -583,38 +583,35 @@ __global__ void __launch_bounds__(DUAL_WAVES * 64) flx_score_phred_dual(const Ph
         auto issue_trail = [&](int h) {  // 4 instructions; h < 0 or behind the reads: a harmless fetch of offset 0
             lds_idle();
             const int o = h * 64;
-            const uint32_t dst = trail_lds + (uint32_t)(((h % DUAL_NH) + DUAL_NH) % DUAL_NH) * 4096u;
+            const uint32_t dst = trail_lds + (uint32_t)(h & 1) * 4096u;
 #pragma unroll
             for (int m = 0; m < 4; ++m) dma16(gsrc[m] + ((o >= 0 && o < lim[m]) ? o : 0), dst + m * 1024);
         };
 
         double s = 0.0, w = 0.0, mn = 0.0;
-        uint32_t carry[4] = {0, 0, 0, 0};  // the trailing piece in front of the round's four
+        uint32_t prev[4][4];  // the trailing half in front of the round's (pieces 4 (h - 1) .. 4 h - 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) prev[k][0] = prev[k][1] = prev[k][2] = prev[k][3] = 0;
         issue_lead(0);
-        for (int h = 0; h < t0; ++h) issue_trail(h);
+        if (A4 == 0) issue_trail(0);
         for (int r = 0; r < n_rounds; ++r) {
-            issue_trail(t0 + r);
-            if (DUAL_NH == 3 || (r & 1) == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (NH = 3: the half this round reads was issued one round ago)
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            // the round's four leading pieces and four trailing pieces (stream pieces 4 r - A .. 4 r - A + 3; below 0: nothing yet)
-            uint32_t lw[4][4], tr[5][4];
+            const int h = r - A4;
+            issue_trail(h + 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // everything but the half just asked for: this round's chunk and half
+            uint32_t lw[4][4], cur[4][4];
             const unsigned char *lrow = lead_slot + (r & 1) * 4096 + lane * 64;
+            const unsigned char *trow = trail_ring + (h & 1) * 4096 + lane * 64;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(lrow + (((k + rot) & 3) << 4));
                 lw[k][0] = v.x; lw[k][1] = v.y; lw[k][2] = v.z; lw[k][3] = v.w;
             }
 #pragma unroll
-            for (int d = 0; d < 4; ++d) tr[0][d] = carry[d];
-#pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int q = 4 * r - A + k;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (q >= 0) v = *reinterpret_cast<const uint4 *>(trail_ring + ((q >> 2) % DUAL_NH) * 4096 + lane * 64 + ((((q & 3) + rot) & 3) << 4));
-                tr[k + 1][0] = v.x; tr[k + 1][1] = v.y; tr[k + 1][2] = v.z; tr[k + 1][3] = v.w;
+                if (h >= 0) v = *reinterpret_cast<const uint4 *>(trow + (((k + rot) & 3) << 4));
+                cur[k][0] = v.x; cur[k][1] = v.y; cur[k][2] = v.z; cur[k][3] = v.w;
             }
-#pragma unroll
-            for (int d = 0; d < 4; ++d) carry[d] = tr[4][d];
             if ((r & 1) && r + 1 < n_rounds) issue_lead((r + 1) >> 1);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -640,8 +637,16 @@ __global__ void __launch_bounds__(DUAL_WAVES * 64) flx_score_phred_dual(const Ph
                     }
                     continue;
                 }
+                // trailing pieces Tp - A - 1 and Tp - A = pieces 4 h - AMOD - 1 + k and the next: index i = k, k + 1 of the five
+                // the round needs; i <= AMOD comes from the previous half (its piece 3 - AMOD + i), the rest from this one
                 uint32_t tw[4];
-                funnel(tr[k], tr[k + 1], fD, fsh, tw);
+                {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const uint32_t(&p0)[4] = (k <= AMOD) ? prev[3 - AMOD + k] : cur[k - AMOD - 1];
+                    const uint32_t(&p1)[4] = (k + 1 <= AMOD) ? prev[3 - AMOD + k + 1] : cur[k - AMOD];
+                    funnel(p0, p1, fD, fsh, tw);
+                }
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     uint32_t aj[4], ai[4];
@@ -672,6 +677,10 @@ __global__ void __launch_bounds__(DUAL_WAVES * 64) flx_score_phred_dual(const Ph
                         }
                     }
                 }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                prev[k][0] = cur[k][0]; prev[k][1] = cur[k][1]; prev[k][2] = cur[k][2]; prev[k][3] = cur[k][3];
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last rounds' fetches must not land in the next group's slots)
@@ -855,12 +864,19 @@ int flx_launch_score_phred_dual(flx_ctx *ctx, PhredArgs a) {
     FLX_HIP(ctx, hipMemsetAsync(scr, 0, 8, ctx->stream));
     a.ticket = (unsigned int *)scr;
     a.n_groups = (unsigned int)((a.n_reads + 63) / 64);
-    const size_t lds = (size_t)Tab<false>::SLOT0 + (size_t)DUAL_WAVES * (8192 + 4096 * DUAL_NH);  // more than half of the LDS: one workgroup per CU
-    FLX_HIP(ctx, hipFuncSetAttribute((const void *)flx_score_phred_dual, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = (size_t)Tab<false>::SLOT0 + (size_t)DUAL_WAVES * 16384;  // more than half of the LDS: one workgroup per CU
     const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)a.n_groups + DUAL_WAVES - 1) / DUAL_WAVES, (uint64_t)ctx->prop.multiProcessorCount);
     ctx->last_phred_kernel = "flx_score_phred_dual";
     flx_time_begin(ctx, ctx->last_phred_kernel);
-    hipLaunchKernelGGL(flx_score_phred_dual, dim3(grid), dim3(DUAL_WAVES * 64), lds, ctx->stream, a);
+#define FLX_DUAL_LAUNCH(M)                                                                                                              \
+    case M:                                                                                                                             \
+        FLX_HIP(ctx, hipFuncSetAttribute((const void *)flx_score_phred_dual<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(flx_score_phred_dual<M>, dim3(grid), dim3(DUAL_WAVES * 64), lds, ctx->stream, a);                            \
+        break;
+    switch ((a.ws >> 4) & 3) {
+        FLX_DUAL_LAUNCH(0) FLX_DUAL_LAUNCH(1) FLX_DUAL_LAUNCH(2) FLX_DUAL_LAUNCH(3)
+    }
+#undef FLX_DUAL_LAUNCH
     flx_time_end(ctx);
     FLX_HIP(ctx, hipGetLastError());
     return FLX_OK;
