@@ -212,15 +212,19 @@ static int add_sequences(flx_ctx *ctx, flx_kmerset *set, const std::vector<std::
 // writes the pieces in order as they become ready, and no more than 2 x threads of them exist at a time.
 static bool g_direct_pieces = false;  // write_pieces: the producers write their pieces themselves (pwrite at known offsets)
 static off_t g_direct_base = 0;
+static int g_shared_out = -1;         // ranks forked by --gpus N: a duplicate of the job's stdout (the SAME open file in every rank)
+// `forced_base` >= 0: the sink is a regular file shared with other processes and this process's pieces start at that offset (the
+// file position is then nobody's to move here)
 template <class Produce>
-static bool write_pieces(size_t n, Produce &&produce, FILE *sink, const std::vector<uint64_t> *offsets) {
+static bool write_pieces(size_t n, Produce &&produce, FILE *sink, const std::vector<uint64_t> *offsets, off_t forced_base = -1) {
     fflush(sink);
     const int fd = fileno(sink);
     struct stat st;
     const int fl = fcntl(fd, F_GETFL);
-    const off_t base = lseek(fd, 0, SEEK_CUR);
-    const bool direct = offsets && !getenv("FLX_CLI_ORDERED_OUTPUT") && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 &&
+    const off_t base = forced_base >= 0 ? forced_base : lseek(fd, 0, SEEK_CUR);
+    const bool direct = offsets && (forced_base >= 0 || !getenv("FLX_CLI_ORDERED_OUTPUT")) && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 &&
                         !(fl & O_APPEND) && base >= 0;
+    if (forced_base >= 0 && !direct) return false;
     g_direct_pieces = direct;
     g_direct_base = base;
     std::vector<std::string> piece(n);
@@ -279,7 +283,7 @@ static bool write_pieces(size_t n, Produce &&produce, FILE *sink, const std::vec
         }
     }
     for (auto &t : pool) t.join();
-    if (direct && !failed && lseek(fd, base + (off_t)(*offsets)[n], SEEK_SET) < 0) failed = true;
+    if (direct && forced_base < 0 && !failed && lseek(fd, base + (off_t)(*offsets)[n], SEEK_SET) < 0) failed = true;
     return !failed;
 }
 
@@ -434,6 +438,7 @@ int main(int argc, char **argv) {
     }
     JobGuard job_guard;  // rank 0 of --gpus: whatever way main() is left, no child and no part file stays behind
     if (g_rank < 0 || g_rank >= g_world) { std::cerr << "Error: RANK " << g_rank << " outside WORLD_SIZE " << g_world << "\n"; return 1; }
+    if (args.gpus > 1 && g_world > 1 && id_file.empty()) g_shared_out = dup(1);  // (forked ranks share the job's stdout: see the output pass)
     if (g_rank > 0) {  // rank 0 speaks for the job
         if (!freopen("/dev/null", "w", stderr)) return 1;
         if (!freopen("/dev/null", "w", stdout)) return 1;
@@ -1049,13 +1054,17 @@ int main(int argc, char **argv) {
     // One rank: straight to stdout.  Several ranks: every rank writes the passed records of its own block to a part file,
     // rank 0 streams the parts to stdout in rank (= file) order.
     if (rank == 0) std::cerr << "Outputting passed long reads\n";
+    // (forked ranks whose common stdout is a regular file write their records straight into it, each at its own offset: below)
     FILE *sink = stdout;
     std::string part_path;
-    if (world > 1) {
+    bool shared_file = false, shared_skip = false;  // several ranks, one output file / an earlier rank's output "died": nothing of this rank's follows
+    off_t shared_base = -1, shared_end = -1;
+    auto open_part = [&]() -> bool {
         part_path = g_part_prefix + ".part" + std::to_string(rank);
         sink = fopen(part_path.c_str(), "wb");
-        if (!sink) { std::cerr << "Error: cannot write " << part_path << "\n"; return 1; }
-    }
+        if (!sink) { std::cerr << "Error: cannot write " << part_path << "\n"; return false; }
+        return true;
+    };
     // the first passing header-only record without a quality string to repeat: the reference's std::cout dies behind its "+" line
     uint64_t dies_at = UINT64_MAX;
     if (fastq_output && !null_qual.empty())
@@ -1145,8 +1154,41 @@ int main(int argc, char **argv) {
             len = (size_t)(end - h);
             return true;
         };
+        if (world > 1) {
+            // Round-3 review, item 8: ONE output file.  The ranks forked by --gpus N share the job's stdout; when that is a regular file
+            // (not in append mode) every rank writes its passed records at its own offset — the sum of the bytes of the ranks in front
+            // of it, one exchange — with the same pwrite / pwritev pieces a single rank uses, and nothing is written twice.  A pipe, a
+            // terminal, or ranks under a launcher (no common stdout): part files that rank 0 streams out in order, as before.
+            std::vector<uint64_t> v(2 + 2 * (size_t)world, 0);
+            if (rank == 0 && g_shared_out >= 0 && !getenv("FLX_CLI_ORDERED_OUTPUT")) {
+                fflush(stdout);
+                struct stat st;
+                const int fl = fcntl(g_shared_out, F_GETFL);
+                const off_t at = lseek(g_shared_out, 0, SEEK_CUR);
+                if (fstat(g_shared_out, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 && !(fl & O_APPEND) && at >= 0) { v[0] = 1; v[1] = (uint64_t)at; }
+            }
+            v[2 + (size_t)rank] = piece_at.back();
+            v[2 + (size_t)world + (size_t)rank] = dies_at != UINT64_MAX;
+            if (flx_comm_sum_u64(ctx, v.data(), v.size()) != FLX_OK) return fail_flx(ctx, "exchange");
+            if (v[0] && g_shared_out >= 0) {
+                shared_file = true;
+                uint64_t before = 0, total = 0;
+                bool dead = false;
+                for (int r = 0; r < world; ++r) {
+                    if (r == rank) { before = total; shared_skip = dead; }
+                    if (!dead) total += v[2 + (size_t)r];
+                    dead = dead || v[2 + (size_t)world + (size_t)r] != 0;
+                }
+                shared_base = (off_t)(v[1] + before);
+                shared_end = (off_t)(v[1] + total);
+                sink = fdopen(dup(g_shared_out), "wb");
+                if (!sink) { std::cerr << "Error: cannot write the output\n"; return 1; }
+            } else if (!open_part()) {
+                return 1;
+            }
+        }
         const int out_fd = fileno(sink);
-        const bool ok = write_pieces(n_pieces, [&](size_t j, std::string &buf) {
+        const bool ok = shared_skip || write_pieces(n_pieces, [&](size_t j, std::string &buf) {
             if (!g_direct_pieces) {  // a pipe / terminal / append-mode file: the caller writes the formatted piece in order
                 for (uint64_t i = piece_first[j]; i < piece_first[j + 1]; ++i) emit(buf, i, kept.recs[reads2[i].rec]);
                 return true;
@@ -1196,7 +1238,7 @@ int main(int argc, char **argv) {
             if (!flush()) return false;
             buf.clear();
             return at == g_direct_base + (off_t)piece_at[j + 1];
-        }, sink, &piece_at);
+        }, sink, &piece_at, shared_file ? shared_base : (off_t)-1);
         if (!ok) { std::cerr << "Error: could not write the output\n"; return 1; }
     } else {
         // Second pass over the compressed input (src/main.cpp:263-313 re-reads the file too), but not front to back on one
@@ -1242,7 +1284,9 @@ int main(int argc, char **argv) {
         done[0] = 1;
         done[(size_t)rank + 1] = dies_at != UINT64_MAX;
         if (flx_comm_sum_u64(ctx, done.data(), done.size()) != FLX_OK) return fail_flx(ctx, "exchange");
-        if (rank == 0) {
+        if (shared_file) {  // everything is in the file already (every rank has written when the exchange returns): the position behind it
+            if (rank == 0 && lseek(g_shared_out, shared_end, SEEK_SET) < 0) { std::cerr << "Error: could not write the output\n"; return 1; }
+        } else if (rank == 0) {
             std::vector<char> buf(1 << 22);
             bool dead = false;
             for (int r = 0; r < world; ++r) {

@@ -228,3 +228,59 @@ def test_cli_output_sinks(tmp_path):
     with open(f1, "wb") as fh:
         assert subprocess.run(args, stdout=fh, stderr=subprocess.PIPE, env=dict(env, FLX_CLI_ORDERED_OUTPUT="1")).returncode == 0
     assert f1.read_bytes() == piped.stdout
+
+
+@pytest.mark.parametrize("gpus", ["2", "3"])
+def test_cli_output_sinks_with_forked_ranks(tmp_path, gpus):
+    """`--gpus N` (ranks forked over the loopback communicator on one GPU): when the job's stdout is a regular file every rank writes
+    its passed records straight into it at its own offset (round-3 review, item 8: one output file, no part files, nothing written
+    twice) — a fresh file, a descriptor that is not at offset 0 of a longer file, k-mer mode with children; a pipe, an O_APPEND file and
+    FLX_CLI_ORDERED_OUTPUT still go through part files that rank 0 streams out.  The same bytes as one rank every way, and the
+    descriptor's position ends behind them (a second command appended to the same descriptor lands behind the first)."""
+    shim_dir = os.path.join(ROOT, "tests", "shim")
+    subprocess.check_call(["make", "-s", "-C", shim_dir])
+    env = dict(os.environ, LANG="C", LC_ALL="C", FLX_RCCL_LIB=os.path.join(shim_dir, "libloopback_rccl.so"), FLX_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    fq = tmp_path / "c1.fastq"
+    fq.write_bytes(_cases.c1_fastq_bytes())
+    inp = _e2e_checks.Inputs()
+    kfq = tmp_path / "kmer.fastq"
+    kfq.write_bytes(_cases.long_fastq_bytes(inp.kreads))
+    fa = tmp_path / "ref.fasta"
+    fa.write_bytes(_cases.fasta_bytes(inp.contigs))
+    jobs = {"phred": ["--target_bases", "20000000", str(fq)],
+            "kmer_children": ["-a", str(fa), "--trim", "--split", "100", "--keep_percent", "80", str(kfq)]}
+    for tag, args in jobs.items():
+        one = subprocess.run([BIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert one.returncode == 0 and len(one.stdout) > 100_000, (tag, one.stderr[-300:])
+        cmd = [BIN, "--gpus", gpus] + args
+        piped = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert piped.returncode == 0 and piped.stdout == one.stdout, (tag, piped.stderr[-300:])
+        f1 = tmp_path / (tag + "_direct.out")
+        with open(f1, "wb") as fh:
+            assert subprocess.run(cmd, stdout=fh, stderr=subprocess.PIPE, env=env).returncode == 0
+            fh.write(b"TAIL\n")  # (the parent's descriptor: its position must be behind the ranks' output)
+        assert f1.read_bytes() == one.stdout + b"TAIL\n", tag
+        f2 = tmp_path / (tag + "_append.out")
+        f2.write_bytes(b"HEAD\n")
+        with open(f2, "ab") as fh:
+            assert subprocess.run(cmd, stdout=fh, stderr=subprocess.PIPE, env=env).returncode == 0
+        assert f2.read_bytes() == b"HEAD\n" + one.stdout, tag
+        f3 = tmp_path / (tag + "_offset.out")
+        f3.write_bytes(b"x" * 7 + b"y" * (len(one.stdout) + 100))
+        with open(f3, "r+b") as fh:
+            fh.seek(7)
+            assert subprocess.run(cmd, stdout=fh, stderr=subprocess.PIPE, env=env).returncode == 0
+            assert os.lseek(fh.fileno(), 0, os.SEEK_CUR) == 7 + len(one.stdout)
+        got = f3.read_bytes()
+        assert got[:7] == b"x" * 7 and got[7:7 + len(one.stdout)] == one.stdout and got[7 + len(one.stdout):] == b"y" * 100, tag
+        with open(f1, "wb") as fh:
+            assert subprocess.run(cmd, stdout=fh, stderr=subprocess.PIPE, env=dict(env, FLX_CLI_ORDERED_OUTPUT="1")).returncode == 0
+        assert f1.read_bytes() == one.stdout, tag
+        # two commands in a row on one descriptor (a shell's `{ a; b; } > file`)
+        f4 = tmp_path / (tag + "_twice.out")
+        with open(f4, "wb") as fh:
+            for _ in range(2):
+                assert subprocess.run(cmd, stdout=fh, stderr=subprocess.PIPE, env=env).returncode == 0
+        assert f4.read_bytes() == one.stdout * 2, tag
