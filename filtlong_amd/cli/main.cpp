@@ -273,7 +273,7 @@ static bool write_pieces(size_t n, Produce &&produce, FILE *sink, const std::vec
             failed = failed || state[j] == 2;
         }
         if (!direct) {
-            if (!failed) fwrite(piece[j].data(), 1, piece[j].size(), sink);
+            if (!failed && fwrite(piece[j].data(), 1, piece[j].size(), sink) != piece[j].size()) failed = true;  // (the producers run dry below)
             std::string().swap(piece[j]);
             {
                 std::unique_lock<std::mutex> lk(mu);
@@ -1276,14 +1276,23 @@ int main(int argc, char **argv) {
         }, sink, nullptr);
         if (!ok) { std::cerr << "Error: " << args.input_reads << " could not be read a second time (did it change?)\n"; return 1; }
     }
-    fflush(sink);
+    // a sink that did not take everything (disk full, the reader of a pipe gone while SIGPIPE is ignored) ends the job with status 1
+    const bool sink_ok = fflush(sink) == 0 && !ferror(sink);
+    if (world == 1 && !sink_ok) { std::cerr << "Error: could not write the output\n"; return 1; }
     if (world > 1) {
         fclose(sink);
         // every part is complete before rank 0 reads it; a rank whose output "died" (above) ends the whole output
         std::vector<uint64_t> done((size_t)world + 1, 0);
-        done[0] = 1;
+        done[0] = sink_ok;
         done[(size_t)rank + 1] = dies_at != UINT64_MAX;
         if (flx_comm_sum_u64(ctx, done.data(), done.size()) != FLX_OK) return fail_flx(ctx, "exchange");
+        if (done[0] != (uint64_t)world) {  // some rank could not write its share: every rank leaves, rank 0 says why
+            if (rank == 0) {
+                for (int r = 0; r < world && !shared_file; ++r) unlink((g_part_prefix + ".part" + std::to_string(r)).c_str());
+                std::cerr << "Error: could not write the output\n";
+            }
+            return rank == 0 ? 1 : 0;
+        }
         if (shared_file) {  // everything is in the file already (every rank has written when the exchange returns): the position behind it
             if (rank == 0 && lseek(g_shared_out, shared_end, SEEK_SET) < 0) { std::cerr << "Error: could not write the output\n"; return 1; }
         } else if (rank == 0) {
@@ -1296,11 +1305,17 @@ int main(int argc, char **argv) {
                 FILE *f = fopen(pth.c_str(), "rb");
                 if (!f) { std::cerr << "Error: cannot read " << pth << "\n"; return 1; }
                 size_t got;
-                while ((got = fread(buf.data(), 1, buf.size(), f)) > 0) fwrite(buf.data(), 1, got, stdout);
+                bool wrote = true;
+                while (wrote && (got = fread(buf.data(), 1, buf.size(), f)) > 0) wrote = fwrite(buf.data(), 1, got, stdout) == got;
                 fclose(f);
                 unlink(pth.c_str());
+                if (!wrote) {
+                    for (int q = r + 1; q < world; ++q) unlink((g_part_prefix + ".part" + std::to_string(q)).c_str());
+                    std::cerr << "Error: could not write the output\n";
+                    return 1;
+                }
             }
-            fflush(stdout);
+            if (fflush(stdout) != 0) { std::cerr << "Error: could not write the output\n"; return 1; }
         }
     }
     stage("output");
@@ -1324,11 +1339,9 @@ int main(int argc, char **argv) {
         fprintf(stderr, "[timing] main() returns at wall clock %.3f\n", ts.tv_sec % 100000 + ts.tv_nsec * 1e-9);
     }
     if (rank == 0) std::cerr << "\n";
-    if (!clean_exit) {
-        fflush(stdout);
-        fflush(stderr);
-        _exit(0);
-    }
-    return 0;
+    const bool flushed = fflush(stdout) == 0 && !ferror(stdout);
+    fflush(stderr);
+    if (!clean_exit) _exit(flushed ? 0 : 1);
+    return flushed ? 0 : 1;
 }
 

@@ -284,3 +284,24 @@ def test_cli_output_sinks_with_forked_ranks(tmp_path, gpus):
             for _ in range(2):
                 assert subprocess.run(cmd, stdout=fh, stderr=subprocess.PIPE, env=env).returncode == 0
         assert f4.read_bytes() == one.stdout * 2, tag
+
+
+@pytest.mark.parametrize("gpus", [None, "2"])
+def test_cli_sink_that_cannot_be_written(tmp_path, gpus):
+    """A sink that does not take the output (/dev/full: every write fails with ENOSPC) ends the job with status 1 and one message —
+    one rank, and ranks whose parts rank 0 streams out; nothing stays behind in the temporary directory."""
+    shim_dir = os.path.join(ROOT, "tests", "shim")
+    subprocess.check_call(["make", "-s", "-C", shim_dir])
+    tmp = tmp_path / "tmp"
+    tmp.mkdir()
+    env = dict(os.environ, LANG="C", LC_ALL="C", FLX_RCCL_LIB=os.path.join(shim_dir, "libloopback_rccl.so"), FLX_DEVICE="0", TMPDIR=str(tmp))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    fq = tmp_path / "c1.fastq"
+    fq.write_bytes(_cases.c1_fastq_bytes())
+    cmd = [BIN] + (["--gpus", gpus] if gpus else []) + ["--target_bases", "20000000", str(fq)]
+    with open("/dev/full", "wb") as fh:
+        res = subprocess.run(cmd, stdout=fh, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert res.returncode == 1, res.stderr[-300:]
+    assert res.stderr.count(b"Error: could not write the output") == 1, res.stderr[-300:]
+    assert list(tmp.iterdir()) == []
