@@ -69,6 +69,11 @@ const uint8_t *flx_kmerset_exact15(const flx_kmerset *set);  // 1 GiB
 //         of a read that holds a text-matching unique 13-mer and is not itself a text match is NOT a member, without any lookup:
 //         this settles most of the false candidates the 12-mer prefilter lets through next to a mismatch (they share 15, 14 or
 //         13 bases with a member, which is exactly why their 12-mers are present)
+//   safe1 uint16 per text word (same index as `text`), bit k set when the 16 bases from base k of the word on lie in one strand copy
+//         and NONE of the 48 16-mers that differ from them in exactly one base is a member (S1).  A window of a read that differs from
+//         the text along the diagonal in exactly one base IS one of those 48: it is not a member, without any lookup — this settles the
+//         single-substitution windows whose mismatch sits in the middle (bases 3..12), which U13 cannot reach; at 5 Mbp 89 % of the
+//         text's windows are safe.  NULL: not built (FLX_KMER_SAFE1=0, or no memory)
 //   seed  open addressing, key = a 16-mer of the text, value = the text position of its first base (the smallest one for a
 //         repeated 16-mer), 0xFFFFFFFF = empty; a slot is verified by comparing the text there with the key
 constexpr uint32_t kLocusPad = 2;
@@ -77,6 +82,7 @@ struct flx_locus {
     const uint2 *text;
     uint32_t n_alloc;    // words in `text`, padding included
     uint64_t n_text;     // text positions (bases of both strand copies)
+    const uint16_t *safe1;  // n_alloc entries or NULL
     const uint32_t *seed;
     uint32_t seed_mask;  // slots - 1
     int seed_shift;      // 32 - log2(slots)

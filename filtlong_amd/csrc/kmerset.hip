@@ -327,6 +327,36 @@ __global__ void __launch_bounds__(256) k_locus_u13(const uint64_t *pos_base, uin
     }
 }
 
+// S1 (kmerset.h), one thread per text position: the 16-window from there on, if it lies in one piece of the text, against the exact
+// bitmap with every one of its bases replaced by the three others (48 far lookups; 10^7 windows: ~10 ms)
+__global__ void __launch_bounds__(256) k_text_safe1(const uint2 *text, uint64_t n_text, const uint32_t *present, uint32_t *safe_words) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t + 16 > n_text) return;
+    {  // no piece starts at t + 1 .. t + 15
+        const uint64_t t1 = t + 1;
+        const uint64_t w = (t1 >> 4) + kLocusPad;
+        const uint32_t s = (uint32_t)(t1 & 15);
+        const uint32_t b = ((text[w].y & 0xffffu) >> s) | ((text[w + 1].y & 0xffffu) << (16 - s));
+        if (b & 0x7fffu) return;
+    }
+    const uint32_t k = flx_locus_kmer_at(text, (uint32_t)t);
+    uint32_t any = 0;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+        uint32_t w[3];
+#pragma unroll
+        for (uint32_t x = 1; x < 4; ++x) {
+            const uint32_t nb = k ^ (x << (2 * j));
+            w[x - 1] = (present[nb >> 5] >> (nb & 31u)) & 1u;
+        }
+        any |= w[0] | w[1] | w[2];
+    }
+    if (!any) {
+        const uint64_t wd = (t >> 4) + kLocusPad;  // (uint16 entry wd = half (wd & 1) of 32-bit word wd >> 1)
+        atomicOr(safe_words + (wd >> 1), (1u << (uint32_t)(t & 15)) << (16 * (uint32_t)(wd & 1)));
+    }
+}
+
 // one thread per 16-mer start of the batch's sequences, both strand copies: the smallest text position of every distinct 16-mer
 __global__ void __launch_bounds__(256) k_locus_seed(const uint64_t *pos_base, uint64_t n_seqs, uint64_t n_pos, uint64_t text_base,
                                                     const uint2 *text, uint32_t *seed, uint32_t mask, int shift) {
@@ -379,7 +409,7 @@ struct flx_kmerset {
     };
     std::vector<Batch> short_batches;
     std::vector<Batch> asm_batches;     // the assembly's sequences, kept until finalize builds the locus text from them (kmerset.h)
-    uint32_t *locus_text = nullptr, *locus_seed = nullptr;
+    uint32_t *locus_text = nullptr, *locus_seed = nullptr, *locus_safe1 = nullptr;
     flx_locus locus;
     bool has_locus = false;
     uint64_t bloom_candidates = 0;
@@ -424,7 +454,7 @@ extern "C" void flx_kmerset_destroy(flx_kmerset *s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     free_batches(s);
     free_batches(s->asm_batches);
-    for (uint32_t *p : {s->present, s->asm_only, s->seen1, s->seen2, s->seen3, s->prefilter, s->pre11, s->exact15, s->locus_text, s->locus_seed})
+    for (uint32_t *p : {s->present, s->asm_only, s->seen1, s->seen2, s->seen3, s->prefilter, s->pre11, s->exact15, s->locus_text, s->locus_seed, s->locus_safe1})
         if (p) (void)hipFree(p);
     delete s;
 }
@@ -795,6 +825,24 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
         }
         free_batches(s->asm_batches);
         free_batches(s);
+        s->locus.safe1 = nullptr;
+        const char *s1 = getenv("FLX_KMER_SAFE1");  // "0": without S1 (tests, A/B)
+        if (s->has_locus && !(s1 && s1[0] == '0')) {
+            const size_t bytes = (((size_t)s->locus.n_alloc + 1) / 2) * 4;
+            if (hipMalloc((void **)&s->locus_safe1, bytes) == hipSuccess) {
+                FLX_HIP(ctx, hipMemsetAsync(s->locus_safe1, 0, bytes, st));
+                flx_time_begin(ctx, "flx_kmerset_locus_build");
+                hipLaunchKernelGGL(k_text_safe1, dim3((unsigned)((s->locus.n_text + 255) / 256)), dim3(256), 0, st, s->locus.text, s->locus.n_text,
+                                   s->present, s->locus_safe1);
+                flx_time_end(ctx);
+                FLX_HIP(ctx, hipGetLastError());
+                FLX_HIP(ctx, hipStreamSynchronize(st));
+                s->locus.safe1 = (const uint16_t *)s->locus_safe1;
+            } else {
+                s->locus_safe1 = nullptr;
+                (void)hipGetLastError();
+            }
+        }
     }
     s->final_ = true;
     return FLX_OK;

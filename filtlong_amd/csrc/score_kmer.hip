@@ -329,11 +329,18 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
         bool have_diag = false, carry_ok = false;
         uint32_t c_mml = 0xffffu, c_bnd = 0xffffu, c_u13 = 0, c_known15 = 0, c_twx = 0, c_twy = 0xffffu;
         uint2 tw = make_uint2(0, 0xffffu), tw_next = make_uint2(0, 0xffffu);
+        uint32_t ts = 0, ts_next = 0, c_ts = 0, c_s1 = 0;  // S1 bits of those text words (kmerset.h: safe1); lane 63's for the next span
+        const bool has_s1 = loc.safe1 != nullptr;
         // the text word that holds the LAST base of the lane's 16 at this diagonal (index clamped into the padded array)
         auto text_word = [&](long long dg, int p0) -> uint2 {
             long long w = ((dg + p0 + 15) >> 4) + (long long)kLocusPad;
             w = w < 0 ? 0 : (w >= (long long)loc.n_alloc ? (long long)loc.n_alloc - 1 : w);
-            return loc.text[w];  // (non-temporal here is slower: 14.2 vs 13.8 ms per 1e10 — a text word is used again by the next span's lane 0 and by reads of the same locus)
+            return loc.text[(uint32_t)w];  // (non-temporal here is slower: 14.2 vs 13.8 ms per 1e10 — a text word is used again by the next span's lane 0 and by reads of the same locus)
+        };
+        auto safe_word = [&](long long dg, int p0) -> uint32_t {  // the S1 bits of that word
+            long long w = ((dg + p0 + 15) >> 4) + (long long)kLocusPad;
+            w = w < 0 ? 0 : (w >= (long long)loc.n_alloc ? (long long)loc.n_alloc - 1 : w);
+            return has_s1 ? (uint32_t)loc.safe1[(uint32_t)w] : 0u;
         };
 
         auto finalize = [&](int sp, uint32_t h, uint32_t right_of_63) {  // hits of span sp -> coverage bits, counts, row words
@@ -356,19 +363,23 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             const uint32_t up = __shfl_down(c16, 1, 64);
             const int word = p0 >> 5;
 #ifndef FLX_COVER_TEMPORAL
-            if ((lane & 1) == 0 && word < row_words) __builtin_nontemporal_store(c16 | (up << 16), &row[word]);
+            if ((lane & 1) == 0 && word < row_words) __builtin_nontemporal_store(c16 | (up << 16), &row[(uint32_t)word]);
 #else
-            if ((lane & 1) == 0 && word < row_words) row[word] = c16 | (up << 16);
+            if ((lane & 1) == 0 && word < row_words) row[(uint32_t)word] = c16 | (up << 16);
 #endif
         };
 
         uint4 raw = make_uint4(0, 0, 0, 0);
-        if (lane * 16 < L) raw = flx_plane16(seq + lane * 16);  // rows are 16-byte aligned and padded
+        // (offsets as unsigned 32-bit values: a uniform base plus a 32-bit lane offset is one address register, not two)
+        if (lane * 16 < L) raw = flx_plane16(seq + (uint32_t)(lane * 16));  // rows are 16-byte aligned and padded
         for (int sp = 0; sp < n_spans; ++sp) {
             const int p0 = (sp << 10) + lane * 16;
             uint4 raw_next = make_uint4(0, 0, 0, 0);
-            if (p0 + 1024 < L) raw_next = flx_plane16(seq + p0 + 1024);
-            if (LOCUS && have_diag && sp + 1 < n_spans) tw_next = text_word(diag, p0 + 1024);
+            if (p0 + 1024 < L) raw_next = flx_plane16(seq + (uint32_t)(p0 + 1024));
+            if (LOCUS && have_diag && sp + 1 < n_spans) {
+                tw_next = text_word(diag, p0 + 1024);
+                ts_next = safe_word(diag, p0 + 1024);
+            }
             // 2 bits per base, earliest base on top: lo = my 16 bases, hi = the 16 before them
             const uint32_t lo = (codes4(raw.x) << 24) | (codes4(raw.y) << 16) | (codes4(raw.z) << 8) | codes4(raw.w);
             uint32_t hi = __shfl_up(lo, 1, 64);
@@ -394,10 +405,13 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     uint2 twl;
                     twl.x = __shfl_up(tw.x, 1, 64);
                     twl.y = __shfl_up(tw.y, 1, 64);
+                    uint32_t tsl = __shfl_up(ts, 1, 64);
                     if (lane == 0) twl = carry_ok ? make_uint2(c_twx, c_twy) : text_word(diag, p0 - 16);  // (a load only behind a new seed)
+                    if (lane == 0) tsl = carry_ok ? c_ts : 0u;  // (not worth a load: lane 0 behind a new seed refutes its own window only, below)
                     const uint32_t t_own = __builtin_amdgcn_alignbit(twl.x, tw.x, 2 * (15 - e));
                     const uint32_t b_own = (((twl.y & 0xffffu) >> (e + 1)) | (tw.y << (15 - e))) & 0xffffu;  // bit j: my base j is the first of a piece
                     const uint32_t u_own = (((twl.y >> 16) >> (e + 1)) | ((tw.y >> 16) << (15 - e))) & 0xffffu;  // bit j: a unique 13-mer starts at my base j
+                    const uint32_t s_own = ((tsl >> (e + 1)) | (ts << (15 - e))) & 0xffffu;  // bit j: the text's 16 bases from my base j on are S1
                     const uint32_t x = lo ^ t_own;
                     uint32_t m = (x | (x >> 1)) & 0x55555555u;  // even bit 2k: the base k places from the END differs
                     m = (m | (m >> 1)) & 0x33333333u;
@@ -405,8 +419,8 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     m = (m | (m >> 4)) & 0x00ff00ffu;
                     m = (m | (m >> 8)) & 0xffffu;
                     const uint32_t mml = __brev(m) >> 16;  // bit j: my base j differs from the text
-                    uint32_t mmh = __shfl_up(mml, 1, 64), bh = __shfl_up(b_own, 1, 64), uh = __shfl_up(u_own, 1, 64);
-                    if (lane == 0) { mmh = carry_ok ? c_mml : 0xffffu; bh = carry_ok ? c_bnd : 0xffffu; uh = carry_ok ? c_u13 : 0u; }
+                    uint32_t mmh = __shfl_up(mml, 1, 64), bh = __shfl_up(b_own, 1, 64), uh = __shfl_up(u_own, 1, 64), sh = __shfl_up(s_own, 1, 64);
+                    if (lane == 0) { mmh = carry_ok ? c_mml : 0xffffu; bh = carry_ok ? c_bnd : 0xffffu; uh = carry_ok ? c_u13 : 0u; sh = carry_ok ? c_s1 : 0u; }
                     const uint32_t z = ~(mmh | (mml << 16));  // bit i: base i of the window [p0 - 16, p0 + 16) matches
                     uint32_t r = z & (z >> 1);
                     r &= r >> 2;
@@ -438,12 +452,34 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     g &= uh | (u_own << 16);  // ... and that 13-mer occurs nowhere else (U13 is only set inside one piece)
                     g |= g >> 1;
                     g |= g >> 2;  // bit i: such a 13-mer starts at base i, i + 1, i + 2 or i + 3: inside the 16 bases from i on
-                    uint32_t rf = ((g & ~r) >> 1) & valid16;
+                    // S1: exactly ONE of the 16 bases from i on differs from the text, and no 16-mer one base away from the text's is a
+                    // member (counted with a saturating two-bit counter per window: `one` = exactly one mismatch, `two` = more)
+                    uint32_t one = ~z, two;
+                    two = one & (one >> 1);
+                    one ^= one >> 1;
+                    {
+                        const uint32_t t2 = two | (two >> 2) | (one & (one >> 2));
+                        one = (one ^ (one >> 2)) & ~t2;
+                        two = t2;
+                    }
+                    {
+                        const uint32_t t2 = two | (two >> 4) | (one & (one >> 4));
+                        one = (one ^ (one >> 4)) & ~t2;
+                        two = t2;
+                    }
+                    {
+                        const uint32_t t2 = two | (two >> 8) | (one & (one >> 8));
+                        one = (one ^ (one >> 8)) & ~t2;
+                    }
+                    one &= q & (sh | (s_own << 16));
+                    uint32_t rf = (((g & ~r) | one) >> 1) & valid16;
                     // (lane 0 behind a new seed knows nothing about the 16 bases in front of it — taken for mismatches above, which is
                     // safe for `known` and would be wrong here: only the window made of its own 16 bases can be refuted)
                     if (lane == 0 && !carry_ok) rf &= 0x8000u;
                     refuted |= rf;
                     c_u13 = __builtin_amdgcn_readlane(u_own, 63);
+                    c_s1 = __builtin_amdgcn_readlane(s_own, 63);
+                    c_ts = __builtin_amdgcn_readlane(ts, 63);
                     c_mml = __builtin_amdgcn_readlane(mml, 63);
                     c_bnd = __builtin_amdgcn_readlane(b_own, 63);
                     c_twx = __builtin_amdgcn_readlane(tw.x, 63);
@@ -488,7 +524,11 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     have_diag = true;
                     carry_ok = false;
                     tw = text_word(diag, p0);
-                    if (sp + 1 < n_spans) tw_next = text_word(diag, p0 + 1024);
+                    ts = safe_word(diag, p0);
+                    if (sp + 1 < n_spans) {
+                        tw_next = text_word(diag, p0 + 1024);
+                        ts_next = safe_word(diag, p0 + 1024);
+                    }
                     again = true;
                 }
             }
@@ -600,7 +640,17 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     return got;
                 };
                 const uint32_t want = settled ? 0u : (need12 & valid12);
-                p12 = fetch(want & 0x3333u, 0);
+                {
+                    // round 1 as well leaves out the pairs whose 12-mers only lie in 16-mers the text has refuted (U13, S1)
+                    uint32_t alive = settled ? 0u : (valid16 & (~refuted | known));
+                    uint32_t right = __shfl_down(alive, 1, 64);
+                    if (lane == 63) right = 0xffffu;
+                    uint32_t dep = alive | (right << 16);
+                    dep |= dep >> 1;
+                    dep |= dep >> 2;
+                    dep |= dep >> 1;
+                    p12 = fetch(want & 0x3333u & dep, 0);
+                }
                 {
                     const uint32_t v1 = p12 & valid12;
                     uint32_t l1 = __shfl_up(v1 >> 11, 1, 64);
@@ -683,7 +733,10 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             c_cand15 = __builtin_amdgcn_readlane(cand >> 15, 63);
             c_hit15 = __builtin_amdgcn_readlane(hits >> 15, 63);
             raw = raw_next;
-            if (LOCUS) tw = tw_next;
+            if (LOCUS) {
+                tw = tw_next;
+                ts = ts_next;
+            }
         }
         if (n_spans > 0) finalize(n_spans - 1, prev_hits, 0u);
         for (int wd = n_spans * 32 + lane; wd < row_words; wd += 64) row[wd] = 0;  // (only L == 0 leaves words unwritten)

@@ -457,7 +457,15 @@ def test_locus_path_vs_oracle(ctx, be, synth, monkeypatch):
     c_n = bytearray(rnd(4000)); c_n[1000:1040] = b"N" * 40; c_n[2000] = ord("N"); c_n[2500:2503] = b"nRY"; c_n = bytes(c_n)
     c_rep = rnd(300) + b"A" * 200 + rnd(100) + b"AC" * 150 + rnd(100) + (rnd(23) * 40) + rnd(300)
     c_low = rnd(1500).lower()
-    contigs = list(synth["contigs"]) + [c_second, c_n, b"ACGTACGTACGTACG", c_rep, c_low, rnd(16), rnd(17)]
+    # S1 (kmerset.h: safe1): 48 16-mers of c0 with ONE base changed — every offset, every other base — that are members through this
+    # contig only; a read that carries those substitutions differs from the text in exactly one base per window, and exactly the
+    # windows that start at the changed 16-mers must not be refuted
+    near_at = [(6000 + 40 * k, k % 16, k // 16 + 1) for k in range(48)]
+    c_near = b""
+    for at, j, x in near_at:
+        w1 = bytearray(c0[at:at + 16]); w1[j] = ord("ACGT"[("ACGT".index(chr(w1[j])) + x) % 4])
+        c_near += rnd(3) + bytes(w1)
+    contigs = list(synth["contigs"]) + [c_second, c_n, b"ACGTACGTACGTACG", c_rep, c_low, rnd(16), rnd(17), c_near]
     codes, starts = _text_codes(contigs)
     dec = np.frombuffer(b"ACGT", dtype=np.uint8)
     reads = []
@@ -498,6 +506,15 @@ def test_locus_path_vs_oracle(ctx, be, synth, monkeypatch):
     r = bytearray(c0[4000:6500]); r[1008] = w[8]
     add("second_locus_only", r)                                            # [1000, 1016) is a member only through c_second
     add("second_locus_rev", _cases.revcomp(bytes(r)))
+    r = bytearray(c0[5800:8100])
+    for at, j, x in near_at:
+        r[at - 5800 + j] = ord("ACGT"[("ACGT".index(chr(c0[at + j])) + x) % 4])
+    add("one_base_away_members", r)
+    add("one_base_away_members_rev", _cases.revcomp(bytes(r)))
+    r2 = bytearray(c0[5800:8100])
+    for at, j, x in near_at:  # the same places with ANOTHER base: one mismatch per window, none of them a member
+        r2[at - 5800 + j] = ord("ACGT"[("ACGT".index(chr(c0[at + j])) + x % 3 + 1) % 4])
+    add("one_base_away_others", r2)
     add("repeats", c_rep)
     add("repeats_rev", _cases.revcomp(c_rep))
     add("homopolymer", b"A" * 3000)
@@ -548,6 +565,13 @@ def test_locus_path_vs_oracle(ctx, be, synth, monkeypatch):
         for (name, _s, _q), a, b, c in zip(reads, got, plain, v2):
             assert bits(a) == bits(b), (name, pkw, "FLX_KMER_LOCUS=0")
             assert bits(a) == bits(c), (name, pkw, "v2")
+    # the same set built without S1: nothing may differ
+    monkeypatch.setenv("FLX_KMER_SAFE1", "0")
+    ks_plain = be.kmers(assembly=contigs)
+    monkeypatch.delenv("FLX_KMER_SAFE1")
+    for pkw in (dict(), dict(trim=True, split=20)):
+        for (name, _s, _q), a, b in zip(reads, be.score(reads, pkw, ks), be.score(reads, pkw, ks_plain)):
+            assert bits(a) == bits(b), (name, pkw, "FLX_KMER_SAFE1=0")
     # the synthetic set, every read, three ways; and a set of assembly + short reads keeps the assembly's text
     sreads = _cases.kmer_reads(synth["contigs"])
     for ks2 in (synth["asm"], synth["both"]):

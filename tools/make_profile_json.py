@@ -68,6 +68,10 @@ def main():
                 continue
             shutil.copy(os.path.join(G, "prof_kmer", "%s_%s.txt" % (d, cfg)), os.path.join(P, "%s_kmer_%s_%s.txt" % (PFX, d, cfg)))
     json.dump(req, open(os.path.join(P, PFX + "_kmer_requests.json"), "w"), indent=1)
+    if len(sys.argv) > 3 and sys.argv[3] == "kmer-only":  # (on the GPU box, between the PMC passes and the bench line that quotes them)
+        print(json.dumps({k: {"kernel_ms": v["kernel_ms"], "far/base": round(v["far_requests_per_base"], 4), "l2/base": round(v["l2_hit_requests_per_base"], 4)}
+                          for k, v in req.items()}))
+        return
     # ---- C2 Phred kernel: HBM traffic
     fe, _ = counters(os.path.join(G, "final", "pmc_fetch.txt"), "flx_score_phred_regs")
     wr, _ = counters(os.path.join(G, "final", "pmc_write.txt"), "flx_score_phred_regs")
