@@ -38,17 +38,19 @@
 namespace {
 
 // The 2-bit codes of the four bases of a dword (src/kmers.cpp:176-196: C/c 1, G/g 2, T/t 3, anything else 0) packed into 8
-// bits, first base (lowest byte) in the top two.  Branch free: a switch per base compiles into divergent control flow — half
-// of the cover kernel's run time before — while three exact SWAR byte comparisons serve four bases at once.
+// bits, first base (lowest byte) in the top two.  Branch free (a switch per base compiles into divergent control flow — half
+// of the cover kernel's run time once) and, since the cover kernel turned out to be bound by its vector instructions (round 4:
+// 0.81 per position, a quarter of them here), by table: bits 1..3 of a letter tell A, C, T and G apart (0, 1, 2, 3 — in either
+// case), v_perm_b32 looks up the letter that index stands for and the byte is that letter or it is none of them; a second
+// v_perm_b32 turns the index into the code and v_dot4_u32_u8 packs the four.  12 instructions per dword (three SWAR comparisons: 30).
 __device__ __forceinline__ uint32_t codes4(uint32_t w) {
-    const uint32_t x = w & 0xDFDFDFDFu;  // folds the case (bit 5); x == 'C' exactly for 'C' and 'c', likewise G and T
-    auto eq = [](uint32_t v, uint32_t k) {  // bit 7 of every byte of v that equals the byte of k
-        const uint32_t y = v ^ k;
-        return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
-    };
-    const uint32_t zc = eq(x, 0x43434343u), zg = eq(x, 0x47474747u), zt = eq(x, 0x54545454u);
-    const uint32_t t = ((zc | zt) >> 7) | ((zg | zt) >> 6);  // bits 0-1 of every byte: its code
-    return ((t << 6) | (t >> 4) | (t >> 14) | (t >> 24)) & 0xffu;
+    const uint32_t idx = (w >> 1) & 0x07070707u;
+    const uint32_t letter = __builtin_amdgcn_perm(0u, 0x47544341u, idx);  // A C T G for 0 1 2 3, 0x00 for 4..7
+    const uint32_t d = (letter ^ w) & 0xDFDFDFDFu;                         // a zero byte: that letter, upper or lower case
+    const uint32_t nz = ((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d;             // bit 7 of every byte that is NOT zero
+    const uint32_t sel = ((nz >> 5) & 0x04040404u) | idx;                  // anything else: an index from 4 on
+    const uint32_t code = __builtin_amdgcn_perm(0u, 0x02030100u, sel);     // A 0, C 1, T 3, G 2; 0 from 4 on
+    return __builtin_amdgcn_udot4(code, 0x01041040u, 0u, false);           // byte 0 * 64 + byte 1 * 16 + byte 2 * 4 + byte 3
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -331,16 +333,20 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
         uint2 tw = make_uint2(0, 0xffffu), tw_next = make_uint2(0, 0xffffu);
         uint32_t ts = 0, ts_next = 0, c_ts = 0, c_s1 = 0;  // S1 bits of those text words (kmerset.h: safe1); lane 63's for the next span
         const bool has_s1 = loc.safe1 != nullptr;
-        // the text word that holds the LAST base of the lane's 16 at this diagonal (index clamped into the padded array)
-        auto text_word = [&](long long dg, int p0) -> uint2 {
-            long long w = ((dg + p0 + 15) >> 4) + (long long)kLocusPad;
-            w = w < 0 ? 0 : (w >= (long long)loc.n_alloc ? (long long)loc.n_alloc - 1 : w);
-            return loc.text[(uint32_t)w];  // (non-temporal here is slower: 14.2 vs 13.8 ms per 1e10 — a text word is used again by the next span's lane 0 and by reads of the same locus)
+        // the text word that holds the LAST base of the lane's 16 at this diagonal, for the lane whose 16 bases start at `base` +
+        // 16 * lane (index clamped into the padded array).  The diagonal and `base` are wave-uniform: the 64-bit part of the index
+        // is scalar work, a lane adds its number and clamps (the cover kernel is bound by its vector instructions)
+        auto word_index = [&](long long dg, int base) -> uint32_t {
+            long long u = ((dg + base + 15) >> 4) + (long long)kLocusPad;  // (16 * lane + c) >> 4 == lane + (c >> 4)
+            u = u < -64 ? -64 : (u > (long long)loc.n_alloc ? (long long)loc.n_alloc : u);
+            const int w = (int)u + lane;
+            return (uint32_t)max(0, min(w, (int)loc.n_alloc - 1));
         };
-        auto safe_word = [&](long long dg, int p0) -> uint32_t {  // the S1 bits of that word
-            long long w = ((dg + p0 + 15) >> 4) + (long long)kLocusPad;
-            w = w < 0 ? 0 : (w >= (long long)loc.n_alloc ? (long long)loc.n_alloc - 1 : w);
-            return has_s1 ? (uint32_t)loc.safe1[(uint32_t)w] : 0u;
+        auto text_word = [&](long long dg, int base) -> uint2 {
+            return loc.text[word_index(dg, base)];  // (non-temporal here is slower: 14.2 vs 13.8 ms per 1e10 — a text word is used again by the next span's lane 0 and by reads of the same locus)
+        };
+        auto safe_word = [&](long long dg, int base) -> uint32_t {  // the S1 bits of that word
+            return has_s1 ? (uint32_t)loc.safe1[word_index(dg, base)] : 0u;
         };
 
         auto finalize = [&](int sp, uint32_t h, uint32_t right_of_63) {  // hits of span sp -> coverage bits, counts, row words
@@ -377,8 +383,8 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             uint4 raw_next = make_uint4(0, 0, 0, 0);
             if (p0 + 1024 < L) raw_next = flx_plane16(seq + (uint32_t)(p0 + 1024));
             if (LOCUS && have_diag && sp + 1 < n_spans) {
-                tw_next = text_word(diag, p0 + 1024);
-                ts_next = safe_word(diag, p0 + 1024);
+                tw_next = text_word(diag, (sp << 10) + 1024);
+                ts_next = safe_word(diag, (sp << 10) + 1024);
             }
             // 2 bits per base, earliest base on top: lo = my 16 bases, hi = the 16 before them
             const uint32_t lo = (codes4(raw.x) << 24) | (codes4(raw.y) << 16) | (codes4(raw.z) << 8) | codes4(raw.w);
@@ -401,12 +407,12 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             if (LOCUS) {
                 // my 16 bases against the text along `diag` (tw = the word that holds the last of them): adds to known / refuted
                 auto compare = [&]() {
-                    const int e = (int)((diag + p0 + 15) & 15);  // index of my last base in my word
+                    const int e = (int)((diag + 15) & 15);  // index of my last base in my word (p0 is a multiple of 16: the same for every lane)
                     uint2 twl;
                     twl.x = __shfl_up(tw.x, 1, 64);
                     twl.y = __shfl_up(tw.y, 1, 64);
                     uint32_t tsl = __shfl_up(ts, 1, 64);
-                    if (lane == 0) twl = carry_ok ? make_uint2(c_twx, c_twy) : text_word(diag, p0 - 16);  // (a load only behind a new seed)
+                    if (lane == 0) twl = carry_ok ? make_uint2(c_twx, c_twy) : text_word(diag, (sp << 10) - 16);  // (a load only behind a new seed; only lane 0 uses it)
                     if (lane == 0) tsl = carry_ok ? c_ts : 0u;  // (not worth a load: lane 0 behind a new seed refutes its own window only, below)
                     const uint32_t t_own = __builtin_amdgcn_alignbit(twl.x, tw.x, 2 * (15 - e));
                     const uint32_t b_own = (((twl.y & 0xffffu) >> (e + 1)) | (tw.y << (15 - e))) & 0xffffu;  // bit j: my base j is the first of a piece
@@ -523,11 +529,11 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     diag = nd;
                     have_diag = true;
                     carry_ok = false;
-                    tw = text_word(diag, p0);
-                    ts = safe_word(diag, p0);
+                    tw = text_word(diag, sp << 10);
+                    ts = safe_word(diag, sp << 10);
                     if (sp + 1 < n_spans) {
-                        tw_next = text_word(diag, p0 + 1024);
-                        ts_next = safe_word(diag, p0 + 1024);
+                        tw_next = text_word(diag, (sp << 10) + 1024);
+                        ts_next = safe_word(diag, (sp << 10) + 1024);
                     }
                     again = true;
                 }
@@ -617,25 +623,36 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 // Round 2 fetches an odd pair only if one of the six 16-mers that hold its 12-mers — five of them may be the right
                 // neighbour's — is still alive under the assumption that every 12-mer not yet seen is present.  A pair that is
                 // skipped keeps that assumption: it only concerns 16-mers that are out anyway.
+                // (the reverse complement of the whole 32-base window once: the canonical form of every pair's 11-mer is then one
+                // funnel shift, and a byte read for the other strand is looked at bit-reversed — bit 7 - x is bit x, bit 3 - y is bit
+                // 4 + y — instead of with two selected bit numbers: kmerset.h, flx_pre11, in 19 instead of 33 instructions per pair)
+                auto rc32 = [](uint32_t w) {
+                    const uint32_t r = __brev(w);
+                    return ~(((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1));
+                };
+                const uint64_t r64 = ((uint64_t)rc32(lo) << 32) | rc32(hi);
                 auto fetch = [&](uint32_t want, int parity) -> uint32_t {  // actual bits of the pairs m = parity, parity + 2, .. that hold a wanted position; 1 elsewhere
-                    uint32_t byte[4], sel[4], got = 0xffffu;
+                    uint32_t byte[4], got = parity ? 0x3333u : 0xCCCCu;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int m = 2 * k + parity;
-                        const uint32_t a = __builtin_amdgcn_alignbit(hi, lo, 28 - 4 * m);
-                        const flx_pre11_slot q = flx_pre11((a >> 2) & 0x3FFFFFu, (a >> 24) & 3u, a & 3u);
+                        const uint32_t a = __builtin_amdgcn_alignbit(hi, lo, 28 - 4 * m);  // x.C.y, the 13 bases ending at position 2m + 1
+                        const uint32_t c = (a >> 2) & 0x3FFFFFu, rc = (uint32_t)(r64 >> (12 + 4 * m)) & 0x3FFFFFu;
+                        const uint32_t kk = (a & 0x2000u) ? rc : c;  // the middle base of C is G or T: the byte belongs to the other strand
+                        const uint32_t index = ((kk >> 12) << 11) | (kk & 0x7FFu);
 #ifdef FLX_ABL_NOL2
                         byte[k] = 0xffu;
 #else
-                        byte[k] = ((want >> (2 * m)) & 3u) ? pre11[q.index] : 0xffu;
+                        byte[k] = ((want >> (2 * m)) & 3u) ? pre11[index] : 0xffu;
 #endif
-                        sel[k] = q.even_bit | (q.odd_bit << 8);
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int m = 2 * k + parity;
-                        const uint32_t two = ((byte[k] >> (sel[k] & 0xffu)) & 1u) | (((byte[k] >> (sel[k] >> 8)) & 1u) << 1);
-                        if ((want >> (2 * m)) & 3u) got &= ~(3u << (2 * m)) | (two << (2 * m));
+                        const uint32_t a = __builtin_amdgcn_alignbit(hi, lo, 28 - 4 * m);
+                        const uint32_t b = (a & 0x2000u) ? (__brev(byte[k]) >> 24) : byte[k];
+                        const uint32_t two = ((b >> ((a >> 24) & 3u)) & 1u) | (((b >> (4u + (a & 3u))) & 1u) << 1);
+                        got |= two << (2 * m);  // (a pair that was not fetched holds 0xff: both present)
                     }
                     return got;
                 };
@@ -649,9 +666,10 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     dep |= dep >> 1;
                     dep |= dep >> 2;
                     dep |= dep >> 1;
-                    p12 = fetch(want & 0x3333u & dep, 0);
+                    const uint32_t w1 = want & 0x3333u & dep;
+                    p12 = __any(w1 != 0) ? fetch(w1, 0) : 0xffffu;  // (a span the text settles: nothing is computed for it)
                 }
-                {
+                if (__any((want & 0xCCCCu) != 0)) {
                     const uint32_t v1 = p12 & valid12;
                     uint32_t l1 = __shfl_up(v1 >> 11, 1, 64);
                     if (lane == 0) l1 = c_p12;
@@ -664,7 +682,8 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     dep |= dep >> 1;
                     dep |= dep >> 2;
                     dep |= dep >> 1;  // bit q: one of the 16-mers ending at q .. q + 4 (those that hold the 12-mer ending at q) is alive
-                    p12 &= fetch(want & 0xCCCCu & dep, 1);
+                    const uint32_t w2 = want & 0xCCCCu & dep;
+                    if (__any(w2 != 0)) p12 &= fetch(w2, 1);
                 }
             }
             p12 &= valid12;
