@@ -34,6 +34,9 @@
 #ifndef FLX_FARFIRST_LANES
 #define FLX_FARFIRST_LANES 16  // settled lanes of a span from which the next span asks the exact table first (score_kmer.hip, below)
 #endif
+#ifndef FLX_FARFIRST_LANES_LOCUS
+#define FLX_FARFIRST_LANES_LOCUS 65  // the same with a text: never (65 > 64) — the text settles the clean lanes, the mode only costs instructions (profiles/r04_microbench.txt)
+#endif
 
 namespace {
 
@@ -359,8 +362,13 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             x |= x >> 4;
             x |= x >> 8;  // bit j = OR of hit bits j .. j+15: base p0+j lies in a member 16-mer (src/read.cpp:53-54)
             uint32_t c16 = x & 0xffffu;
-            if (p0 >= L) c16 = 0;
-            else if (p0 + 16 > L) c16 &= (1u << (L - p0)) - 1u;
+#ifndef FLX_NO_VALID_FAST
+            if (((sp + 1) << 10) > L)  // (wave-uniform: only the read's last span has positions to cut off)
+#endif
+            {
+                if (p0 >= L) c16 = 0;
+                else if (p0 + 16 > L) c16 &= (1u << (L - p0)) - 1u;
+            }
             cnt += __popc(c16);
             if (c16) {
                 fst = min(fst, p0 + (__ffs(c16) - 1));
@@ -392,6 +400,11 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             if (lane == 0) hi = c_lo;
             // positions p0 + j that end a 12-mer / a 16-mer inside the read
             uint32_t valid12 = 0, valid16 = 0;
+#ifndef FLX_NO_VALID_FAST
+            if (sp > 0 && ((sp + 1) << 10) <= L) {  // (wave-uniform: a span inside the read has every position, no lane computes masks)
+                valid12 = valid16 = 0xffffu;
+            } else
+#endif
             if (p0 < L) {
                 valid12 = valid16 = 0xffffu;
                 if (p0 < 11) valid12 &= ~((1u << (11 - p0)) - 1u);
@@ -738,7 +751,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             if (LOCUS) {  // lanes the text settles anyway do not count: they ask nothing either way
                 uint32_t lknown = __shfl_up(known >> 15, 1, 64);
                 if (lane == 0) lknown = c_known15;
-                far_first = __popcll(__ballot((hits >> 15) && lhit && !((known >> 15) && lknown))) >= FLX_FARFIRST_LANES;
+                far_first = __popcll(__ballot((hits >> 15) && lhit && !((known >> 15) && lknown))) >= FLX_FARFIRST_LANES_LOCUS;
                 c_known15 = __builtin_amdgcn_readlane(known >> 15, 63);
             } else {
                 far_first = __popcll(__ballot((hits >> 15) && lhit)) >= FLX_FARFIRST_LANES;
