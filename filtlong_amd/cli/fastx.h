@@ -303,19 +303,17 @@ static size_t find_record_start(const Input &d, size_t from, size_t limit, bool 
 // would start at or after S_{k+1}; the result is accepted only if every chunk stopped EXACTLY at S_{k+1} between two
 // records — then the concatenation is what the sequential parser produces (its state there is just "between records").
 // Anything else (odd formats, an error inside a chunk) returns false and the caller parses sequentially.
-static bool parse_parallel(const Input &d, Parsed &out) {
+// [from, to): `from` is 0 or a certain record start, `to` a certain record start or the end of the data (the whole file: 0, d.n);
+// `fastq` as find_record_start wants it (the kind of the FILE's first record).
+static bool parse_parallel_range(const Input &d, size_t from, size_t to, bool fastq, size_t min_bytes, Parsed &out) {
     const unsigned t = host_threads();
-    size_t min_bytes = 32u << 20;
-    if (const char *e = getenv("FLX_CLI_PARALLEL_PARSE_MIN")) min_bytes = (size_t)atoll(e);  // tests force it on small files
-    if (t < 2 || d.n < min_bytes || d.n < t || d.stream_error) return false;  // (a damaged stream: the sequential parser knows how kseq ends)
-    std::vector<size_t> start(t + 1, d.n);
-    start[0] = 0;
-    size_t h0 = 0;  // the kind of the first record decides which lines can start a record
-    while (h0 < d.n && d.p[h0] != '>' && d.p[h0] != '@') ++h0;
-    const bool fastq = h0 < d.n && d.p[h0] == '@';
+    const size_t len = to - from;
+    if (t < 2 || len < min_bytes || len < t || d.stream_error) return false;  // (a damaged stream: the sequential parser knows how kseq ends)
+    std::vector<size_t> start(t + 1, to);
+    start[0] = from;
     for (unsigned k = 1; k < t; ++k) {
-        start[k] = find_record_start(d, d.n / t * k, d.n / t * (k + 1), fastq);
-        if (start[k] >= d.n || start[k] <= start[k - 1]) return false;
+        start[k] = find_record_start(d, from + len / t * k, from + len / t * (k + 1), fastq);
+        if (start[k] >= to || start[k] <= start[k - 1]) return false;
     }
     struct Chunk { std::vector<Record> recs; std::deque<std::string> arena; bool ok = false; };
     std::vector<Chunk> chunks(t);
@@ -345,6 +343,53 @@ static bool parse_parallel(const Input &d, Parsed &out) {
     }
     out.status = -1;
     return true;
+}
+
+static bool first_record_is_fastq(const Input &d) {  // the kind of the first record decides which lines can start a record
+    size_t h0 = 0;
+    while (h0 < d.n && d.p[h0] != '>' && d.p[h0] != '@') ++h0;
+    return h0 < d.n && d.p[h0] == '@';
+}
+
+static bool parse_parallel(const Input &d, Parsed &out) {
+    size_t min_bytes = 32u << 20;
+    if (const char *e = getenv("FLX_CLI_PARALLEL_PARSE_MIN")) min_bytes = (size_t)atoll(e);  // tests force it on small files
+    if (d.n < min_bytes) return false;
+    return parse_parallel_range(d, 0, d.n, first_record_is_fastq(d), min_bytes, out);
+}
+
+// One rank's share of a mapped file (review of round 3, item 8: a rank that parses only its byte range).  Rank r of `world` owns
+// the records that START in [S_r, S_{r+1}), S_0 = 0, S_world = the end, S_k = the first certain record start at or behind byte
+// k * n / world — every rank computes its two borders itself, they are a function of the file.  Accepted (true) only if the range
+// ends exactly at S_{r+1} between two records and nothing in it is out of the ordinary (a parse error, the end of the data inside a
+// record): then the ranks' shares, in rank order, are what one sequential parse of the file gives.  On false the caller falls back
+// to parsing the whole file — on EVERY rank, which is why the decision is taken from a sum over the ranks.
+static bool parse_rank_range(const Input &d, int rank, int world, Parsed &out) {
+    if (world < 1 || rank < 0 || rank >= world || d.stream_error || d.n < (size_t)world) return false;
+    const bool fastq = first_record_is_fastq(d);
+    auto border = [&](int k) -> size_t {
+        if (k <= 0) return 0;
+        if (k >= world) return d.n;
+        return find_record_start(d, d.n / (size_t)world * (size_t)k, d.n / (size_t)world * (size_t)(k + 1), fastq);
+    };
+    const size_t from = border(rank), to = border(rank + 1);
+    if (from >= d.n || to <= from) return false;  // (no certain record start inside a slice: a file of very long or unusual records)
+    if (rank > 0 && border(rank - 1) >= from) return false;
+    size_t min_bytes = 32u << 20;
+    if (const char *e = getenv("FLX_CLI_PARALLEL_PARSE_MIN")) min_bytes = (size_t)atoll(e);
+    if (to - from >= min_bytes && parse_parallel_range(d, from, to, fastq, min_bytes, out)) return true;
+    out = Parsed();
+    out.arenas.emplace_back();
+    Parser p(d, out.arenas.back());
+    p.pos = from;
+    Record r;
+    for (;;) {
+        const size_t h = p.peek_header();
+        if (h >= to) { out.status = -1; return h == to; }
+        const long long l = p.next(r);
+        if (l < 0) return false;
+        out.recs.push_back(r);
+    }
 }
 
 static bool parse_all(const Input &d, Parsed &out) {  // true: the concurrent parse was accepted

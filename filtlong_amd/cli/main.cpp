@@ -70,7 +70,7 @@ static std::string pad(const std::string &s, size_t width) { return width > s.si
 #include "fastx.h"
 #include "gzblocks.h"
 
-// FLX_CLI_PARSE_ONLY=seq|par|blk: parse the input, print a digest of every field and exit (no GPU needed).  The CPU tests
+// FLX_CLI_PARSE_ONLY=seq|par|blk|unit|ranks:W: parse the input, print a digest of every field and exit (no GPU needed).  The CPU tests
 // compare the sequential parser with the concurrent one and with the block-wise reader on generated odd files.
 static int parse_only(const std::string &path, const char *mode) {
     uint64_t h = 1469598103934665603ull;
@@ -125,6 +125,24 @@ static int parse_only(const std::string &path, const char *mode) {
     }
     Input data;
     if (!data.open(path)) { std::cerr << "Error reading " << path << "\n"; return 1; }
+    if (strncmp(mode, "ranks:", 6) == 0) {
+        // ranks:W — every rank's share of the file (parse_rank_range), one after the other; accepted only if EVERY rank accepts its
+        // share, as the command line decides it from a sum over the ranks — else the whole file, as every rank would parse it then
+        const int world = std::max(1, atoi(mode + 6));
+        std::vector<Parsed> share((size_t)world);
+        bool all = data.map != nullptr;
+        for (int r = 0; r < world && all; ++r) all = parse_rank_range(data, r, world, share[(size_t)r]);
+        size_t n = 0;
+        if (all) {
+            for (const Parsed &sh : share) { mix_all(sh); n += sh.recs.size(); }
+        } else {
+            parse_all(data, parsed);
+            mix_all(parsed);
+            n = parsed.recs.size();
+        }
+        std::cout << "records " << n << " status " << parsed.status << " bad " << parsed.bad.name << " parallel " << (all ? 1 : 0) << " digest " << h << "\n";
+        return 0;
+    }
     if (mode[0] == 's') parse_sequential(data, parsed);
     else par = parse_all(data, parsed);
     mix_all(parsed);

@@ -247,3 +247,51 @@ def test_malformed_inputs_fail_like_the_reference_binary(tmp_path):
         assert (n.returncode, n.stdout, shown(n.stderr)) == (r.returncode, r.stdout, shown(r.stderr)), (i, argv[:-1], data[:300])
         compared += 1
     assert compared >= 120
+
+
+@pytest.mark.parametrize("style", ["plain", "atq", "crlf", "multiline", "blank", "mixedlen"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_rank_ranges_equal_sequential(tmp_path, style, world):
+    """A rank that parses only its byte range (filtlong_amd/cli/fastx.h: parse_rank_range; round-3 review, item 8): the shares of ranks
+    0..W-1, in rank order, are the records of one sequential parse — or some rank declines and the whole file is parsed, which is what
+    every rank of the command line then does.  Odd layouts, truncated files, more ranks than records."""
+    rng = np.random.RandomState(zlib.crc32(repr((style, world, "ranks")).encode()) % 2 ** 31)
+    for rep in range(3):
+        data = random_fastq(rng, int(rng.randint(1, 400)), style)
+        path = str(tmp_path / ("in_%s_%d.fastq" % (style, rep)))
+        open(path, "wb").write(data)
+        for threads in (1, 4):
+            seq, _ = digest(path, "seq", threads)
+            got, accepted = digest(path, "ranks:%d" % world, threads)
+            assert seq == got, (style, world, rep, threads, accepted)
+        cut = int(rng.randint(1, len(data)))
+        open(path, "wb").write(data[:cut])
+        seq, _ = digest(path, "seq")
+        got, accepted = digest(path, "ranks:%d" % world)
+        assert seq == got, (style, world, rep, "truncated at %d" % cut, accepted)
+
+
+def test_rank_ranges_are_taken_on_plain_fastq_and_fasta(tmp_path):
+    rng = np.random.RandomState(5)
+    path = str(tmp_path / "plain.fastq")
+    open(path, "wb").write(random_fastq(rng, 800, "plain"))
+    fa = str(tmp_path / "x.fasta")
+    open(fa, "wb").write(_cases.fasta_bytes(_cases.synth_reference(n_contigs=40, contig_len=500), width=60))
+    gt = bytearray()
+    for i in range(600):  # quality lines that start with '>' and '@'
+        L = int(rng.randint(20, 300))
+        gt += b"@q%d\n" % i + bytes(rng.choice(list(b"ACGT"), size=L).astype(np.uint8)) + b"\n+\n" + (b">" if i % 2 else b"@") * L + b"\n"
+    gtp = str(tmp_path / "gt.fastq")
+    open(gtp, "wb").write(bytes(gt))
+    for p in (path, fa, gtp):
+        seq, _ = digest(p, "seq")
+        for world in (2, 5, 8):
+            for threads in (1, 8):
+                got, accepted = digest(p, "ranks:%d" % world, threads)
+                assert accepted and got == seq, (p, world, threads)
+    # a gzip file is not split (it is not mapped): declined, and still the same records
+    import gzip
+    gz = str(tmp_path / "plain.fastq.gz")
+    open(gz, "wb").write(gzip.compress(open(path, "rb").read()))
+    got, accepted = digest(gz, "ranks:4")
+    assert not accepted and got == digest(gz, "seq")[0]
