@@ -786,6 +786,96 @@ int main(int argc, char **argv) {
     std::string last_plus_stash;    // ... or, from an earlier block of a streamed input, a copy of it
     bool last_plus_in_batch = false;
 
+    // ---- several ranks, a mapped file: every rank indexes only ITS byte range (round-3 review, item 8a; FLX_CLI_RANK_RANGES=1 — off by
+    // default until it has been through the GPU suite).  parse_rank_range gives the share; what the loop below checks record by record
+    // over the whole file becomes three facts about the shares and two exchanges:
+    //   * every share is accepted and made of ordinary records of ONE kind (FASTQ with as many qualities as bases, or FASTA in k-mer
+    //     mode), none empty, none longer than an int: a sum of flags.  Anything else — an error to report in file order, records
+    //     whose output depends on the ones in front of them (the header-only records below) — and EVERY rank parses the whole file
+    //     as before: the odd cases keep the code that is checked against the reference, and they are cheap or fatal anyway;
+    //   * no name occurs twice: the 64-bit hashes of all names, gathered (a sum into disjoint slots) and sorted on every rank; two
+    //     equal hashes — a duplicate or a collision — send every rank to the whole file as well;
+    //   * the progress lines of src/main.cpp:119-127 depend on every read's length in file order: gathered with the hashes, rank 0
+    //     replays them.
+    // 0: not taken (parse the whole file), 1: `mine` holds this rank's records and the totals are set, -1: the exchange failed.
+    bool ranged = false;
+    const bool rank_ranges = world > 1 && !streamed && data.map != nullptr && getenv("FLX_CLI_RANK_RANGES") != nullptr;
+    auto index_rank_range = [&](Parsed &mine) -> int {
+        bool ok = parse_rank_range(data, rank, world, mine);
+        bool fa = false, fq = false;
+        uint64_t bases = 0;
+        if (ok)
+            for (const Record &r : mine.recs) {
+                const bool fasta_format = r.qual.empty() && !r.seq.empty() && !r.is_fastq;
+                const bool fastq_format = r.is_fastq && !r.seq.empty() && r.qual.size() == r.seq.size();
+                if ((!fasta_format && !fastq_format) || r.seq.size() > (size_t)INT32_MAX) { ok = false; break; }
+                fa = fa || fasta_format;
+                fq = fq || fastq_format;
+                bases += r.seq.size();
+            }
+        const uint64_t n_mine = ok ? mine.recs.size() : 0;
+        std::vector<uint64_t> v(3 + 2 * (size_t)world, 0);
+        v[0] = ok; v[1] = ok && fa; v[2] = ok && fq;
+        v[3 + (size_t)rank] = n_mine;
+        v[3 + (size_t)world + (size_t)rank] = ok ? bases : 0;
+        if (flx_comm_sum_u64(ctx, v.data(), v.size()) != FLX_OK) return -1;
+        if (v[0] != (uint64_t)world || (v[1] && v[2]) || (v[1] && kmers_empty)) return 0;
+        uint64_t n_all = 0, lo = 0, bases_all = 0;
+        for (int r = 0; r < world; ++r) {
+            if (r == rank) lo = n_all;
+            n_all += v[3 + (size_t)r];
+            bases_all += v[3 + (size_t)world + (size_t)r];
+        }
+        // names and lengths of every read, in file order: hashes in [0, n_all), lengths two to a word behind them
+        std::vector<uint64_t> w(n_all + (n_all + 1) / 2, 0);
+        parallel_for(std::min<size_t>(std::max<size_t>(1, n_mine), 64), [&](size_t k) {
+            const size_t parts = std::min<size_t>(std::max<size_t>(1, n_mine), 64);
+            for (size_t i = n_mine * k / parts; i < n_mine * (k + 1) / parts; ++i) {
+                uint64_t h = 1469598103934665603ull;
+                const View &nm = mine.recs[i].name;
+                for (size_t q = 0; q < nm.n; ++q) { h ^= (unsigned char)nm.p[q]; h *= 1099511628211ull; }
+                w[lo + i] = h ^ (h >> 29);
+            }
+        });
+        for (uint64_t i = 0; i < n_mine; ++i)  // (serial: two neighbours share a word)
+            w[n_all + ((lo + i) >> 1)] |= (uint64_t)(uint32_t)mine.recs[i].seq.size() << (32 * ((lo + i) & 1));
+        if (flx_comm_sum_u64(ctx, w.data(), w.size()) != FLX_OK) return -1;
+        {  // two equal hashes anywhere?  1024 buckets by the top bits, sorted concurrently
+            const size_t NB = 1024;
+            std::vector<size_t> at(NB + 1, 0);
+            for (uint64_t i = 0; i < n_all; ++i) ++at[(w[i] >> 54) + 1];
+            for (size_t b = 0; b < NB; ++b) at[b + 1] += at[b];
+            std::vector<uint64_t> sorted(n_all);
+            {
+                std::vector<size_t> cur(at.begin(), at.end() - 1);
+                for (uint64_t i = 0; i < n_all; ++i) sorted[cur[w[i] >> 54]++] = w[i];
+            }
+            std::vector<char> twice(NB, 0);
+            parallel_for(NB, [&](size_t b) {
+                std::sort(sorted.begin() + (ptrdiff_t)at[b], sorted.begin() + (ptrdiff_t)at[b + 1]);
+                for (size_t i = at[b] + 1; i < at[b + 1]; ++i)
+                    if (sorted[i] == sorted[i - 1]) { twice[b] = 1; break; }
+            });
+            for (char t : twice)
+                if (t) return 0;
+        }
+        n_records = n_all;
+        total_bases = (long long)bases_all;
+        any_fasta = v[1] != 0;
+        any_fastq = v[2] != 0;
+        if (rank == 0 && !args.verbose) {  // the progress lines, as the loop below prints them read by read
+            long long tb = 0, lp = 0;
+            for (uint64_t i = 0; i < n_all; ++i) {
+                tb += (long long)((w[n_all + (i >> 1)] >> (32 * (i & 1))) & 0xffffffffull);
+                if (tb - lp >= 483611) {
+                    lp = tb;
+                    std::cerr << "\r  " << int_to_string((long long)(i + 1)) << " reads (" << int_to_string(tb) << " bp)";
+                }
+            }
+        }
+        return 1;
+    };
+
     // An error of the INPUT is found by every rank at the same record (all of them index the whole file): rank 0 reports it and
     // ends the job; the others leave quietly with status 0, so that the watchdog does not take their exit for a rank that died
     // while rank 0 is still scoring and printing the --verbose blocks in front of the error.
@@ -800,11 +890,25 @@ int main(int argc, char **argv) {
             }
         } else {
             if (n_batches > 0) break;
-            parse_all(data, batch);
+            const int took = rank_ranges ? index_rank_range(batch) : 0;
+            if (took < 0) return fail_flx(ctx, "exchange");
+            ranged = took > 0;
+            if (!ranged) {
+                batch = Parsed();
+                parse_all(data, batch);
+            }
             stage("parse");
         }
         ++n_batches;
         const std::vector<Record> &recs = batch.recs;
+        if (ranged) {  // every check of the loop below has been made for the whole file (index_rank_range): this rank's records are its share
+            lo_rec = 0;
+            names.reserve(recs.size());
+            for (const Record &r : recs) names.push_back(r.name.sv());
+            if (g_timing) fprintf(stderr, "[timing] rank ranges: %llu of %llu records indexed here\n", (unsigned long long)recs.size(), (unsigned long long)n_records);
+            if (const int rc = score_records(recs, 0, recs.size())) return rc;
+            continue;
+        }
         // the per-record checks of src/main.cpp:84-117, in file order, then the parser's own end status
         // Duplicate names (src/main.cpp:113-117: the first record whose name an earlier record has).  Streamed input: a set, block
         // after block.  Mapped input: every thread owns the names whose hash falls into its share, walks the records in file order and
