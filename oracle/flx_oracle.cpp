@@ -23,6 +23,8 @@
 // /root/reference).
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -365,6 +367,75 @@ extern "C" int flo_score_read(const flo_kmerset *set, const char *seq, const cha
         children[i].n_child = 0;
     }
     return 0;
+}
+
+// ---------------------------------------------------------------------------
+// the same constructor over a packed batch, on several host threads (whole-population parity at BASELINE size:
+// tests/test_gpu_fullsize.py re-scores 10^5..10^6 reads of the device's own plane).  Every read goes through
+// flo_score_read above; the threads only share the read-only set.  Children come back as a CSR in read order.
+// Returns the number of children, or -1 if a read has more than `cap_per_read` children / the CSR more than child_cap.
+// ---------------------------------------------------------------------------
+extern "C" int64_t flo_score_plane_mt(const flo_kmerset *set, int kmer_plane, const uint8_t *plane, const uint64_t *offsets,
+                                      const int32_t *lengths, uint64_t n, const flo_params *p, int n_threads, double *mean_q,
+                                      double *window_q, uint8_t *passed, int32_t *first, int32_t *last,
+                                      uint64_t *child_offsets, uint64_t child_cap, int32_t *child_ranges, double *child_mean_q,
+                                      double *child_window_q, uint8_t *child_passed) {
+    struct Kid { uint64_t read; int32_t s, e; double mean, window; uint8_t passed; };
+    if (n_threads < 1) n_threads = 1;
+    std::vector<std::vector<Kid>> kids((size_t)n_threads);
+    std::vector<uint32_t> n_kids((size_t)n + 1, 0u);
+    std::atomic<uint64_t> next(0);
+    std::atomic<int> failed(0);
+    const int cap = 4096;
+    auto work = [&](int t) {
+        std::vector<int32_t> bad(2 * cap), rng(2 * cap);
+        std::vector<flo_read_result> ch((size_t)cap);
+        for (;;) {
+            const uint64_t b = next.fetch_add(64);
+            if (b >= n) break;
+            for (uint64_t i = b; i < std::min<uint64_t>(b + 64, n); ++i) {
+                flo_read_result r;
+                const char *bytes = (const char *)plane + offsets[i];
+                if (flo_score_read(set, kmer_plane ? bytes : nullptr, kmer_plane ? nullptr : bytes, lengths[i], p, &r, bad.data(),
+                                   rng.data(), ch.data(), cap) != 0) {
+                    failed = 1;
+                    continue;
+                }
+                mean_q[i] = r.mean_q;
+                window_q[i] = r.window_q;
+                passed[i] = (uint8_t)r.passed;
+                if (first) first[i] = r.first;
+                if (last) last[i] = r.last;
+                n_kids[i] = (uint32_t)r.n_child;
+                for (int k = 0; k < r.n_child; ++k)
+                    kids[(size_t)t].push_back(Kid{i, rng[2 * k], rng[2 * k + 1], ch[k].mean_q, ch[k].window_q, (uint8_t)ch[k].passed});
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    if (failed) return -1;
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (child_offsets) child_offsets[i] = total;
+        total += n_kids[i];
+    }
+    if (child_offsets) child_offsets[n] = total;
+    if (total == 0) return 0;
+    if (!child_offsets || total > child_cap) return -1;
+    std::vector<uint32_t> fill((size_t)n, 0u);  // a read's children were pushed in order by ONE thread
+    for (auto &v : kids)
+        for (auto &k : v) {
+            const uint64_t at = child_offsets[k.read] + fill[k.read]++;
+            child_ranges[2 * at] = k.s;
+            child_ranges[2 * at + 1] = k.e;
+            child_mean_q[at] = k.mean;
+            child_window_q[at] = k.window;
+            child_passed[at] = k.passed;
+        }
+    return (int64_t)total;
 }
 
 // ---------------------------------------------------------------------------

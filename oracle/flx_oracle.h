@@ -76,6 +76,14 @@ int flo_score_read(const flo_kmerset *set, const char *seq, const char *qual, in
                    flo_read_result *out, int32_t *bad_ranges, int32_t *child_ranges, flo_read_result *children,
                    int cap);
 
+/* flo_score_read over a packed batch on n_threads host threads (kmer_plane: the plane holds sequences, else quality strings);
+ * children as a CSR in read order; returns the number of children or -1 */
+int64_t flo_score_plane_mt(const flo_kmerset *set, int kmer_plane, const uint8_t *plane, const uint64_t *offsets,
+                           const int32_t *lengths, uint64_t n, const flo_params *p, int n_threads, double *mean_q,
+                           double *window_q, uint8_t *passed, int32_t *first, int32_t *last, uint64_t *child_offsets,
+                           uint64_t child_cap, int32_t *child_ranges, double *child_mean_q, double *child_window_q,
+                           uint8_t *child_passed);
+
 /* a19b: reads2 = file order with every parent replaced in place by its children (src/main.cpp:138-147).
  * child_offsets[n+1] is the CSR of the children (children of read i: child_offsets[i] .. child_offsets[i+1]-1, each with
  * its (start,end) range).  Outputs hold n - #parents-with-children + #children entries; returns that count. */

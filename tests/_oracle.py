@@ -198,6 +198,36 @@ def score_read(seq, qual, params, kmerset=None, cap=4096):
     }
 
 
+def score_plane_mt(plane, offsets, lengths, params, kmerset=None, threads=None, child_cap=None):
+    """flo_score_plane_mt: every read of a packed batch through flo_score_read on `threads` host threads (default: all the
+    cores this process may use).  plane: uint8 array (quality strings, or sequences when kmerset is given); returns the per-read
+    arrays and the children as a CSR (keys as filtlong_amd.api.Context.score_reads returns them)."""
+    n = len(lengths)
+    if threads is None:
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    pl = np.ascontiguousarray(plane, dtype=np.uint8)
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    ln = np.ascontiguousarray(lengths, dtype=np.int32)
+    cap = int(child_cap if child_cap is not None else 4 * n + 16)
+    out = {"mean_q": np.zeros(n, np.float64), "window_q": np.zeros(n, np.float64), "passed": np.zeros(n, np.uint8),
+           "first": np.zeros(n, np.int32), "last": np.zeros(n, np.int32), "child_offsets": np.zeros(n + 1, np.uint64),
+           "child_ranges": np.zeros((cap, 2), np.int32), "child_mean_q": np.zeros(cap, np.float64),
+           "child_window_q": np.zeros(cap, np.float64), "child_passed": np.zeros(cap, np.uint8)}
+    f = lib().flo_score_plane_mt
+    f.restype = C.c_int64
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Params), C.c_int] + [C.c_void_p] * 6 \
+        + [C.c_uint64] + [C.c_void_p] * 4
+    nc = f(kmerset.h if kmerset is not None else None, 1 if kmerset is not None else 0, pl.ctypes.data, off.ctypes.data, ln.ctypes.data, n,
+           C.byref(params), int(threads), out["mean_q"].ctypes.data, out["window_q"].ctypes.data, out["passed"].ctypes.data,
+           out["first"].ctypes.data, out["last"].ctypes.data, out["child_offsets"].ctypes.data, cap, out["child_ranges"].ctypes.data,
+           out["child_mean_q"].ctypes.data, out["child_window_q"].ctypes.data, out["child_passed"].ctypes.data)
+    assert nc >= 0, "flo_score_plane_mt failed (child capacity?)"
+    for k in ("child_ranges", "child_mean_q", "child_window_q", "child_passed"):
+        out[k] = out[k][:nc]
+    out["n_children"] = int(nc)
+    return out
+
+
 def reads2_gather(lengths, sc):
     """flo_reads2_gather on a score dictionary (keys as filtlong_amd.api.Context.score_reads returns them)."""
     n = len(lengths)

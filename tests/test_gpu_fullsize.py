@@ -2,7 +2,9 @@
 --target_bases 50 % of the bases), checked through properties that do not need a full CPU scoring run:
 
   * per-read exactness on a sample: reads are independent, so the oracle re-scores ~300 of them (regenerated on the
-    host from the same integer hash) and must match the device bit for bit;
+    host from the same integer hash) and must match the device bit for bit — and since round 5 on a whole POPULATION: the
+    first 10^6 reads of C2 (10^5 of C3 / C4, children and ranges included) re-scored by the oracle on every host core from
+    the device's own plane bytes, every field bit for bit;
   * the global stage is re-run by the ORACLE on the device's 10^7 per-read values (std::sort of 10^7 takes seconds):
     exact statistics and IDENTICAL pass set;
   * threshold structure: every kept read scores >= every dropped-but-passed read; the walk overshoots the target by
@@ -64,6 +66,21 @@ def test_c2_full_size_properties():
     for i in sample:
         w = _oracle.score_read(None, synth.qual_read(int(i), int(lengths[i])).tobytes(), p)
         assert w["mean_q"] == mean[i] and w["window_q"] == win[i] and w["passed"] == pre[i], int(i)
+
+    # 1b. WHOLE-POPULATION exactness on the first 10^6 reads (10^10 bases: every lane of ~15 000 wavefronts, ticket scheduler,
+    # tail groups and redo list included): the oracle re-scores the device's OWN plane bytes on every host core (flo_score_plane_mt
+    # = flo_score_read per read), 10^5 reads at a time, and every mean / window / pass flag must match bit for bit
+    # (src/read.cpp:25-73, 208-236)
+    n_pop, step = (1_000_000, 100_000) if n >= 1_000_000 else (n, n)
+    for a in range(0, n_pop, step):
+        b = min(a + step, n_pop)
+        lo, hi = int(offsets[a]), int(offsets[b - 1]) + int(lengths[b - 1])
+        chunk = d_plane[lo:hi].cpu().numpy()
+        w = _oracle.score_plane_mt(chunk, offsets[a:b] - np.uint64(lo), lengths[a:b], p)
+        assert (w["mean_q"].view(np.uint64) == mean[a:b].view(np.uint64)).all(), ("mean_q", a)
+        assert (w["window_q"].view(np.uint64) == win[a:b].view(np.uint64)).all(), ("window_q", a)
+        assert (w["passed"] == pre[a:b]).all(), ("passed", a)
+        del chunk, w
 
     # 2. oracle global stage on the device's per-read values: exact statistics, identical pass set
     want = _oracle.rank_and_cut(mean, win, lengths, pre, target_bases=total // 2, total_bases=total)
@@ -233,6 +250,27 @@ def test_kmer_mode_properties(short_reads, size):
         for k, ch in enumerate(w["children"]):
             assert w["child_ranges"][k] == (int(crng[a + k, 0]), int(crng[a + k, 1])), (int(i), k)
             assert ch["mean_q"] == cmean[a + k] and ch["window_q"] == cwin[a + k] and ch["passed"] == cpass[a + k], (int(i), k)
+
+    # WHOLE-POPULATION exactness on the first 10^5 reads (10^9 bases through the reference's own unordered_set lookups, on every
+    # host core): the oracle re-scores the device's own plane bytes — every mean, window, first / last, pass flag, child range and
+    # child score bit for bit (src/read.cpp:25-144)
+    n_pop = min(n, 100_000)
+    hi = int(offsets[n_pop - 1]) + int(lengths[n_pop - 1])
+    chunk = d_plane[:hi].cpu().numpy()
+    w = _oracle.score_plane_mt(chunk, offsets[:n_pop], lengths[:n_pop], p, kmerset=oset)
+    del chunk
+    dev_pass = t["pass"].cpu().numpy()
+    assert (w["mean_q"].view(np.uint64) == mean[:n_pop].view(np.uint64)).all()
+    assert (w["window_q"].view(np.uint64) == win[:n_pop].view(np.uint64)).all()
+    assert (w["first"] == first[:n_pop]).all() and (w["last"] == last[:n_pop]).all() and (w["passed"] == dev_pass[:n_pop]).all()
+    assert (w["child_offsets"] == coff[:n_pop + 1].view(np.uint64)).all()
+    nc = w["n_children"]
+    assert nc == int(coff[n_pop]) and (short_reads or nc == 0)
+    assert (w["child_ranges"] == crng[:nc]).all()
+    assert (w["child_mean_q"].view(np.uint64) == cmean[:nc].view(np.uint64)).all()
+    assert (w["child_window_q"].view(np.uint64) == cwin[:nc].view(np.uint64)).all()
+    assert (w["child_passed"] == cpass[:nc]).all()
+    del w
 
     # The global stage at this size (src/main.cpp:138-147 then 169-261): the device's reads2 gather equals the oracle's loop
     # entry for entry, and on those reads2 arrays the ORACLE (its std::sort over all ~1.2x10^7 entries) gives the same

@@ -208,3 +208,45 @@ def test_bloom_false_positive_rule():
     for k, v in gold["present"].items():
         assert ks.contains(int(k)) == v
     assert len(ks) == 1
+
+
+def test_batch_scorer_equals_per_read_calls():
+    """flo_score_plane_mt (the oracle on every host thread over a packed batch: whole-population parity at BASELINE size,
+    tests/test_gpu_fullsize.py) is flo_score_read per read — the function the goldens above pin — in Phred mode and in k-mer
+    mode with children, any number of threads."""
+    from filtlong_amd import synth
+    n = 150
+    lens = np.maximum(synth.lengths(n, first=7) // 8, 1)
+    offs = np.concatenate([[0], np.cumsum((lens.astype(np.int64) + 15) // 16 * 16)]).astype(np.uint64)
+    # Phred mode
+    plane = np.zeros(int(offs[-1]), np.uint8)
+    quals = [synth.qual_read(7 + i, int(L)) for i, L in enumerate(lens)]
+    for o, q in zip(offs, quals):
+        plane[int(o):int(o) + len(q)] = q
+    p = _oracle.make_params(min_length=300, min_mean_q=80.0)
+    for th in (1, 3):
+        got = _oracle.score_plane_mt(plane, offs[:-1], lens, p, threads=th)
+        for i, q in enumerate(quals):
+            w = _oracle.score_read(None, q.tobytes(), p)
+            assert (w["mean_q"], w["window_q"], w["passed"]) == (got["mean_q"][i], got["window_q"][i], got["passed"][i])
+        assert got["n_children"] == 0
+    # k-mer mode, --trim --split 200
+    ref = synth.bases_read(synth.STREAM_REF, 0, 0, 60000)
+    ks = _oracle.KmerSet()
+    ks.add_assembly([ref.tobytes()])
+    seqs = [synth.seq_read(7 + i, int(L), ref) for i, L in enumerate(lens)]
+    for o, q in zip(offs, seqs):
+        plane[int(o):int(o) + len(q)] = q
+    p = _oracle.make_params(trim=True, split=200, window_size=100)
+    for th in (1, 4):
+        got = _oracle.score_plane_mt(plane, offs[:-1], lens, p, kmerset=ks, threads=th)
+        co = got["child_offsets"]
+        assert int(co[-1]) == got["n_children"] > 0
+        for i, q in enumerate(seqs):
+            w = _oracle.score_read(q.tobytes(), None, p, kmerset=ks)
+            assert (w["mean_q"], w["window_q"], w["passed"], w["first"], w["last"]) == (
+                got["mean_q"][i], got["window_q"][i], got["passed"][i], got["first"][i], got["last"][i])
+            a, b = int(co[i]), int(co[i + 1])
+            assert [tuple(r) for r in got["child_ranges"][a:b]] == w["child_ranges"]
+            assert [(c["mean_q"], c["window_q"], c["passed"]) for c in w["children"]] == list(
+                zip(got["child_mean_q"][a:b], got["child_window_q"][a:b], got["child_passed"][a:b]))
