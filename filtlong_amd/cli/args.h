@@ -1,6 +1,7 @@
 // args.h — the command line of the drop-in binary: flags, unit suffixes, validation order and messages of the reference
 // (src/arguments.cpp:28-393, src/args.h for the generic readers).  Included by main.cpp only.
 #pragma once
+#include <sys/ioctl.h>
 #include <climits>
 #include <cmath>
 #include <fstream>
@@ -96,39 +97,109 @@ static long long read_ll(const std::string &name, const std::string &value, long
     return v;
 }
 
+// The help menu of the reference, byte for byte: src/arguments.cpp:126-221 declares the flags and groups and hands them to the
+// formatter of the vendored src/args.h (Help(), 1065-1218, and Wrap(), 94-149), whose layout is a function of the width of the
+// terminal on STDOUT (TIOCGWINSZ; indent 1 / 2 / 3 / 4 for widths up to 60 / 80 / 120 / beyond).  When stdout is no terminal the
+// reference reads the width out of an untouched `struct winsize` — 0 in practice: the description comes out one word per line and,
+// the other widths being unsigned differences that wrap around, nothing else is wrapped at all.  Both cases are restated here.
+// (--gpus, this binary's one flag of its own, is documented in README.md: the menu is the reference's.)
+static std::vector<std::string> help_wrap(const std::string &in, size_t width, size_t first = 0) {  // src/args.h:94-149
+    std::vector<std::string> out;
+    size_t cur = first ? first : width, linesize = 0;
+    std::string line;
+    std::istringstream ss(in);
+    while (ss) {
+        std::string item;
+        ss >> item;
+        if (linesize + 1 + item.size() > cur && linesize > 0) {
+            out.push_back(line);
+            line.clear();
+            linesize = 0;
+            cur = width;
+        }
+        if (!item.empty()) {
+            if (linesize) { ++linesize; line += ' '; }
+            line += item;
+            linesize += item.size();
+        }
+    }
+    if (linesize > 0) out.push_back(line);
+    return out;
+}
+
 static void print_help(const char *prog) {
-    std::cerr <<
-        "  " << prog << " {OPTIONS} [input_reads]\n\n"
-        "Filtlong: a quality filtering tool for Nanopore and PacBio reads\n"
-        "(MI355X-native scoring hot path; drop-in for the reference command line)\n\n"
-        "usage:\n"
-        "  positional arguments:\n"
-        "    input_reads                         input long reads to be filtered\n\n"
-        "  output thresholds:\n"
-        "    -t[int], --target_bases [int]       keep only the best reads up to this many total bases (unit suffixes: k, kb, m, mb, g, gb)\n"
-        "    -p[float], --keep_percent [float]   keep only this percentage of the best reads (measured by bases)\n"
-        "    -l[int], --min_length [int]         minimum length threshold (unit suffixes: k, kb, m, mb, g, gb)\n"
-        "    -L[int], --max_length [int]         maximum length threshold (unit suffixes: k, kb, m, mb, g, gb)\n"
-        "    -q[float], --min_mean_q [float]     minimum mean quality threshold\n"
-        "    --min_window_q [float]              minimum window quality threshold\n\n"
-        "  external references (if provided, read quality will be determined using these instead of from the Phred scores):\n"
-        "    -a[file], --assembly [file]         reference assembly in FASTA format\n"
-        "    -1[file], --short_1 [file]          reference short reads in FASTQ format\n"
-        "    -2[file], --short_2 [file]          reference short reads in FASTQ format\n\n"
-        "  score weights (control the relative contribution of each score to the final read score):\n"
-        "    --length_weight [float]             weight given to the length score (default: 1)\n"
-        "    --mean_q_weight [float]             weight given to the mean quality score (default: 1)\n"
-        "    --window_q_weight [float]           weight given to the window quality score (default: 1)\n\n"
-        "  read manipulation:\n"
-        "    --trim                              trim non-k-mer-matching bases from start/end of reads\n"
-        "    --split [split]                     split reads at this many (or more) consecutive non-k-mer-matching bases (unit suffixes: k, kb, m, mb, g, gb)\n\n"
-        "  other:\n"
-        "    --window_size [int]                 size of sliding window used when measuring window quality (default: 250)\n"
-        "    --verbose                           verbose output to stderr with info for each read\n"
-        "    --gpus [int]                        score on this many GPUs of the node (one process per GPU, RCCL; default: 1)\n"
-        "    --version                           display the program version and quit\n"
-        "    -h, --help                          display this help menu\n\n"
-        "For more information, go to: https://github.com/rrwick/Filtlong\n";
+    struct winsize ws;
+    memset(&ws, 0, sizeof ws);
+    ioctl(STDOUT_FILENO, TIOCGWINSZ, &ws);
+    const unsigned width = ws.ws_col;
+    const unsigned indent = width > 120 ? 4 : width > 80 ? 3 : width > 60 ? 2 : 1;
+    const unsigned flagindent = indent, eachgroup = indent, helpindent = 40, gutter = 1;  // progindent = descriptionindent = 0
+    struct Entry { const char *names, *info; unsigned level; };
+    static const Entry positional[] = {{"input_reads", "input long reads to be filtered", 0}};
+    static const Entry optional[] = {
+        {"output thresholds:", "", 0},
+        {"-t[int], --target_bases [int]", "keep only the best reads up to this many total bases (unit suffixes: k, kb, m, mb, g, gb)", 1},
+        {"-p[float], --keep_percent [float]", "keep only this percentage of the best reads (measured by bases)", 1},
+        {"-l[int], --min_length [int]", "minimum length threshold (unit suffixes: k, kb, m, mb, g, gb)", 1},
+        {"-L[int], --max_length [int]", "maximum length threshold (unit suffixes: k, kb, m, mb, g, gb)", 1},
+        {"-q[float], --min_mean_q [float]", "minimum mean quality threshold", 1},
+        {"--min_window_q [float]", "minimum window quality threshold", 1},
+        {"NLexternal references (if provided, read quality will be determined using these instead of from the Phred scores):", "", 0},
+        {"-a[file], --assembly [file]", "reference assembly in FASTA format", 1},
+        {"-1[file], --short_1 [file]", "reference short reads in FASTQ format", 1},
+        {"-2[file], --short_2 [file]", "reference short reads in FASTQ format", 1},
+        {"NLscore weights (control the relative contribution of each score to the final read score):", "", 0},
+        {"--length_weight [float]", "weight given to the length score (default: 1)", 1},
+        {"--mean_q_weight [float]", "weight given to the mean quality score (default: 1)", 1},
+        {"--window_q_weight [float]", "weight given to the window quality score (default: 1)", 1},
+        {"NLread manipulation:", "", 0},
+        {"--trim", "trim non-k-mer-matching bases from start/end of reads", 1},
+        {"--split [split]", "split reads at this many (or more) consecutive non-k-mer-matching bases (unit suffixes: k, kb, m, mb, g, gb)", 1},
+        {"NLother:", "", 0},
+        {"--window_size [int]", "size of sliding window used when measuring window quality (default: 250)", 1},
+        {"--verbose", "verbose output to stderr with info for each read", 1},
+        {"--version", "display the program version and quit", 1},
+        {"-h, --help", "display this help menu", 0},
+    };
+    std::ostream &os = std::cerr;
+    const std::string progline = std::string("usage: ") + prog + " {OPTIONS} [input_reads]";
+    const auto proglines = help_wrap(progline, (size_t)(unsigned)(width - 4u), (size_t)width);
+    for (size_t i = 0; i < proglines.size(); ++i) os << (i ? "    " : "") << proglines[i] << '\n';  // (progtailindent 4)
+    os << '\n';
+    for (const auto &l : help_wrap("Filtlong: a quality filtering tool for Nanopore and PacBio reads", width)) os << l << "\n";
+    os << "\n";
+    auto block = [&](const Entry &e, bool optional_rules) {
+        const unsigned groupindent = e.level * eachgroup;
+        const std::string names = e.names;
+        const bool nl = optional_rules && names.compare(0, 2, "NL") == 0;
+        // (unsigned differences, as in the reference: a width below the indents wraps around to "never wrap")
+        const unsigned flag_width = nl ? width - (flagindent + gutter) : width - (flagindent + helpindent + gutter);
+        const auto flags = help_wrap(names, (size_t)flag_width);
+        const auto info = help_wrap(e.info, (size_t)(unsigned)(width - (helpindent + groupindent)));
+        size_t flagssize = 0;
+        for (size_t i = 0; i < flags.size(); ++i) {
+            if (i) os << '\n';
+            const bool line_nl = optional_rules && flags[i].compare(0, 2, "NL") == 0;
+            if (optional_rules && (line_nl || flags[i].compare(0, 2, "-h") == 0)) os << '\n';
+            os << std::string(groupindent + flagindent, ' ') << (line_nl ? flags[i].substr(2) : flags[i]);
+            flagssize = flags[i].size() - (line_nl ? 2 : 0);
+        }
+        size_t k = 0;
+        if (flagindent + flagssize + gutter > helpindent || info.empty()) {
+            os << '\n';
+        } else {
+            os << std::string(helpindent - (flagindent + flagssize), ' ') << info[0] << '\n';
+            k = 1;
+        }
+        for (; k < info.size(); ++k) os << std::string(groupindent + helpindent, ' ') << info[k] << '\n';
+    };
+    os << "positional arguments:\n";
+    for (const Entry &e : positional) block(e, false);
+    os << "\n";
+    os << "optional arguments:\n";
+    for (const Entry &e : optional) block(e, true);
+    os << "\n";
+    for (const auto &l : help_wrap("For more information, go to: https://github.com/rrwick/Filtlong", width)) os << l << "\n";
 }
 
 static bool file_exists(const std::string &f) { std::ifstream in(f); return in.good(); }

@@ -181,47 +181,7 @@ static int fail_flx(flx_ctx *ctx, const char *what) {
     return 1;
 }
 
-static void print_hash_progress(const std::string &filename, long long base_count) {
-    std::cerr << "\r  " << filename << " (" << int_to_string(base_count) << " bp)";
-}
-
-// reads one reference file; returns the number of sequences (counting those < 16 bp, src/kmers.cpp:96-100)
-static int load_reference(const std::string &filename, std::vector<std::string> &seqs) {
-    Input data;
-    int n = 0;
-    long long bases = 0;
-    std::deque<std::string> arena;
-    if (data.open(filename)) {
-        Parser p(data, arena);
-        Record r;
-        long long l;
-        while ((l = p.next(r)) >= 0) {  // errors end the loop silently, like src/kmers.cpp:91-94
-            ++n;
-            if (r.seq.size() < 16) continue;
-            bases += (long long)r.seq.size();
-            seqs.push_back(r.seq.str());
-        }
-    }
-    print_hash_progress(filename, bases);
-    std::cerr << "\n";
-    return n;
-}
-
-static int add_sequences(flx_ctx *ctx, flx_kmerset *set, const std::vector<std::string> &seqs, bool short_reads) {
-    std::vector<uint64_t> offsets(seqs.size());
-    std::vector<int64_t> lengths(seqs.size());
-    uint64_t total = 0;
-    for (size_t i = 0; i < seqs.size(); ++i) { offsets[i] = total; lengths[i] = (int64_t)seqs[i].size(); total += seqs[i].size(); }
-    std::string bases;
-    bases.reserve(total + 1);
-    for (auto &s : seqs) bases += s;
-    if (bases.empty()) bases.push_back('\0');
-    const int rc = short_reads
-        ? flx_kmerset_add_short_reads(set, (const uint8_t *)bases.data(), offsets.data(), lengths.data(), seqs.size())
-        : flx_kmerset_add_assembly(set, (const uint8_t *)bases.data(), offsets.data(), lengths.data(), seqs.size());
-    (void)ctx;
-    return rc;
-}
+#include "reference.h"
 
 // ---- ordered pieces ----------------------------------------------------------------------------------------------------
 // The output is produced as `n` independent pieces by several threads.  produce(j, piece) fills piece j and says whether it
@@ -559,30 +519,27 @@ int main(int argc, char **argv) {
         if (args.assembly_set) {
             std::cerr << "Hashing 16-mers from assembly\n";
             std::cerr << "  " << args.assembly << "\n";
-            std::vector<std::string> seqs;
-            const int count = load_reference(args.assembly, seqs);
-            if (add_sequences(ctx, kmers, seqs, false) != FLX_OK) return fail_flx(ctx, "assembly");
-            if (args.short_reads.empty()) {
-                if (flx_kmerset_finalize(kmers) != FLX_OK) return fail_flx(ctx, "k-mer set");
-                std::cerr << "  " << int_to_string(count) << " " << (count == 1 ? "contig" : "contigs") << ", "
-                          << int_to_string((long long)flx_kmerset_size(kmers)) << " 16-mers\n\n";
-            } else {
-                // the reference prints the set size after the assembly alone; that needs a count before the short reads
-                flx_kmerset *tmp = nullptr;
-                if (flx_kmerset_create(ctx, &tmp) != FLX_OK) return fail_flx(ctx, "k-mer set");
-                if (add_sequences(ctx, tmp, seqs, false) != FLX_OK || flx_kmerset_finalize(tmp) != FLX_OK) return fail_flx(ctx, "assembly");
-                std::cerr << "  " << int_to_string(count) << " " << (count == 1 ? "contig" : "contigs") << ", "
-                          << int_to_string((long long)flx_kmerset_size(tmp)) << " 16-mers\n\n";
-                flx_kmerset_destroy(tmp);
-            }
+            // the reference prints the set's size after the assembly alone (src/kmers.cpp:60-72); with short reads to follow that
+            // takes a second set, which is fed the same batches and dropped once it has been counted
+            flx_kmerset *alone = nullptr;
+            if (!args.short_reads.empty() && flx_kmerset_create(ctx, &alone) != FLX_OK) return fail_flx(ctx, "k-mer set");
+            flx_kmerset *both[2] = {kmers, alone};
+            bool ok = true;
+            const int count = hash_reference(args.assembly, both, alone ? 2 : 1, false, ok);
+            if (!ok) return fail_flx(ctx, "assembly");
+            flx_kmerset *counted = alone ? alone : kmers;
+            if (flx_kmerset_finalize(counted) != FLX_OK) return fail_flx(ctx, alone ? "assembly" : "k-mer set");
+            std::cerr << "  " << int_to_string(count) << " " << (count == 1 ? "contig" : "contigs") << ", "
+                      << int_to_string((long long)flx_kmerset_size(counted)) << " 16-mers\n\n";
+            if (alone) flx_kmerset_destroy(alone);
         }
         if (!args.short_reads.empty()) {
             std::cerr << "Hashing 16-mers from short reads\n";
             int count = 0;
             for (auto &f : args.short_reads) {
-                std::vector<std::string> seqs;
-                count += load_reference(f, seqs);
-                if (add_sequences(ctx, kmers, seqs, true) != FLX_OK) return fail_flx(ctx, "short reads");
+                bool ok = true;
+                count += hash_reference(f, &kmers, 1, true, ok);
+                if (!ok) return fail_flx(ctx, "short reads");
             }
             if (flx_kmerset_finalize(kmers) != FLX_OK) return fail_flx(ctx, "k-mer set");
             std::cerr << "  " << int_to_string(count) << " reads, " << int_to_string((long long)flx_kmerset_size(kmers)) << " 16-mers\n\n";
@@ -786,8 +743,8 @@ int main(int argc, char **argv) {
     std::string last_plus_stash;    // ... or, from an earlier block of a streamed input, a copy of it
     bool last_plus_in_batch = false;
 
-    // ---- several ranks, a mapped file: every rank indexes only ITS byte range (round-3 review, item 8a; FLX_CLI_RANK_RANGES=1 — off by
-    // default until it has been through the GPU suite).  parse_rank_range gives the share; what the loop below checks record by record
+    // ---- several ranks, a mapped file: every rank indexes only ITS byte range (round-3 review, item 8a; the default since round 5,
+    // after the ranks fuzz, the damaged-input fuzz and the CLI's multi-rank tests had been through it; FLX_CLI_RANK_RANGES=0 switches it off).  parse_rank_range gives the share; what the loop below checks record by record
     // over the whole file becomes three facts about the shares and two exchanges:
     //   * every share is accepted and made of ordinary records of ONE kind (FASTQ with as many qualities as bases, or FASTA in k-mer
     //     mode), none empty, none longer than an int: a sum of flags.  Anything else — an error to report in file order, records
@@ -799,7 +756,8 @@ int main(int argc, char **argv) {
     //     replays them.
     // 0: not taken (parse the whole file), 1: `mine` holds this rank's records and the totals are set, -1: the exchange failed.
     bool ranged = false;
-    const bool rank_ranges = world > 1 && !streamed && data.map != nullptr && getenv("FLX_CLI_RANK_RANGES") != nullptr;
+    const char *rr_env = getenv("FLX_CLI_RANK_RANGES");  // "0": every rank parses the whole file (round 4's default; tests, A/B)
+    const bool rank_ranges = world > 1 && !streamed && data.map != nullptr && !(rr_env && rr_env[0] == '0');
     auto index_rank_range = [&](Parsed &mine) -> int {
         bool ok = parse_rank_range(data, rank, world, mine);
         bool fa = false, fq = false;
@@ -1215,6 +1173,7 @@ int main(int argc, char **argv) {
             out += '\n';
         }
     };
+    bool pieces_ok = true;
     if (!streamed) {
         // The passed records are cut out of the mapped input by several threads, ~16 MiB of output per piece.  Every piece's
         // place in the output is known beforehand, so when the sink is a regular file each thread writes its pieces itself
@@ -1361,7 +1320,10 @@ int main(int argc, char **argv) {
             buf.clear();
             return at == g_direct_base + (off_t)piece_at[j + 1];
         }, sink, &piece_at, shared_file ? shared_base : (off_t)-1);
-        if (!ok) { std::cerr << "Error: could not write the output\n"; return 1; }
+        // (several ranks: a rank that could not write — a full disk under its pwrite — still goes to the exchange below, where
+        // every rank learns of it and rank 0 says why; leaving here would strand the others in that exchange)
+        if (!ok && world == 1) { std::cerr << "Error: could not write the output\n"; return 1; }
+        pieces_ok = ok;
     } else {
         // Second pass over the compressed input (src/main.cpp:263-313 re-reads the file too), but not front to back on one
         // thread: pass 1 left access points in the deflate stream, the pieces between them (whole records, ~32 MiB of text)
@@ -1399,7 +1361,7 @@ int main(int argc, char **argv) {
         if (!ok) { std::cerr << "Error: " << args.input_reads << " could not be read a second time (did it change?)\n"; return 1; }
     }
     // a sink that did not take everything (disk full, the reader of a pipe gone while SIGPIPE is ignored) ends the job with status 1
-    const bool sink_ok = fflush(sink) == 0 && !ferror(sink);
+    const bool sink_ok = pieces_ok && fflush(sink) == 0 && !ferror(sink);
     if (world == 1 && !sink_ok) { std::cerr << "Error: could not write the output\n"; return 1; }
     if (world > 1) {
         fclose(sink);

@@ -76,6 +76,12 @@ def test_help_and_version():
     assert rc == 0 and "usage:" in err and "Filtlong:" in err
     rc, out, err = run("--help")
     assert rc == 0 and "usage:" in err
+    # the menu of the reference, byte for byte, as recorded from its binary with stdout not a terminal (tests/golden/ref_suite.json)
+    import json
+    gold = json.load(open(os.path.join(_cases.GOLDEN, "ref_suite.json")))
+    menus = [inv["stderr"] for inv in gold["invocations"] if "usage:" in inv["stderr"]]
+    assert menus and err.replace(BIN, "PROG", 1) == menus[0].replace("/root/repo/oracle/_ref/filtlong", "PROG", 1)
+    assert out == b""
     rc, out, err = run("--version")
     assert rc == 0 and out == b"Filtlong v0.3.1\n"
 
@@ -135,3 +141,36 @@ def test_random_rejected_command_lines_match_the_reference_binary():
         assert run_bin(BIN, argv) == r, argv
         compared += 1
     assert compared >= 500
+
+
+def _menu_on_a_terminal(binary, width, args):
+    """stderr of `binary args` with a pseudo-terminal of `width` columns as stdout (the reference's formatter asks STDOUT for its
+    width, src/arguments.cpp:131-133); run under the same argv[0] so that the usage line is the same"""
+    import fcntl
+    import pty
+    import struct
+    import termios
+    m, s = pty.openpty()
+    try:
+        fcntl.ioctl(s, termios.TIOCSWINSZ, struct.pack("HHHH", 40, width, 0, 0))
+        p = subprocess.run(["./filtlong"] + list(args), stdout=s, stderr=subprocess.PIPE, cwd=os.path.dirname(binary),
+                           env=dict(os.environ, LANG="C", LC_ALL="C", LD_LIBRARY_PATH=os.path.join(ROOT, "filtlong_amd", "lib")))
+    finally:
+        os.close(m)
+        os.close(s)
+    return p.returncode, p.stderr
+
+
+def test_help_menu_is_the_references_at_every_terminal_width():
+    """src/arguments.cpp:126-221 + the formatter of src/args.h: the layout depends on the terminal's width (indents 1-4, wrapped
+    descriptions, flags whose help moves to the next line).  Against the reference binary, widths 1..250 and beyond, --help and no
+    argument at all."""
+    import _oracle
+    if not _oracle.have_ref():
+        pytest.skip("reference binary not built")
+    widths = list(range(1, 251)) + [400, 1000, 65535]
+    for w in widths:
+        for args in ((), ("--help",), ("-h",)):
+            if args != ("--help",) and w % 10:
+                continue
+            assert _menu_on_a_terminal(_oracle.REF_FILTLONG, w, args) == _menu_on_a_terminal(BIN, w, args), (w, args)

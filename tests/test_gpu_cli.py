@@ -305,3 +305,132 @@ def test_cli_sink_that_cannot_be_written(tmp_path, gpus):
     assert res.returncode == 1, res.stderr[-300:]
     assert res.stderr.count(b"Error: could not write the output") == 1, res.stderr[-300:]
     assert list(tmp.iterdir()) == []
+
+
+# ---- raw stderr: every progress update of the hashing and the scoring loop ----------------------------------------------------
+_RAW = {}
+
+
+def _raw_inputs(td):
+    """A reference of 1.7 Mbp in three contigs (wrapped lines), 24 000 error-free short-read pairs of 100 bp and 260 long reads
+    of ~9 kbp: every loop that prints "\\r  ... (N bp)" (src/kmers.cpp:123-126, src/main.cpp:119-123) crosses its 483 611-base step
+    several times.  Written once per session."""
+    import gzip
+    import numpy as np
+    from filtlong_amd import synth
+    if _RAW:
+        return _RAW
+    import atexit
+    import shutil
+    d = tempfile.mkdtemp(prefix="flx_raw_")
+    atexit.register(shutil.rmtree, d, True)
+    ref = synth.bases_read(synth.STREAM_REF, 0, 0, 1_700_000)
+    cuts = [0, 600_011, 1_250_007, 1_700_000]
+    with open(os.path.join(d, "ref.fasta"), "wb") as f:
+        for k in range(3):
+            f.write(b">contig_%d some words\n" % (k + 1))
+            s = ref[cuts[k]:cuts[k + 1]].tobytes()
+            f.write(b"\n".join(s[i:i + 70] for i in range(0, len(s), 70)) + b"\n")
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    n_pairs = 12_000
+    starts = (synth.mix(synth.SEED, synth.STREAM_START, np.arange(n_pairs, dtype=np.uint64) + np.uint64(1 << 41), 0)
+              % np.uint64(len(ref) - 500)).astype(np.int64)
+    # ~3.4x of the first 350 kbp only (every 16-mer there is seen often enough for the multi-copy rule), the rest of the pairs anywhere
+    starts[: n_pairs // 2] %= 350_000
+    idx = starts[:, None] + np.arange(100)[None, :]
+    for name, rows in (("sr_1.fastq", ref[idx]), ("sr_2.fastq", comp[ref[idx + 350]][:, ::-1])):
+        with open(os.path.join(d, name), "wb") as f:
+            for k, r in enumerate(rows):
+                f.write(b"@p%d/%s\n%s\n+\n%s\n" % (k, name[3:4].encode(), r.tobytes(), b"I" * 100))
+    with open(os.path.join(d, "sr_1.fastq"), "rb") as f, gzip.open(os.path.join(d, "sr_1.fastq.gz"), "wb", compresslevel=3) as g:
+        g.write(f.read())
+    with open(os.path.join(d, "ref.fasta"), "rb") as f, gzip.open(os.path.join(d, "ref.fasta.gz"), "wb", compresslevel=6) as g:
+        g.write(f.read())
+    lens = np.maximum(synth.lengths(260, first=900) * 9 // 10, 300)
+    with open(os.path.join(d, "reads.fastq"), "wb") as f:
+        for i, L in enumerate(lens):
+            f.write(b"@read_%d\n%s\n+\n%s\n" % (i, synth.seq_read(900 + i, int(L), ref).tobytes(), synth.qual_read(900 + i, int(L)).tobytes()))
+    _RAW.update(dir=d, n_bases=int(lens.sum()))
+    return _RAW
+
+
+_RAW_FLAGS = {
+    "phred": ["--target_bases", "1500000"],
+    "assembly": ["-a", "ref.fasta", "--keep_percent", "70"],
+    "assembly_gz": ["-a", "ref.fasta.gz", "--min_mean_q", "60", "--target_bases", "1400000"],
+    "short_reads": ["-1", "sr_1.fastq", "-2", "sr_2.fastq", "--keep_percent", "80"],
+    "short_reads_gz": ["-1", "sr_1.fastq.gz", "-2", "sr_2.fastq", "--trim", "--split", "300", "--target_bases", "1000000"],
+    "assembly_and_short_reads": ["-a", "ref.fasta", "-1", "sr_1.fastq", "-2", "sr_2.fastq", "--trim", "--split", "500", "--keep_percent", "90"],
+}
+_RAW_ENVS = {
+    "default": {},
+    "many_batches": {"FLX_CLI_REF_BATCH_BYTES": "150000", "FLX_CLI_CHUNK_BYTES": "300000"},
+    "in_memory": {"FLX_CLI_NO_STREAM": "1"},
+    "small_blocks": {"FLX_CLI_FORCE_STREAM": "1", "FLX_CLI_BLOCK_BYTES": "70000", "FLX_CLI_PINFLATE_MIN": "1", "FLX_CLI_PINFLATE_CHUNK": "30000"},
+    "gpus2": None,
+    "gpus3": None,
+}
+
+
+@pytest.mark.parametrize("flags", sorted(_RAW_FLAGS))
+def test_cli_stderr_is_the_references_byte_for_byte(tmp_path, flags):
+    """Round-4 review: stderr was compared as a terminal shows it (the last "\\r" segment of a line).  Here RAW, against the
+    reference binary, on inputs whose hashing and scoring loops print several progress updates — every scoring mode, the streamed
+    reference reader with whole and with tiny batches / blocks, the in-memory reader, gzip references, and two and three forked ranks
+    (which index only their byte range of the reads: the progress lines are replayed by rank 0 from the gathered lengths)."""
+    import _oracle
+    if not os.path.exists(_oracle.REF_FILTLONG):
+        pytest.skip("reference binary not built")
+    raw = _raw_inputs(str(tmp_path))
+    argv = _RAW_FLAGS[flags] + ["reads.fastq"]
+    env0 = dict(os.environ, LANG="C", LC_ALL="C")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env0.pop(k, None)
+    ref = subprocess.run([_oracle.REF_FILTLONG] + argv, cwd=raw["dir"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env0)
+    assert ref.returncode == 0 and ref.stderr.count(b"\r") >= (4 if flags == "phred" else 8), ref.stderr[-300:]
+    shim_dir = os.path.join(ROOT, "tests", "shim")
+    for name, extra in sorted(_RAW_ENVS.items()):
+        prefix = []
+        if extra is None:
+            subprocess.check_call(["make", "-s", "-C", shim_dir])
+            extra = {"FLX_RCCL_LIB": os.path.join(shim_dir, "libloopback_rccl.so"), "FLX_DEVICE": "0"}
+            prefix = ["--gpus", name[4:]]
+        new = subprocess.run([BIN] + prefix + argv, cwd=raw["dir"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(env0, **extra))
+        assert new.returncode == 0, (name, new.stderr[-500:])
+        assert new.stderr == ref.stderr, (name, new.stderr[-600:], ref.stderr[-600:])
+        assert hashlib.sha256(new.stdout).hexdigest() == hashlib.sha256(ref.stdout).hexdigest(), name
+
+
+def test_cli_rank_that_cannot_write_its_share(tmp_path):
+    """Advisor, round 4: a rank > 0 whose pwrite into the job's common output file fails (a full disk; here: RLIMIT_FSIZE, which
+    rank 0's share stays under and rank 1's crosses) used to leave before the exchange in which every rank learns of it — the others
+    then waited in that exchange for ever.  Now every rank reaches it, the job ends with status 1 and rank 0's one message."""
+    import resource
+    import signal
+    shim_dir = os.path.join(ROOT, "tests", "shim")
+    subprocess.check_call(["make", "-s", "-C", shim_dir])
+    tmp = tmp_path / "tmp"
+    tmp.mkdir()
+    env = dict(os.environ, LANG="C", LC_ALL="C", FLX_RCCL_LIB=os.path.join(shim_dir, "libloopback_rccl.so"), FLX_DEVICE="0", TMPDIR=str(tmp))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    fq = tmp_path / "c1.fastq"
+    fq.write_bytes(_cases.c1_fastq_bytes())
+    cmd = [BIN, "--gpus", "2", "--target_bases", "20000000", str(fq)]
+    with open(tmp_path / "whole.fastq", "wb") as fh:
+        assert subprocess.run(cmd, stdout=fh, stderr=subprocess.PIPE, env=env, timeout=300).returncode == 0
+    size = os.path.getsize(tmp_path / "whole.fastq")
+    assert size > 30 << 20
+    limit = size * 3 // 4  # behind rank 0's share (about half of the output), inside rank 1's
+
+    def limited():
+        signal.signal(signal.SIGXFSZ, signal.SIG_IGN)  # (inherited by the forked ranks: write then fails with EFBIG)
+        resource.setrlimit(resource.RLIMIT_FSIZE, (limit, limit))
+
+    with open(tmp_path / "cut.fastq", "wb") as fh:
+        res = subprocess.run(cmd, stdout=fh, stderr=subprocess.PIPE, env=env, timeout=300, preexec_fn=limited)
+    assert res.returncode == 1, res.stderr[-300:]
+    assert res.stderr.count(b"Error: could not write the output") == 1, res.stderr[-300:]
+    assert b"ended early" not in res.stderr
+    assert list(tmp.iterdir()) == []

@@ -217,8 +217,9 @@ def _oracle_revcomp(s):
 
 
 def shown(err):
-    """stderr as a terminal shows it: the last carriage-return segment of every line"""
-    return [l.split("\r")[-1] for l in err.split("\n")]
+    """stderr RAW, line by line (round 5: every "\\r  N reads (M bp)" / "\\r  file (M bp)" progress update is part of the comparison —
+    up to round 4 only the last carriage-return segment of a line was looked at, i.e. what a terminal ends up showing)"""
+    return err.split("\n")
 
 
 def run_both(case, td, extra_env=None, new_argv_prefix=()):
@@ -377,7 +378,7 @@ def test_damaged_gzip_inputs_match_the_reference_binary(tmp_path, part):
             assert new.returncode == ref.returncode, (what, new.stderr.decode(errors="replace")[-600:], ref.stderr.decode(errors="replace")[-600:])
             assert new.stdout == ref.stdout, (what, len(new.stdout), len(ref.stdout))
             assert shown(new.stderr.decode(errors="replace")) == shown(ref.stderr.decode(errors="replace")), what
-        last = [l for l in shown(ref.stderr.decode(errors="replace")) if l.startswith("Error") or l.startswith("  problem")]
+        last = [l for l in (x.split("\r")[-1] for x in shown(ref.stderr.decode(errors="replace"))) if l.startswith("Error") or l.startswith("  problem")]
         key = (case["style"], ref.returncode, last[0].split(" for read")[0].split(" reads.")[0] if last else "")
         seen[key] = seen.get(key, 0) + 1
     assert len(seen) >= 4, seen  # clean ends, cut-off records (-2), the stream's error state (-3), ...
