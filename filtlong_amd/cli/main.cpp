@@ -349,12 +349,36 @@ struct JobGuard {
     }
 };
 
+// The FLX_CLI_* environment variables this binary reads (test hooks and tuning knobs, README.md); any other FLX_CLI_* name is an
+// error — a mistyped switch must not be ignored silently.  (The library checks the rest of the FLX_* names: flx_ctx_create.)
+static int check_cli_environment() {
+    static const char *const known[] = {
+        "FLX_CLI_BLOCK_BYTES", "FLX_CLI_BLOCK_MB", "FLX_CLI_CHUNK_BYTES", "FLX_CLI_CHUNK_MB", "FLX_CLI_CLEAN_EXIT", "FLX_CLI_FORCE_STREAM",
+        "FLX_CLI_INFLATE_THREADS", "FLX_CLI_NO_STREAM", "FLX_CLI_ORDERED_OUTPUT", "FLX_CLI_PARALLEL_PARSE_MIN", "FLX_CLI_PARSE_ONLY",
+        "FLX_CLI_PINFLATE", "FLX_CLI_PINFLATE_AHEAD_MB", "FLX_CLI_PINFLATE_CHUNK", "FLX_CLI_PINFLATE_MIN", "FLX_CLI_PINFLATE_TIMING",
+        "FLX_CLI_RANK_RANGES", "FLX_CLI_REF_BATCH_BYTES", "FLX_CLI_SPAN_BYTES", "FLX_CLI_THREADS", "FLX_CLI_TIMING",
+    };
+    for (char **e = environ; e && *e; ++e) {
+        if (strncmp(*e, "FLX_CLI_", 8) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
+        bool ok = false;
+        for (const char *k : known) ok = ok || name == k;
+        if (!ok) {
+            std::cerr << "Error: unknown environment variable " << name << " (the FLX_CLI_* switches are listed in README.md)\n";
+            return 1;
+        }
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     Args args;
     const ParsingResult pr = parse_args(argc, argv, args);
     if (pr == BAD) return 1;
     if (pr == HELP) return 0;
     if (pr == VERSION) { std::cout << "Filtlong v" << PROGRAM_VERSION << "\n"; return 0; }
+    if (const int bad_env = check_cli_environment()) return bad_env;
     if (const char *po = getenv("FLX_CLI_PARSE_ONLY")) return parse_only(args.input_reads, po);
 
     // ---- ranks: one process per GPU (north_star / SURVEY §8e) ---------------------------------------------------

@@ -303,7 +303,11 @@ extern "C" int flx_rank_and_cut_comm_dev(flx_ctx *ctx, uint64_t n_local, const v
     // replicated fallback is needed) + the padded slots of an all-gather with unequal counts + one send slot
     const size_t rec_bytes = (n_total * 21 + 255) & ~(size_t)255;
     const size_t pad_bytes = ((size_t)c->world * slot * 8 + 255) & ~(size_t)255;
-    const size_t need = rec_bytes + pad_bytes + slot * 8 + 64;
+    // (+ the final scores and the report of the replicated fallback below: nothing is allocated once the collectives of that path
+    // have begun — a rank that returned on a failed allocation there would leave its peers inside a broadcast)
+    const size_t fs_bytes = d_final_score ? ((n_total * 8 + 255) & ~(size_t)255) : 0;
+    const size_t rep_bytes = (sizeof(flx_cut_report) + 8 + 255) & ~(size_t)255;
+    const size_t need = rec_bytes + pad_bytes + ((slot * 8 + 64 + 255) & ~(size_t)255) + fs_bytes + rep_bytes;
     if (need > c->gather_bytes) {
         FLX_HIP(ctx, hipStreamSynchronize(st));
         if (c->gather) (void)hipFree(c->gather);
@@ -318,6 +322,8 @@ extern "C" int flx_rank_and_cut_comm_dev(flx_ctx *ctx, uint64_t n_local, const v
     uint8_t *g_pass = (uint8_t *)(g_len + n_total);
     void *g_padded = (char *)c->gather + rec_bytes;
     void *g_sendpad = (char *)g_padded + pad_bytes;
+    void *g_fs = (char *)g_sendpad + ((slot * 8 + 64 + 255) & ~(size_t)255);
+    void *g_rep = (char *)g_fs + fs_bytes;
 
     flx_time_begin(ctx, "flx_comm_allgather_means");
     int rc = allgather_v(ctx, d_mean_q, g_mean, g_padded, g_sendpad, counts, 8);
@@ -339,26 +345,25 @@ extern "C" int flx_rank_and_cut_comm_dev(flx_ctx *ctx, uint64_t n_local, const v
     if (rc == FLX_OK) rc = allgather_v(ctx, d_passed, g_pass, g_padded, g_sendpad, counts, 1);
     flx_time_end(ctx);
     FLX_CHECK(rc);
-    flx_dbuf d_fs, d_rep;
-    if (d_final_score) FLX_CHECK(flx_dalloc(ctx, d_fs, n_total * 8));
-    FLX_CHECK(flx_dalloc(ctx, d_rep, sizeof(flx_cut_report) + 8));
     int stage_rc = FLX_OK;
-    if (c->rank == 0) {
+    if (c->rank == 0) {  // (errors are recorded, not returned: the head word must reach the peers, who are on their way into the broadcast)
         stage_rc = flx_rank_and_cut_dev(ctx, n_total, g_mean, g_win, g_len, g_pass, lw, mw, ww, target_bases_set, target_bases,
-                                        keep_percent_set, keep_percent, total_bases, d_final_score ? d_fs.p : nullptr, rep);
+                                        keep_percent_set, keep_percent, total_bases, d_final_score ? g_fs : nullptr, rep);
         int64_t head[1] = {stage_rc};
-        FLX_HIP(ctx, hipMemcpyAsync(d_rep.p, head, 8, hipMemcpyHostToDevice, st));
-        FLX_HIP(ctx, hipMemcpyAsync((char *)d_rep.p + 8, rep, sizeof(flx_cut_report), hipMemcpyHostToDevice, st));
+        if (hipMemcpyAsync(g_rep, head, 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync((char *)g_rep + 8, rep, sizeof(flx_cut_report), hipMemcpyHostToDevice, st) != hipSuccess) {
+            if (stage_rc == FLX_OK) stage_rc = flx_fail(ctx, FLX_ERR_HIP, "the outcome of the global stage could not be staged for the broadcast");
+        }
     }
     flx_time_begin(ctx, "flx_comm_broadcast_outcome");
-    FLX_NCCL(ctx, g_rccl.Broadcast(d_rep.p, d_rep.p, sizeof(flx_cut_report) + 8, ncclUint8, 0, c->comm, st));
+    FLX_NCCL(ctx, g_rccl.Broadcast(g_rep, g_rep, sizeof(flx_cut_report) + 8, ncclUint8, 0, c->comm, st));
     if (n_total) FLX_NCCL(ctx, g_rccl.Broadcast(g_pass, g_pass, n_total, ncclUint8, 0, c->comm, st));
-    if (d_final_score && n_total) FLX_NCCL(ctx, g_rccl.Broadcast(d_fs.p, d_fs.p, n_total * 8, ncclUint8, 0, c->comm, st));
+    if (d_final_score && n_total) FLX_NCCL(ctx, g_rccl.Broadcast(g_fs, g_fs, n_total * 8, ncclUint8, 0, c->comm, st));
     flx_time_end(ctx);
     {
         int64_t head[1] = {0};
-        FLX_HIP(ctx, hipMemcpyAsync(head, d_rep.p, 8, hipMemcpyDeviceToHost, st));
-        FLX_HIP(ctx, hipMemcpyAsync(rep, (char *)d_rep.p + 8, sizeof(flx_cut_report), hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipMemcpyAsync(head, g_rep, 8, hipMemcpyDeviceToHost, st));
+        FLX_HIP(ctx, hipMemcpyAsync(rep, (char *)g_rep + 8, sizeof(flx_cut_report), hipMemcpyDeviceToHost, st));
         FLX_HIP(ctx, hipStreamSynchronize(st));
         if (c->rank == 0 && stage_rc != FLX_OK) return stage_rc;
         if (head[0] != FLX_OK) return flx_fail(ctx, (int)head[0], "the global stage failed on rank 0");
@@ -366,7 +371,7 @@ extern "C" int flx_rank_and_cut_comm_dev(flx_ctx *ctx, uint64_t n_local, const v
     if (n_local) {
         FLX_HIP(ctx, hipMemcpyAsync(d_passed, g_pass + first, n_local, hipMemcpyDeviceToDevice, st));
         if (d_final_score)
-            FLX_HIP(ctx, hipMemcpyAsync(d_final_score, (const double *)d_fs.p + first, n_local * 8, hipMemcpyDeviceToDevice, st));
+            FLX_HIP(ctx, hipMemcpyAsync(d_final_score, (const double *)g_fs + first, n_local * 8, hipMemcpyDeviceToDevice, st));
     }
     FLX_HIP(ctx, hipStreamSynchronize(st));
     return FLX_OK;

@@ -45,9 +45,40 @@ static void build_phred_lut(double *lut257) {
     lut257[256] = 0.0;
 }
 
+// Every FLX_* environment variable the library reads (README.md lists what each one does) — most of them select a second
+// implementation for the tests.  A name that is none of these is refused once, here: a mistyped switch in a user's shell would
+// otherwise be ignored silently, i.e. run another kernel than the one asked for.  (FLX_CLI_* belong to the command line, which
+// checks its own; FLX_FUZZ_* / FLX_BENCH_* / FLX_TEST_* to the test and bench drivers.  tests/test_abi.py holds this list against
+// the getenv calls in the sources.)
+static const char *const kKnownEnv[] = {
+    "FLX_API_TIMING", "FLX_KMER_COVER", "FLX_KMER_FOLD", "FLX_KMER_FOLD_EVENTS", "FLX_KMER_FOLD_STREAMS", "FLX_KMER_LOCUS",
+    "FLX_KMER_LOCUS_BUILD", "FLX_KMER_PAIRTABLE", "FLX_KMER_PREFILTER", "FLX_KMER_SAFE1", "FLX_KMER_TEXT_ORDER", "FLX_PHRED_KERNEL",
+    "FLX_PHRED_TABLES", "FLX_RANK_EXACT", "FLX_RANK_SORT", "FLX_RCCL_LIB",
+    // read by the hosts above the C ABI (cli/main.cpp, filtlong_amd/_lib.py, bench.py)
+    "FLX_DEVICE", "FLX_COMM_ID_FILE", "FLX_LIB_PATH", "FLX_NO_TORCH_PRELOAD",
+};
+extern char **environ;
+static int check_environment() {
+    for (char **e = environ; e && *e; ++e) {
+        if (strncmp(*e, "FLX_", 4) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
+        if (name.compare(0, 8, "FLX_CLI_") == 0 || name.compare(0, 9, "FLX_FUZZ_") == 0 || name.compare(0, 10, "FLX_BENCH_") == 0 ||
+            name.compare(0, 9, "FLX_TEST_") == 0)
+            continue;
+        bool known = false;
+        for (const char *k : kKnownEnv) known = known || name == k;
+        if (!known)
+            return flx_fail(nullptr, FLX_ERR_INVALID, "unknown environment variable %s: not one of this library's switches (README.md lists them; "
+                                                      "a mistyped one would silently select another kernel)", name.c_str());
+    }
+    return FLX_OK;
+}
+
 extern "C" int flx_ctx_create(int device_ordinal, flx_ctx **out) {
     if (!out) return flx_fail(nullptr, FLX_ERR_INVALID, "flx_ctx_create: out is NULL");
     *out = nullptr;
+    FLX_CHECK(check_environment());
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)

@@ -746,9 +746,18 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
             std::vector<flx_seq_batch> wb;
             for (auto *list : {&s->asm_batches, &s->short_batches})
                 for (auto &b : *list) wb.push_back({b.bases, b.offsets, b.pos_base, b.n_seqs, b.n_pos});
-            FLX_CHECK(flx_build_path_text(ctx, s->present, (const uint8_t *)s->exact15, sz, wb.data(), wb.size(), &s->locus_text, &s->locus_seed, &s->locus));
+            // (the text is optional — include/filtlong_hip.h: "when that memory cannot be had the set works without" — so a build
+            // that fails on its transient memory, ~12 GB for the C4 set, leaves a set without a text, not a failed finalize)
+            if (flx_build_path_text(ctx, s->present, (const uint8_t *)s->exact15, sz, wb.data(), wb.size(), &s->locus_text, &s->locus_seed, &s->locus) != FLX_OK) {
+                if (s->locus_text) (void)hipFree(s->locus_text);
+                if (s->locus_seed) (void)hipFree(s->locus_seed);
+                s->locus_text = s->locus_seed = nullptr;
+                (void)hipGetLastError();
+            }
             s->has_locus = s->locus_text != nullptr;
-        } else if (n_windows > 0 && n_text <= (1ull << 28) && !(lb && lb[0] == '0')) {
+        } else if (!s->has_short && n_windows > 0 && n_text <= (1ull << 28) && !(lb && lb[0] == '0')) {
+            // (!has_short: with short reads in the set — and no room for the pair table, or the text switched off above — the assembly's
+            // text would NOT hold every member as a window, which is what U13 / S1 rest on: no text then, and no memory spent on one)
             const uint64_t n_words = (n_text + 15) / 16;
             const uint64_t n_alloc = n_words + kLocusPad + 68;
             int bits = 10;
@@ -756,7 +765,12 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
             const uint64_t slots = 1ull << bits;
             hipError_t e1 = hipMalloc((void **)&s->locus_text, n_alloc * 8);
             hipError_t e2 = e1 == hipSuccess ? hipMalloc((void **)&s->locus_seed, slots * 4) : e1;
-            if (e1 == hipSuccess && e2 == hipSuccess) {
+            // the two counting planes of U13 as well, BEFORE anything is built: a failure here is "no text", like the two above
+            uint32_t *u13_planes = nullptr;
+            const size_t plane = (size_t)1 << (26 - 3);
+            hipError_t e3 = e2 == hipSuccess ? hipMalloc((void **)&u13_planes, 2 * plane) : e2;
+            if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) {
+                struct PlaneGuard { uint32_t *p; ~PlaneGuard() { if (p) (void)hipFree(p); } } plane_guard{u13_planes};
                 FLX_HIP(ctx, hipMemsetAsync(s->locus_text, 0, n_alloc * 8, st));
                 // padding: no window may start or end there
                 std::vector<uint32_t> pad_front(2 * kLocusPad), pad_back(2 * 68);
@@ -780,11 +794,8 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
                     hipLaunchKernelGGL(k_set_word_bits, dim3(1), dim3(1), 0, st, s->locus_text + 2 * (kLocusPad + n_words - 1) + 1, tail_bits);
                 }
                 {  // U13: the 13-mers that occur once
-                    flx_dbuf seen;
-                    const size_t plane = (size_t)1 << (26 - 3);
-                    FLX_CHECK(flx_dalloc(ctx, seen, 2 * plane));
-                    FLX_HIP(ctx, hipMemsetAsync(seen.p, 0, 2 * plane, st));
-                    uint32_t *seen1 = seen.as<uint32_t>(), *seen2 = seen1 + plane / 4;
+                    FLX_HIP(ctx, hipMemsetAsync(u13_planes, 0, 2 * plane, st));
+                    uint32_t *seen1 = u13_planes, *seen2 = seen1 + plane / 4;
                     for (int pass = 0; pass < 2; ++pass) {
                         tb = 0;
                         for (auto &b : s->asm_batches) {
@@ -819,7 +830,9 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
                 s->has_locus = true;
             } else {  // not enough memory for it: the scoring path works without
                 if (s->locus_text) (void)hipFree(s->locus_text);
-                s->locus_text = nullptr;
+                if (s->locus_seed) (void)hipFree(s->locus_seed);
+                if (u13_planes) (void)hipFree(u13_planes);
+                s->locus_text = s->locus_seed = nullptr;
                 (void)hipGetLastError();
             }
         }

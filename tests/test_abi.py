@@ -53,3 +53,43 @@ def test_no_gpu_fails_loudly():
     from filtlong_amd import api
     with pytest.raises(api.FlxError):
         api.Context(0)
+
+
+def _getenv_names(paths):
+    names = set()
+    for p in paths:
+        names |= set(re.findall(r'getenv\("(FLX_[A-Z0-9_]+)"\)', open(p).read()))
+    return names
+
+
+def test_environment_switch_lists_match_the_sources(lib):
+    """Round-4 review, item 9: an unknown FLX_* name is refused (flx_ctx_create for the library's switches, the command line for
+    FLX_CLI_*) instead of being ignored.  The two lists must hold exactly the names the sources read, README.md must name every one
+    of them, and the check itself must fire — before any device is asked for, so it runs without a GPU."""
+    import glob
+    import subprocess
+    import sys
+    csrc = glob.glob(os.path.join(ROOT, "filtlong_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "filtlong_amd", "csrc", "*.h"))
+    cli = glob.glob(os.path.join(ROOT, "filtlong_amd", "cli", "*.h")) + glob.glob(os.path.join(ROOT, "filtlong_amd", "cli", "*.cpp"))
+    ctx_src = open(os.path.join(ROOT, "filtlong_amd", "csrc", "flx_ctx.hip")).read()
+    known_lib = set(re.findall(r'"(FLX_[A-Z0-9_]+)"', ctx_src[ctx_src.index("kKnownEnv[] = {"):ctx_src.index("extern char **environ;")]))
+    hosts = {"FLX_DEVICE", "FLX_COMM_ID_FILE", "FLX_LIB_PATH", "FLX_NO_TORCH_PRELOAD"}
+    assert _getenv_names(csrc) == known_lib - hosts
+    main_src = open(os.path.join(ROOT, "filtlong_amd", "cli", "main.cpp")).read()
+    known_cli = set(re.findall(r'"(FLX_CLI_[A-Z0-9_]+)"', main_src[main_src.index("static int check_cli_environment()"):main_src.index("int main(int argc")]))
+    read_cli = _getenv_names(cli)
+    assert {n for n in read_cli if n.startswith("FLX_CLI_")} == known_cli
+    assert {n for n in read_cli if not n.startswith("FLX_CLI_")} <= hosts
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    for name in sorted(known_lib | known_cli):
+        assert name in readme, name + " is not in README.md"
+    # the checks fire
+    code = "from filtlong_amd import api\ntry:\n    api.Context(0)\nexcept api.FlxError as e:\n    print('REFUSED', e)\n"
+    env = dict(os.environ, FLX_KMER_COVR="v2", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+    assert "REFUSED" in out and "FLX_KMER_COVR" in out, out
+    exe = os.path.join(ROOT, "filtlong_amd", "bin", "filtlong")
+    if os.path.exists(exe):
+        fq = os.path.join(ROOT, "tests", "golden", "ref_fixtures", "test_sort.fastq")
+        p = subprocess.run([exe, "--target_bases", "1000", fq], env=dict(os.environ, FLX_CLI_CHUNK_BYTE="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 1 and b"unknown environment variable FLX_CLI_CHUNK_BYTE" in p.stderr
