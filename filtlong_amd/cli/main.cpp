@@ -354,7 +354,7 @@ struct JobGuard {
 static int check_cli_environment() {
     static const char *const known[] = {
         "FLX_CLI_BLOCK_BYTES", "FLX_CLI_BLOCK_MB", "FLX_CLI_CHUNK_BYTES", "FLX_CLI_CHUNK_MB", "FLX_CLI_CLEAN_EXIT", "FLX_CLI_FORCE_STREAM",
-        "FLX_CLI_INFLATE_THREADS", "FLX_CLI_NO_STREAM", "FLX_CLI_ORDERED_OUTPUT", "FLX_CLI_PARALLEL_PARSE_MIN", "FLX_CLI_PARSE_ONLY",
+        "FLX_CLI_FAIL_WRITE_RANK", "FLX_CLI_INFLATE_THREADS", "FLX_CLI_NO_STREAM", "FLX_CLI_ORDERED_OUTPUT", "FLX_CLI_PARALLEL_PARSE_MIN", "FLX_CLI_PARSE_ONLY",
         "FLX_CLI_PINFLATE", "FLX_CLI_PINFLATE_AHEAD_MB", "FLX_CLI_PINFLATE_CHUNK", "FLX_CLI_PINFLATE_MIN", "FLX_CLI_PINFLATE_TIMING",
         "FLX_CLI_RANK_RANGES", "FLX_CLI_REF_BATCH_BYTES", "FLX_CLI_SPAN_BYTES", "FLX_CLI_THREADS", "FLX_CLI_TIMING",
     };
@@ -1293,7 +1293,10 @@ int main(int argc, char **argv) {
             }
         }
         const int out_fd = fileno(sink);
+        const char *fail_env = getenv("FLX_CLI_FAIL_WRITE_RANK");  // tests: this rank's writes fail (a full disk under one rank's share of the file)
+        const bool fail_writes = fail_env && atoi(fail_env) == rank;
         const bool ok = shared_skip || write_pieces(n_pieces, [&](size_t j, std::string &buf) {
+            if (fail_writes) return false;
             if (!g_direct_pieces) {  // a pipe / terminal / append-mode file: the caller writes the formatted piece in order
                 for (uint64_t i = piece_first[j]; i < piece_first[j + 1]; ++i) emit(buf, i, kept.recs[reads2[i].rec]);
                 return true;

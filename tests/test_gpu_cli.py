@@ -403,11 +403,10 @@ def test_cli_stderr_is_the_references_byte_for_byte(tmp_path, flags):
 
 
 def test_cli_rank_that_cannot_write_its_share(tmp_path):
-    """Advisor, round 4: a rank > 0 whose pwrite into the job's common output file fails (a full disk; here: RLIMIT_FSIZE, which
-    rank 0's share stays under and rank 1's crosses) used to leave before the exchange in which every rank learns of it — the others
-    then waited in that exchange for ever.  Now every rank reaches it, the job ends with status 1 and rank 0's one message."""
-    import resource
-    import signal
+    """Advisor, round 4: a rank > 0 whose writes into the job's common output file fail (a full disk under its share; here forced
+    with FLX_CLI_FAIL_WRITE_RANK) used to leave before the exchange in which every rank learns of it — the others then waited in
+    that exchange for ever.  Now every rank reaches it, the job ends with status 1 and rank 0's one message; the same for rank 0
+    itself and for part files (a pipe as the job's stdout)."""
     shim_dir = os.path.join(ROOT, "tests", "shim")
     subprocess.check_call(["make", "-s", "-C", shim_dir])
     tmp = tmp_path / "tmp"
@@ -416,21 +415,17 @@ def test_cli_rank_that_cannot_write_its_share(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     fq = tmp_path / "c1.fastq"
-    fq.write_bytes(_cases.c1_fastq_bytes())
-    cmd = [BIN, "--gpus", "2", "--target_bases", "20000000", str(fq)]
-    with open(tmp_path / "whole.fastq", "wb") as fh:
-        assert subprocess.run(cmd, stdout=fh, stderr=subprocess.PIPE, env=env, timeout=300).returncode == 0
-    size = os.path.getsize(tmp_path / "whole.fastq")
-    assert size > 30 << 20
-    limit = size * 3 // 4  # behind rank 0's share (about half of the output), inside rank 1's
-
-    def limited():
-        signal.signal(signal.SIGXFSZ, signal.SIG_IGN)  # (inherited by the forked ranks: write then fails with EFBIG)
-        resource.setrlimit(resource.RLIMIT_FSIZE, (limit, limit))
-
-    with open(tmp_path / "cut.fastq", "wb") as fh:
-        res = subprocess.run(cmd, stdout=fh, stderr=subprocess.PIPE, env=env, timeout=300, preexec_fn=limited)
-    assert res.returncode == 1, res.stderr[-300:]
-    assert res.stderr.count(b"Error: could not write the output") == 1, res.stderr[-300:]
-    assert b"ended early" not in res.stderr
-    assert list(tmp.iterdir()) == []
+    fq.write_bytes(_cases.c1_fastq_bytes()[:6_000_000].rsplit(b"\n@", 1)[0] + b"\n")
+    cmd = [BIN, "--gpus", "3", "--target_bases", "2000000", str(fq)]
+    for failing in ("0", "1", "2"):
+        for sink in ("file", "pipe"):
+            e = dict(env, FLX_CLI_FAIL_WRITE_RANK=failing)
+            if sink == "file":
+                with open(tmp_path / "cut.fastq", "wb") as fh:
+                    res = subprocess.run(cmd, stdout=fh, stderr=subprocess.PIPE, env=e, timeout=120)
+            else:
+                res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=120)
+            assert res.returncode == 1, (failing, sink, res.stderr[-300:])
+            assert res.stderr.count(b"Error: could not write the output") == 1, (failing, sink, res.stderr[-300:])
+            assert b"ended early" not in res.stderr
+            assert list(tmp.iterdir()) == []
