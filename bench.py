@@ -64,25 +64,36 @@ def _run_ref_bench(argv):
     return json.loads(out.strip().splitlines()[-1])
 
 
+def _with_upper_bound(cb):
+    """beside the honest 1-core number of the single-threaded reference, the optimistic figure "every host core scores
+    its own shard" — NOT a valid Filtlong run (the normalisation and the cut are global, src/main.cpp:170-261), an upper bound only."""
+    if cb and cb.get("host_cores_available"):
+        cb["upper_bound_all_cores"] = {"value": round(cb["value"] * cb["host_cores_available"], 1), "unit": cb["unit"],
+                                       "cores": cb["host_cores_available"],
+                                       "note": "value x host cores, as if independent shards scaled perfectly: not a valid Filtlong run "
+                                               "(global normalisation and cut), an upper bound on what the host could do"}
+    return cb
+
+
 def cpu_baseline_phred(sample_reads):
     """Time the CPU reference on a bounded sample of the same workload (rank 0, N == 1 only)."""
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_bench")):
         # ~half of the sample's bases as target, like --target_bases 50g on 1e11 bases
         r = _run_ref_bench([sample_reads, 0, sample_reads * 5000])
-        return {"value": round(r["mbases_per_s"], 3), "unit": "Mbases/s", "cores": 1, "kind": "reference",
+        return _with_upper_bound({"value": round(r["mbases_per_s"], 3), "unit": "Mbases/s", "cores": 1, "kind": "reference",
                 "sample": "%d reads / %d bases of the same synthetic Phred-only workload, reference objects "
                           "(Read::Read + set_final_score + std::sort) in memory, %.1f s score + %.2f s rank"
                           % (r["reads"], r["bases"], r["score_s"], r["rank_s"]),
-                "host_cores_available": os.cpu_count()}
+                "host_cores_available": os.cpu_count()})
     # fall back to the oracle restatement ("port")
     lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
     lib.flo_bench_phred.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int64, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     ss, rs, tb, kb = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
     lib.flo_bench_phred(sample_reads, 20250919, 0, sample_reads * 5000, ss, rs, tb, kb)
-    return {"value": round(tb.value / (ss.value + rs.value) / 1e6, 3), "unit": "Mbases/s", "cores": 1,
+    return _with_upper_bound({"value": round(tb.value / (ss.value + rs.value) / 1e6, 3), "unit": "Mbases/s", "cores": 1,
             "kind": "port", "sample": "%d reads / %d bases, oracle restatement in memory" % (sample_reads, tb.value),
-            "host_cores_available": os.cpu_count()}
+            "host_cores_available": os.cpu_count()})
 
 
 def cpu_baseline_kmer(cfg, sample_reads, full_set):
@@ -117,11 +128,11 @@ def cpu_baseline_kmer(cfg, sample_reads, full_set):
                 note = "set from the assembly (same 16-mers as the short-read set, which takes the reference ~80 s to hash)"
             opts += ["--trim", "--split", "500"]
         r = _run_ref_bench(["kmer", os.path.join(d, "reads.fastq"), int(lens.astype(np.int64).sum()) // 2] + opts)
-    return {"value": round(r["mbases_per_s"], 3), "unit": "Mbases/s", "cores": 1, "kind": "reference",
+    return _with_upper_bound({"value": round(r["mbases_per_s"], 3), "unit": "Mbases/s", "cores": 1, "kind": "reference",
             "sample": "%d reads / %d bases of the same synthetic k-mer workload, reference objects in memory, %s: "
                       "%.1f s score + %.3f s rank (set build %.1f s, not counted)"
                       % (r["reads"], r["bases"], note, r["score_s"], r["rank_s"], r["set_build_s"]),
-            "host_cores_available": os.cpu_count()}
+            "host_cores_available": os.cpu_count()})
 
 
 def short_read_pairs(ref):
@@ -225,6 +236,55 @@ def end_to_end_cli_kmer(n_reads):
         if os.path.exists(ref_bin):
             t_ref, rc_ref = run(ref_bin, os.path.join(d, "r.out"))
             out.update({"reference_seconds": round(t_ref, 2), "reference_exit_code": rc_ref, "speedup": round(t_ref / t_ours, 1),
+                        "stdout_identical_to_reference": sha(os.path.join(d, "r.out")) == out["stdout_sha256"]})
+        return out
+
+
+def _timed_child(argv, stdout_path, env):
+    """one command: wall clock, exit code and the child's own peak resident set (wait4)"""
+    t = time.perf_counter()
+    with open(stdout_path, "wb") as fo:
+        p = subprocess.Popen(argv, stdout=fo, stderr=subprocess.DEVNULL, env=env)
+        _, status, ru = os.wait4(p.pid, 0)
+        p.returncode = os.waitstatus_to_exitcode(status) if hasattr(os, "waitstatus_to_exitcode") else (status >> 8)
+    return time.perf_counter() - t, p.returncode, ru.ru_maxrss // 1024
+
+
+def end_to_end_cli_kmer_short(n_reads, n_pairs):
+    """C4 through the command line: `-1 sr_1.fastq -2 sr_2.fastq --trim --split 500 --target_bases <half>` — the short-read
+    reference (error-free 100 bp pairs from the 5 Mbp genome, tools/gen_kmer_inputs = the C4 definition of SURVEY §8d) is STREAMED
+    into the device set in batches (cli/reference.h, round 5: host memory O(batch)), the set's text is built from the 24-mers of the
+    pairs, long reads drawn from the genome are scored, trimmed and split.  The drop-in binary and the reference binary on the same
+    files, stdout compared by digest; peak resident memory of both processes.  (The default run bounds the pairs so that the
+    reference's hashing — ~80 s per 10^6 pairs — stays within the bench's minutes; profiles/r05_e2e_kmer.json holds the run with
+    the full 10^6 pairs and one with a 10 GB short-read set.)"""
+    import hashlib
+    gen = os.path.join(ROOT, "tools", "gen_kmer_inputs")
+    ours = os.path.join(ROOT, "filtlong_amd", "bin", "filtlong")
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "filtlong")
+    env = dict(os.environ, LANG="C", LC_ALL="C")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        long_bases, short_bases = (int(x) for x in subprocess.run([gen, d, str(n_reads), str(n_pairs)], check=True, stdout=subprocess.PIPE).stdout.split())
+        argv = ["-1", os.path.join(d, "sr_1.fastq"), "-2", os.path.join(d, "sr_2.fastq"), "--trim", "--split", "500",
+                "--target_bases", str(long_bases // 2), os.path.join(d, "reads.fastq")]
+
+        def sha(path):
+            return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+        _timed_child([ours] + argv, os.path.join(d, "a.out"), env)
+        t_ours, rc_ours, rss_ours = min(_timed_child([ours] + argv, os.path.join(d, "a.out"), env) for _ in range(2))
+        out = {"measured_in_this_run": True, "flags": "-1 sr_1.fastq -2 sr_2.fastq --trim --split 500 --target_bases <half>",
+               "short_read_pairs": n_pairs, "short_read_bases": short_bases, "reads": n_reads, "bases": long_bases,
+               "seconds": round(t_ours, 3), "exit_code": rc_ours, "peak_rss_mib": rss_ours,
+               "stdout_bytes": os.path.getsize(os.path.join(d, "a.out")), "stdout_sha256": sha(os.path.join(d, "a.out")),
+               "note": "the whole command: both short-read files parsed and streamed into the device set, multi-copy rule + Bloom replay, "
+                       "the set's text from the pairs' 24-mers, scoring, trimming / splitting, output"}
+        if os.path.exists(ref_bin):
+            t_ref, rc_ref, rss_ref = _timed_child([ref_bin] + argv, os.path.join(d, "r.out"), env)
+            out.update({"reference_seconds": round(t_ref, 2), "reference_exit_code": rc_ref, "reference_peak_rss_mib": rss_ref,
+                        "speedup": round(t_ref / t_ours, 1),
                         "stdout_identical_to_reference": sha(os.path.join(d, "r.out")) == out["stdout_sha256"]})
         return out
 
@@ -436,6 +496,8 @@ def main():
     ap.add_argument("--cpu-sample-reads-kmer", type=int, default=2000)
     ap.add_argument("--full-cpu-baseline", action="store_true", help="c4: let the CPU reference hash the short reads itself (~80 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e-kmer-pairs", type=int, default=250_000, help="short-read pairs of extras.end_to_end_cli_kmer_short (C4 has "
+                    "10^6; the reference hashes ~12 000 pairs a second, so the default run takes a quarter)")
     ap.add_argument("--no-extras", action="store_true", help="default config only: skip the c2wide / c3 / c4 / cut-path extras")
     ap.add_argument("--window-size", type=int, default=250)
     ap.add_argument("--global-stage", choices=("rccl", "sharded", "replicated"), default="rccl",
@@ -755,6 +817,10 @@ def main():
                 extras["end_to_end_cli"] = end_to_end_cli(100_000)
             except Exception as e:  # an extra must not cost the headline line
                 extras["end_to_end_cli"] = {"measured_in_this_run": False, "error": repr(e)}
+            try:
+                extras["end_to_end_cli_kmer_short"] = end_to_end_cli_kmer_short(3000, args.e2e_kmer_pairs)
+            except Exception as e:
+                extras["end_to_end_cli_kmer_short"] = {"measured_in_this_run": False, "error": repr(e)}
             try:
                 extras["end_to_end_cli_kmer"] = end_to_end_cli_kmer(3000)
             except Exception as e:
