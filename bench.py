@@ -660,6 +660,15 @@ def main():
     rank_ms, _ = ctx.timing_get("flx_rank")
     sort_ms, _ = ctx.timing_get("flx_sort")
     comm_ms, _ = ctx.timing_get("flx_comm")
+    # where a step's exchange time goes, collective by collective (rank 0's stream clocks; DESIGN §5: per step 1 all-gather of the mean
+    # qualities, 8 device-side all-reduces of selection histograms — inside flx_rank_select's own bracket —, 2 host-visible sums, and
+    # the three extra gathers + broadcasts only when the reference's own std::sort has to decide)
+    comm_split = {}
+    for key, prefix in (("counts_sum_host_visible", "flx_comm_counts"), ("allgather_means", "flx_comm_allgather_means"),
+                        ("allreduce_histograms_device", "flx_comm_allreduce_dev"), ("band_sum_host_visible", "flx_comm_sum_host"),
+                        ("allgather_records_fallback", "flx_comm_allgather_records"), ("broadcast_outcome_fallback", "flx_comm_broadcast_outcome")):
+        ms, cnt = ctx.timing_get(prefix)
+        comm_split[key] = {"ms_per_step": round(ms / args.steps, 4), "calls_per_step": round(cnt / args.steps, 2)}
     ctx.timing_enable(False)
     if args.dump_flags:
         torch.cuda.synchronize()
@@ -727,7 +736,8 @@ def main():
             },
             "stage_ms_per_step": {"score_kernel": round(k_ms / args.steps, 3), "sort": round(sort_ms / args.steps, 3),
                                   "rank_other_kernels": round(rank_ms / args.steps, 3),
-                                  "comm": round(comm_ms / args.steps, 3)},
+                                  "comm": round(comm_ms / args.steps, 3),
+                                  "comm_split": comm_split if multi else None},
             "cut": {"target_bases": int(rep.target_bases), "kept_bases": int(rep.kept_bases),
                     "outcome": int(rep.outcome), "audited": int(rep.audited), "exact_fallback": int(rep.exact_fallback)},
             "setup_s": round(setup_s, 1),

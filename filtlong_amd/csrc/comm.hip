@@ -164,7 +164,10 @@ extern "C" int flx_comm_world(const flx_ctx *ctx) { return ctx && ctx->comm ? ct
 int flx_comm_allreduce_u64_dev(flx_ctx *ctx, uint64_t *d_buf, uint64_t count) {
     flx_comm *c = ctx->comm;
     if (!c) return flx_fail(ctx, FLX_ERR_STATE, "no communicator");
-    FLX_NCCL(ctx, g_rccl.AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, c->comm, ctx->stream));
+    flx_time_begin(ctx, "flx_comm_allreduce_dev");  // (inside the selection's own bracket, flx_rank_select: brackets nest)
+    ncclResult_t r = g_rccl.AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, c->comm, ctx->stream);
+    flx_time_end(ctx);
+    if (r != ncclSuccess) return flx_fail(ctx, FLX_ERR_STATE, "ncclAllReduce failed: %s", g_rccl.GetErrorString(r));
     return FLX_OK;
 }
 
@@ -187,9 +190,13 @@ int flx_comm_allreduce_u64_host(flx_ctx *ctx, uint64_t *buf, uint64_t count) {
     if (!c) return flx_fail(ctx, FLX_ERR_STATE, "no communicator");
     const size_t bytes = count * 8;
     FLX_CHECK(comm_stage(ctx, bytes));
-    FLX_HIP(ctx, hipMemcpyAsync(c->stage, buf, bytes, hipMemcpyHostToDevice, ctx->stream));
-    FLX_NCCL(ctx, g_rccl.AllReduce(c->stage, c->stage, count, ncclUint64, ncclSum, c->comm, ctx->stream));
-    FLX_HIP(ctx, hipMemcpyAsync(buf, c->stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    flx_time_begin(ctx, "flx_comm_sum_host");  // a host-visible sum: copy in, all-reduce, copy out, and the host waits for it
+    hipError_t e = hipMemcpyAsync(c->stage, buf, bytes, hipMemcpyHostToDevice, ctx->stream);
+    ncclResult_t r = e == hipSuccess ? g_rccl.AllReduce(c->stage, c->stage, count, ncclUint64, ncclSum, c->comm, ctx->stream) : ncclSuccess;
+    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(buf, c->stage, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    flx_time_end(ctx);
+    if (r != ncclSuccess) return flx_fail(ctx, FLX_ERR_STATE, "ncclAllReduce failed: %s", g_rccl.GetErrorString(r));
+    FLX_HIP(ctx, e);
     FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FLX_OK;
 }

@@ -180,12 +180,14 @@ void flx_time_begin(flx_ctx *ctx, const char *name) {
     t.start = take_event(ctx);
     t.stop = take_event(ctx);
     (void)hipEventRecord(t.start, ctx->stream);
+    ctx->timed_open.push_back(ctx->timed.size());
     ctx->timed.push_back(t);
 }
 
-void flx_time_end(flx_ctx *ctx) {
-    if (!ctx->timing || ctx->timed.empty()) return;
-    (void)hipEventRecord(ctx->timed.back().stop, ctx->stream);
+void flx_time_end(flx_ctx *ctx) {  // closes the innermost open bracket
+    if (!ctx->timing || ctx->timed_open.empty()) return;
+    (void)hipEventRecord(ctx->timed[ctx->timed_open.back()].stop, ctx->stream);
+    ctx->timed_open.pop_back();
 }
 
 extern "C" int flx_timing_enable(flx_ctx *ctx, int on) {
@@ -202,6 +204,7 @@ extern "C" int flx_timing_reset(flx_ctx *ctx) {
         ctx->event_pool.push_back(t.stop);
     }
     ctx->timed.clear();
+    ctx->timed_open.clear();
     return FLX_OK;
 }
 

@@ -42,6 +42,7 @@ struct flx_ctx {
     // timing
     bool timing = false;
     std::vector<flx_timed_launch> timed;
+    std::vector<size_t> timed_open;  // brackets that are open, innermost last (they nest: a collective inside the selection's bracket)
     std::vector<hipEvent_t> event_pool;
 
     // reusable device scratch (grown on demand)
