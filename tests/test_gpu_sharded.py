@@ -274,6 +274,6 @@ def test_bench_eight_ranks_exactly_as_the_driver_types_it(tmp_path):
     split = j["stage_ms_per_step"]["comm_split"]
     assert split["allgather_means"]["calls_per_step"] == 1 and split["allgather_means"]["ms_per_step"] > 0
     assert split["allreduce_histograms_device"]["calls_per_step"] == 8
-    assert split["counts_sum_host_visible"]["calls_per_step"] == 1 and split["band_sum_host_visible"]["calls_per_step"] == 1
+    assert split["counts_sum_host_visible"]["calls_per_step"] == 1 and 1 <= split["band_sum_host_visible"]["calls_per_step"] <= 2
     assert split["allgather_records_fallback"]["calls_per_step"] == 0 and split["broadcast_outcome_fallback"]["calls_per_step"] == 0
     assert j["config"]["allgather_bytes_per_rank"] == {"sent": 800000, "received": 6400000}
