@@ -357,6 +357,9 @@ class Context:
     def last_kmer_locus(self):
         return bool(self.L.flx_last_kmer_locus(self.h))
 
+    def last_kmer_fold_grid(self):
+        return bool(self.L.flx_last_kmer_fold_grid(self.h))
+
     def synth_qual_dev(self, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n, profile=0):
         self._check(self.L.flx_synth_qual_profile_dev(self.h, seed, profile, d_plane, plane_bytes, d_offsets, d_lengths,
                                                       d_read_ids, n))

@@ -29,6 +29,7 @@ extern "C" const char *flx_version(void) { return "filtlong-amd 0.1 (hot path of
 
 extern "C" const char *flx_last_phred_kernel(const flx_ctx *ctx) { return ctx ? ctx->last_phred_kernel : ""; }
 extern "C" int flx_last_kmer_locus(const flx_ctx *ctx) { return ctx && ctx->last_kmer_locus ? 1 : 0; }
+extern "C" int flx_last_kmer_fold_grid(const flx_ctx *ctx) { return ctx && ctx->last_kmer_fold_grid ? 1 : 0; }
 
 extern "C" const char *flx_last_error(const flx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -51,7 +52,7 @@ static void build_phred_lut(double *lut257) {
 // checks its own; FLX_FUZZ_* / FLX_BENCH_* / FLX_TEST_* to the test and bench drivers.  tests/test_abi.py holds this list against
 // the getenv calls in the sources.)
 static const char *const kKnownEnv[] = {
-    "FLX_API_TIMING", "FLX_KMER_COVER", "FLX_KMER_FOLD", "FLX_KMER_FOLD_EVENTS", "FLX_KMER_FOLD_STREAMS", "FLX_KMER_LOCUS",
+    "FLX_API_TIMING", "FLX_KMER_COVER", "FLX_KMER_FOLD", "FLX_KMER_FOLD_EVENTS", "FLX_KMER_FOLD_GRID", "FLX_KMER_FOLD_STREAMS", "FLX_KMER_LOCUS",
     "FLX_KMER_LOCUS_BUILD", "FLX_KMER_PAIRTABLE", "FLX_KMER_PREFILTER", "FLX_KMER_SAFE1", "FLX_KMER_TEXT_ORDER", "FLX_PHRED_KERNEL",
     "FLX_PHRED_TABLES", "FLX_RANK_EXACT", "FLX_RANK_SORT", "FLX_RCCL_LIB",
     // read by the hosts above the C ABI (cli/main.cpp, filtlong_amd/_lib.py, bench.py)

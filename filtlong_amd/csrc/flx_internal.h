@@ -26,6 +26,7 @@ struct flx_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop;
     std::string err;
+    bool last_kmer_fold_grid = false;    // ... and its window folds on the integer grid (score_kmer.hip: GridTab)
     bool last_kmer_locus = false;        // the last k-mer scoring call ran with the assembly text (kmerset.h: flx_locus)
     const char *last_phred_kernel = "";  // which Phred kernel the last scoring call launched (flx_last_phred_kernel)
 

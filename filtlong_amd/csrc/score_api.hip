@@ -126,6 +126,13 @@ extern "C" int flx_score_batch(flx_ctx *ctx, const flx_kmerset *set, const uint8
             dev.child_passed = d_cpass.as<uint8_t>();
         }
     }
+    // The outputs start out as a pattern no result can be (0xA5...: a huge negative quality, pass flag 165): device memory that
+    // comes back from the allocator holds the previous call's results at the same addresses, and a kernel that wrote nothing
+    // would otherwise hand back yesterday's right answers (round 5: that is how the fold kernels with both streams from global
+    // memory were found dead — their launch had failed silently while the tests compared stale buffers).
+    FLX_HIP(ctx, hipMemsetAsync(d_mean.p, 0xA5, n_reads * 8, ctx->stream));
+    FLX_HIP(ctx, hipMemsetAsync(d_win.p, 0xA5, n_reads * 8, ctx->stream));
+    FLX_HIP(ctx, hipMemsetAsync(d_pass.p, 0xA5, n_reads, ctx->stream));
     pt.mark("small uploads + alloc");
     int rc = flx_score_batch_dev(ctx, set, d_plane.p, plane_bytes, d_off.p, d_len.p, order ? d_ord.p : nullptr,
                                  n_reads, params, &dev);

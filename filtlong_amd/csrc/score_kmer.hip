@@ -305,6 +305,27 @@ __device__ __forceinline__ uint4 flx_plane16(const uint8_t *p) {
     return *reinterpret_cast<const uint4 *>(p);
 #endif
 }
+// A lane's left / right neighbour's value, with lane 0's / lane 63's coming from a wave-uniform carry: ONE DPP move (wave_shr:1 /
+// wave_shl:1: a lane without a source keeps the destination's old value, which is set to the carry).  __shfl_up + `if (lane == 0)`
+// compiles to ds_bpermute_b32 + v_cndmask_b32 with the lane mask held in an SGPR pair — twenty of those per span kept four such pairs
+// alive in a kernel that is short of scalar registers (78 at 8 waves per SIMD: they were spilled to vector lanes and read back with
+// two v_readlane each), and sent thirty operations per span through the LDS crossbar.  (FLX_COVER_NO_DPP: the old form, A/B.)
+__device__ __forceinline__ uint32_t flx_from_left(uint32_t x, uint32_t lane0) {
+#ifndef FLX_COVER_NO_DPP
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+#else
+    const uint32_t v = __shfl_up(x, 1, 64);
+    return (threadIdx.x & 63) == 0 ? lane0 : v;
+#endif
+}
+__device__ __forceinline__ uint32_t flx_from_right(uint32_t x, uint32_t lane63) {
+#ifndef FLX_COVER_NO_DPP
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane63, (int)x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+#else
+    const uint32_t v = __shfl_down(x, 1, 64);
+    return (threadIdx.x & 63) == 63 ? lane63 : v;
+#endif
+}
 #ifndef FLX_COVER_WAVES_PER_EU
 #define FLX_COVER_WAVES_PER_EU 8
 #endif
@@ -332,9 +353,9 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
         // LOCUS: the diagonal (wave-uniform), whether a seed is due, the text of this span / the next one, lane 63's carry
         long long diag = 0;
         bool have_diag = false, carry_ok = false;
-        uint32_t c_mml = 0xffffu, c_bnd = 0xffffu, c_u13 = 0, c_known15 = 0, c_twx = 0, c_twy = 0xffffu;
+        uint32_t c_mb = 0xffffffffu /* mismatches | piece starts << 16 of lane 63 */, c_us = 0 /* its U13 | S1 << 16 */, c_known15 = 0, c_twx = 0, c_twy = 0xffffu;
         uint2 tw = make_uint2(0, 0xffffu), tw_next = make_uint2(0, 0xffffu);
-        uint32_t ts = 0, ts_next = 0, c_ts = 0, c_s1 = 0;  // S1 bits of those text words (kmerset.h: safe1); lane 63's for the next span
+        uint32_t ts = 0, ts_next = 0, c_ts = 0;  // S1 bits of those text words (kmerset.h: safe1); lane 63's for the next span
         const bool has_s1 = loc.safe1 != nullptr;
         // the text word that holds the LAST base of the lane's 16 at this diagonal, for the lane whose 16 bases start at `base` +
         // 16 * lane (index clamped into the padded array).  The diagonal and `base` are wave-uniform: the 64-bit part of the index
@@ -354,8 +375,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
 
         auto finalize = [&](int sp, uint32_t h, uint32_t right_of_63) {  // hits of span sp -> coverage bits, counts, row words
             const int p0 = (sp << 10) + lane * 16;
-            uint32_t next = __shfl_down(h, 1, 64);
-            if (lane == 63) next = right_of_63;
+            const uint32_t next = flx_from_right(h, right_of_63);
             uint32_t x = h | (next << 16);
             x |= x >> 1;
             x |= x >> 2;
@@ -374,7 +394,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 fst = min(fst, p0 + (__ffs(c16) - 1));
                 lst = max(lst, p0 + (32 - __clz(c16)));
             }
-            const uint32_t up = __shfl_down(c16, 1, 64);
+            const uint32_t up = flx_from_right(c16, 0u);  // (only the even lanes write: lane 63's is never used)
             const int word = p0 >> 5;
 #ifndef FLX_COVER_TEMPORAL
             if ((lane & 1) == 0 && word < row_words) __builtin_nontemporal_store(c16 | (up << 16), &row[(uint32_t)word]);
@@ -396,8 +416,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             }
             // 2 bits per base, earliest base on top: lo = my 16 bases, hi = the 16 before them
             const uint32_t lo = (codes4(raw.x) << 24) | (codes4(raw.y) << 16) | (codes4(raw.z) << 8) | codes4(raw.w);
-            uint32_t hi = __shfl_up(lo, 1, 64);
-            if (lane == 0) hi = c_lo;
+            const uint32_t hi = flx_from_left(lo, c_lo);
             // positions p0 + j that end a 12-mer / a 16-mer inside the read
             uint32_t valid12 = 0, valid16 = 0;
 #ifndef FLX_NO_VALID_FAST
@@ -421,12 +440,12 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 // my 16 bases against the text along `diag` (tw = the word that holds the last of them): adds to known / refuted
                 auto compare = [&]() {
                     const int e = (int)((diag + 15) & 15);  // index of my last base in my word (p0 is a multiple of 16: the same for every lane)
+                    // lane 0's left word: the carry, or behind a new seed a load (wave-uniform choice; only lane 0's copy is used)
+                    const uint2 tw0 = carry_ok ? make_uint2(c_twx, c_twy) : text_word(diag, (sp << 10) - 16);
                     uint2 twl;
-                    twl.x = __shfl_up(tw.x, 1, 64);
-                    twl.y = __shfl_up(tw.y, 1, 64);
-                    uint32_t tsl = __shfl_up(ts, 1, 64);
-                    if (lane == 0) twl = carry_ok ? make_uint2(c_twx, c_twy) : text_word(diag, (sp << 10) - 16);  // (a load only behind a new seed; only lane 0 uses it)
-                    if (lane == 0) tsl = carry_ok ? c_ts : 0u;  // (not worth a load: lane 0 behind a new seed refutes its own window only, below)
+                    twl.x = flx_from_left(tw.x, tw0.x);
+                    twl.y = flx_from_left(tw.y, tw0.y);
+                    const uint32_t tsl = flx_from_left(ts, carry_ok ? c_ts : 0u);  // (not worth a load: lane 0 behind a new seed refutes its own window only, below)
                     const uint32_t t_own = __builtin_amdgcn_alignbit(twl.x, tw.x, 2 * (15 - e));
                     const uint32_t b_own = (((twl.y & 0xffffu) >> (e + 1)) | (tw.y << (15 - e))) & 0xffffu;  // bit j: my base j is the first of a piece
                     const uint32_t u_own = (((twl.y >> 16) >> (e + 1)) | ((tw.y >> 16) << (15 - e))) & 0xffffu;  // bit j: a unique 13-mer starts at my base j
@@ -438,8 +457,9 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     m = (m | (m >> 4)) & 0x00ff00ffu;
                     m = (m | (m >> 8)) & 0xffffu;
                     const uint32_t mml = __brev(m) >> 16;  // bit j: my base j differs from the text
-                    uint32_t mmh = __shfl_up(mml, 1, 64), bh = __shfl_up(b_own, 1, 64), uh = __shfl_up(u_own, 1, 64), sh = __shfl_up(s_own, 1, 64);
-                    if (lane == 0) { mmh = carry_ok ? c_mml : 0xffffu; bh = carry_ok ? c_bnd : 0xffffu; uh = carry_ok ? c_u13 : 0u; sh = carry_ok ? c_s1 : 0u; }
+                    const uint32_t mb0 = carry_ok ? c_mb : 0xffffffffu, us0 = carry_ok ? c_us : 0u;
+                    const uint32_t mmh = flx_from_left(mml, mb0 & 0xffffu), bh = flx_from_left(b_own, mb0 >> 16);
+                    const uint32_t uh = flx_from_left(u_own, us0 & 0xffffu), sh = flx_from_left(s_own, us0 >> 16);
                     const uint32_t z = ~(mmh | (mml << 16));  // bit i: base i of the window [p0 - 16, p0 + 16) matches
                     uint32_t r = z & (z >> 1);
                     r &= r >> 2;
@@ -496,11 +516,9 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     // safe for `known` and would be wrong here: only the window made of its own 16 bases can be refuted)
                     if (lane == 0 && !carry_ok) rf &= 0x8000u;
                     refuted |= rf;
-                    c_u13 = __builtin_amdgcn_readlane(u_own, 63);
-                    c_s1 = __builtin_amdgcn_readlane(s_own, 63);
+                    c_us = __builtin_amdgcn_readlane(u_own | (s_own << 16), 63);
                     c_ts = __builtin_amdgcn_readlane(ts, 63);
-                    c_mml = __builtin_amdgcn_readlane(mml, 63);
-                    c_bnd = __builtin_amdgcn_readlane(b_own, 63);
+                    c_mb = __builtin_amdgcn_readlane(mml | (b_own << 16), 63);
                     c_twx = __builtin_amdgcn_readlane(tw.x, 63);
                     c_twy = __builtin_amdgcn_readlane(tw.y, 63);
                     carry_ok = true;
@@ -591,12 +609,10 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             if (far_first) {
                 const bool ask15 = (valid16 >> 15) != 0 && ((known | refuted) >> 15) == 0;
                 if (__any(ask15)) probe(ask15 ? 15 : -1, -1, valid16);
-                ltop = __shfl_up(hits >> 15, 1, 64);
-                if (lane == 0) ltop = c_hit15;
+                ltop = flx_from_left(hits >> 15, c_hit15);
                 settled = (hits >> 15) && ltop;
             } else if (LOCUS) {
-                ltop = __shfl_up(known >> 15, 1, 64);
-                if (lane == 0) ltop = c_hit15;
+                ltop = flx_from_left(known >> 15, c_hit15);
                 settled = (known >> 15) && ltop;
             }
             // LOCUS: the 12-mers ending at [lowest hit - 4, highest hit] need no lookup — those inside a member are present, the
@@ -673,8 +689,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 {
                     // round 1 as well leaves out the pairs whose 12-mers only lie in 16-mers the text has refuted (U13, S1)
                     uint32_t alive = settled ? 0u : (valid16 & (~refuted | known));
-                    uint32_t right = __shfl_down(alive, 1, 64);
-                    if (lane == 63) right = 0xffffu;
+                    const uint32_t right = flx_from_right(alive, 0xffffu);
                     uint32_t dep = alive | (right << 16);
                     dep |= dep >> 1;
                     dep |= dep >> 2;
@@ -684,13 +699,11 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 }
                 if (__any((want & 0xCCCCu) != 0)) {
                     const uint32_t v1 = p12 & valid12;
-                    uint32_t l1 = __shfl_up(v1 >> 11, 1, 64);
-                    if (lane == 0) l1 = c_p12;
+                    const uint32_t l1 = flx_from_left(v1 >> 11, c_p12);
                     const uint32_t m1 = (l1 >> 1) | (v1 << 4);
                     uint32_t alive = m1 & (m1 >> 1) & (m1 >> 2) & (m1 >> 3) & (m1 >> 4) & valid16 & ~refuted;
                     if (settled) alive = 0;  // (a settled lane asks nothing; its neighbours' 16-mers that reach into it count below)
-                    uint32_t right = __shfl_down(alive, 1, 64);
-                    if (lane == 63) right = 0xffffu;  // the next span's first lane is not known yet
+                    const uint32_t right = flx_from_right(alive, 0xffffu);  // (lane 63: the next span's first lane is not known yet)
                     uint32_t dep = alive | (right << 16);
                     dep |= dep >> 1;
                     dep |= dep >> 2;
@@ -700,15 +713,13 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 }
             }
             p12 &= valid12;
-            uint32_t p12_left = __shfl_up(p12 >> 11, 1, 64);  // the left lane's 12-mers ending at its positions 11..15 = mine at -5..-1
-            if (lane == 0) p12_left = c_p12;
+            uint32_t p12_left = flx_from_left(p12 >> 11, c_p12);  // the left lane's 12-mers ending at its positions 11..15 = mine at -5..-1
             if (!HAS_PREFILTER) p12_left = 0x1fu;
             const uint32_t m12 = (p12_left >> 1) | (p12 << 4);  // bit i: the 12-mer ending at p0 - 4 + i
             uint32_t cand = m12 & (m12 >> 1) & (m12 >> 2) & (m12 >> 3) & (m12 >> 4) & valid16;  // all five 12-mers present
             if (LOCUS) cand &= ~refuted | known;  // (a member known on one diagonal cannot be refuted on another — its 13-mers then occur twice in the text — but nothing is lost by saying so)
             if (settled) cand = hits;  // nothing open: the confirmed members are all this lane contributes
-            uint32_t lcand = __shfl_up(cand >> 15, 1, 64);
-            if (lane == 0) lcand = c_cand15;
+            const uint32_t lcand = flx_from_left(cand >> 15, c_cand15);
             hits &= cand;  // (a member is always a candidate)
             probed |= ~cand & 0xffffu;
 
@@ -736,9 +747,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 // that lane's search, so its answer arrives with this round's), corrected right after
                 const bool need = next_asks(lcand, top, bot);
                 if (__any(need)) probe(top, bot, cand);
-                lhit = __shfl_up(hits >> 15, 1, 64);
-                if (lane == 0) lhit = c_hit15;
-                lhit &= lcand;
+                lhit = flx_from_left(hits >> 15, c_hit15) & lcand;
             }
             for (;;) {
                 const bool need = next_asks(lhit, top, bot);
@@ -749,8 +758,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             // far first for the next span?  Per lane the skipped prefilter lines are worth 8 x 3.8 ps, a wasted request 18 ps
             // (tools/tabench): worth it from about half the lanes settled.
             if (LOCUS) {  // lanes the text settles anyway do not count: they ask nothing either way
-                uint32_t lknown = __shfl_up(known >> 15, 1, 64);
-                if (lane == 0) lknown = c_known15;
+                const uint32_t lknown = flx_from_left(known >> 15, c_known15);
                 far_first = __popcll(__ballot((hits >> 15) && lhit && !((known >> 15) && lknown))) >= FLX_FARFIRST_LANES_LOCUS;
                 c_known15 = __builtin_amdgcn_readlane(known >> 15, 63);
             } else {
@@ -791,7 +799,32 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
 #ifndef FLX_FOLD_FMA
 #define FLX_FOLD_FMA 1
 #endif
+// ---- the window recurrence on the integer grid (round 5) ------------------------------------------------------------------------
+// src/read.cpp:228-231 with qualities 0.0 / 1.0 is  w = fl(fl(w - tb * d) + lb * d),  d = fl(1 / ws), and the drift of those
+// roundings is part of the result.  But WHERE w rounds is known: on the grid of its binade.  Let d_E be d rounded to the grid of
+// binade E (2^(E-52)); a GROUP is a run of binades on which d_E is the same real number d* (and no binade rounds d on a tie).  While
+//   * w stays strictly above the bottom of its group (and above 4 d: a step that takes a base out and puts one in dips by d, and the
+//     way back is only exact from at most one binade down), and
+//   * w does not reach a binade above the one it was in when the regime began (there w's own low bits would be rounded away),
+// every step is EXACT:  w = w_b + c * d*  with c the number of covered bases that entered the window minus those that left — all
+// operands are multiples of the regime's grid, nothing rounds.  A word of 32 positions then is three small integers — the total,
+// the lowest and the highest prefix of its +-1 walk (a table over the (new, old) nibble pairs in LDS) — two compares and two adds;
+// the minimum of w over the word is w_b + (lowest prefix) * d*.  A word that leaves the regime is replayed in floating point, FOR
+// THAT LANE (the others keep their integer step), and the regime begins again from the value it ends on.  ws = 250 (the default):
+// d* = d + 4 ulp on every binade from 2^-4 up, so one regime holds while 16 of the 250 bases are covered and w has been as high
+// before; on the synthetic reads 0.7 % of a lane's words are replayed (the way into and out of a junk block, the first time a read's
+// window fills up).  tools/sim_fold_grid.cpp: the same regime logic on the host against the plain recurrence, 180 000 bit streams x
+// 6000 window sizes, bit for bit — and the tests hold this kernel against the FP kernel (FLX_KMER_FOLD_GRID=0) on every read and child.
+struct GridTab {
+    enum { kMax = 26 };
+    double dstar[kMax];  // per binade of w (biased exponent e0 + i): d on that binade's grid; 0 = no regime there (a tie, or outside)
+    double lv[kMax];     // the value w must stay strictly above: max(bottom of the binade's group, 4 d)
+    int top[kMax];       // biased exponent of the highest binade of the binade's group
+    int e0, n;
+};
+
 struct FoldArgs {
+    GridTab gt;
     const uint32_t *cov;
     const uint64_t *cov_off;
     const int32_t *lengths;
@@ -803,6 +836,7 @@ struct FoldArgs {
     int ws;
     int ring_words;  // RING kernels: words per lane in the LDS ring (a power of two)
     int events;      // FLX_KMER_FOLD_EVENTS=1: the steady state walks the positions where the window's edges differ (measured: not faster)
+    int grid;        // 1: the steady state runs on the integer grid (GridTab below; FLX_KMER_FOLD_GRID=0 and windows without a wide group: 0)
     double ws_d;
     double delta;  // fl(1.0 / ws): the value of q/ws for a covered base (src/read.cpp:228-229)
     double clamp;  // 0.5 / ws
@@ -856,8 +890,16 @@ __device__ __forceinline__ double window_result(const FoldArgs &a, int len, int 
 // recurrence on the parent's coverage bits [start, end) (the row words funnel-shifted by start mod 32) and writes the child's
 // mean / window / pass flag.  5 + 6 replace MODE 4, whose 32 predicated positions per word carry the event machinery through
 // every bit (67 of the 98 ms per 10^11 positions of C4's folds).
-template <int MODE, bool RING>
-__global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
+#ifndef FLX_FOLD_WALK_COPIES
+#define FLX_FOLD_WALK_COPIES 1  // copies of the integer-grid fold's walk table in LDS (a power of two; 1, 8, 16 measured: no difference — the gathers are not what bounds the kernel)
+#endif
+#ifdef FLX_FOLD_WAVES_PER_EU  // (A/B builds: the register budget of the fold kernels)
+#define FLX_FOLD_OCC __attribute__((amdgpu_waves_per_eu(FLX_FOLD_WAVES_PER_EU)))
+#else
+#define FLX_FOLD_OCC
+#endif
+template <int MODE, bool RING, bool GRID = false>
+__global__ void __launch_bounds__(256) FLX_FOLD_OCC k_kmer_fold(const FoldArgs a) {
     const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = slot < (MODE == 6 ? a.n_children : a.n_reads);
     uint32_t rid = 0;  // MODE 6: the child's index
@@ -945,9 +987,11 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
         }
     };
     auto word = [&](const WStream &st, int wi) -> uint32_t {  // wi inside block st.blk or st.blk + 1
-        const uint4 &q = ((wi >> 2) == st.blk) ? st.cur : st.nxt;
+        // (selects, no reference to one of the two blocks: a reference makes the compiler keep the stream in scratch memory)
+        const bool cur = (wi >> 2) == st.blk;
         const int c = wi & 3;
-        const uint32_t v = c == 0 ? q.x : c == 1 ? q.y : c == 2 ? q.z : q.w;
+        const uint32_t x = cur ? st.cur.x : st.nxt.x, y = cur ? st.cur.y : st.nxt.y, z = cur ? st.cur.z : st.nxt.z, w = cur ? st.cur.w : st.nxt.w;
+        const uint32_t v = c == 0 ? x : c == 1 ? y : c == 2 ? z : w;
         return wi < n_words ? v : 0u;  // the padding of the last block is not coverage
     };
     WStream lead = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), 0};
@@ -955,7 +999,38 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
     WStream trail = lead;
     extern __shared__ uint32_t fold_ring[];
     const int R = a.ring_words;  // power of two >= 16 + ceil(ws / 32) + 2
-    uint32_t *ring = fold_ring + (size_t)(threadIdx.x >> 6) * (size_t)R * 64 + (threadIdx.x & 63);
+    // GRID: in front of the rings the table of the +-1 walk of four positions, indexed by (new nibble << 4 | old nibble): two dwords,
+    // {lowest prefix, -(highest prefix)} and {total, -total} as pairs of 16-bit integers (packed adds and minima carry both at once)
+    // ... and behind it the grid table itself (GridTab: d* and the lower bound per binade, 4 dwords per entry): a regime begins in
+    // the middle of the steady state, and a load from the kernel's arguments there costs the whole wave a trip to memory
+    // (kWalkCopies copies of the walk table, entry idx of copy c at (idx * copies + c): a lane reads copy lane % copies, so that
+    // lanes with different nibble pairs rarely meet in one bank — with one copy the 64 lanes of a gather share 32 bank pairs)
+    constexpr int kWalkCopies = FLX_FOLD_WALK_COPIES;
+    constexpr int kGridTabAt = 512 * kWalkCopies;  // dword index of the grid table
+    constexpr int kWalkWords = GRID ? kGridTabAt + 8 * 32 : 0;
+    if (GRID) {
+        for (int i = threadIdx.x; i < GridTab::kMax; i += blockDim.x) {
+            fold_ring[kGridTabAt + 8 * i + 0] = (uint32_t)__double2loint(a.gt.dstar[i]);
+            fold_ring[kGridTabAt + 8 * i + 1] = (uint32_t)__double2hiint(a.gt.dstar[i]);
+            fold_ring[kGridTabAt + 8 * i + 2] = (uint32_t)__double2loint(a.gt.lv[i]);
+            fold_ring[kGridTabAt + 8 * i + 3] = (uint32_t)__double2hiint(a.gt.lv[i]);
+            fold_ring[kGridTabAt + 8 * i + 4] = (uint32_t)a.gt.top[i];
+        }
+        for (int idx = threadIdx.x; idx < 256; idx += blockDim.x) {
+            int t = 0, mp = 0, xp = 0;
+            for (int i = 0; i < 4; ++i) {
+                t += ((idx >> (4 + i)) & 1) - ((idx >> i) & 1);
+                mp = min(mp, t);
+                xp = max(xp, t);
+            }
+            for (int c = 0; c < kWalkCopies; ++c) {
+                fold_ring[2 * (idx * kWalkCopies + c)] = ((uint32_t)mp & 0xffffu) | ((uint32_t)(-xp) << 16);
+                fold_ring[2 * (idx * kWalkCopies + c) + 1] = ((uint32_t)t & 0xffffu) | ((uint32_t)(-t) << 16);
+            }
+        }
+        __syncthreads();
+    }
+    uint32_t *ring = fold_ring + kWalkWords + (size_t)(threadIdx.x >> 6) * (size_t)R * 64 + (threadIdx.x & 63);
     uint4 nq[4];       // the block after the newest one in the ring
     int have_blk = -1;  // newest block in the ring (wave-uniform: every lane is at the same position)
     if (RING) {
@@ -1009,6 +1084,48 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
     for (int o = 32; o > 0; o >>= 1) Lmin = min(Lmin, __shfl_xor(Lmin, o, 64));
     const unsigned int d_lo = (unsigned int)(__double_as_longlong(delta) & 0xffffffffll);
     const unsigned int d_hi = (unsigned int)(__double_as_longlong(delta) >> 32);
+    // GRID: the regime of this lane's parent window (w = g_wb + g_c * g_ds while it holds; lowest c so far in g_cmin)
+    double g_wb = 0.0, g_ds = 0.0;
+    int g_c = 0, g_cmin = 0, g_lo = 0x7fffffff, g_hi = (int)0x80000000;
+    bool grid_on = false;  // wave-uniform: the steady state has begun (and not ended)
+    auto grid_flush = [&]() {  // the regime's state as the recurrence's: exact, every operand is a multiple of the regime's grid
+        P.mn = fmin(P.mn, fma((double)g_cmin, g_ds, g_wb));
+        P.w = fma((double)g_c, g_ds, g_wb);
+    };
+    auto grid_begin = [&]() {  // a regime from P.w on (tools/sim_fold_grid.cpp: begin_regime — the same arithmetic)
+        g_wb = P.w;
+        g_ds = 0.0;
+        g_c = 0;
+        g_cmin = 0;
+        g_lo = 0x7fffffff;
+        g_hi = (int)0x80000000;
+        const int eb = (__double2hiint(P.w) >> 20) & 0x7ff;
+        const int idx = eb - a.gt.e0;
+        if (P.w > 0.0 && idx >= 0 && idx < a.gt.n) {
+            const uint4 e = *reinterpret_cast<const uint4 *>(fold_ring + kGridTabAt + 8 * idx);
+            const double ds = __hiloint2double((int)e.y, (int)e.x), lv = __hiloint2double((int)e.w, (int)e.z);
+            if (ds > 0.0) {
+                // The top: w must not reach a binade on whose grid w_b does NOT lie (its low bits would be rounded away there).  w_b
+                // lies on the grid of binade eb + z, z = the trailing zero bits of its mantissa — a window that has once been full
+                // (w = 1.0) stays on the grid of [1, 2) whatever is subtracted, d* is a multiple of it — up to the top of the group.
+                const uint32_t m_lo = (uint32_t)__double2loint(P.w), m_hi = ((uint32_t)__double2hiint(P.w) & 0xfffffu) | 0x100000u;
+                const int z = m_lo ? __ffs((int)m_lo) - 1 : 32 + (__ffs((int)m_hi) - 1);
+                const int gb = min(eb + z, (int)fold_ring[kGridTabAt + 8 * idx + 4]);
+                const double uv = __hiloint2double((gb + 1) << 20, 0);
+                // smallest c with w + c d* > lv: the estimate's floor is the answer or up to two below it; the values decide
+                int k0 = (int)floor((lv - P.w) * a.ws_d);
+                if (fma((double)k0, ds, P.w) <= lv) ++k0;
+                if (fma((double)k0, ds, P.w) <= lv) ++k0;
+                // largest c with w + c d* < uv
+                int k1 = (int)ceil((uv - P.w) * a.ws_d);
+                if (fma((double)k1, ds, P.w) >= uv) --k1;
+                if (fma((double)k1, ds, P.w) >= uv) --k1;
+                g_ds = ds;
+                g_lo = k0;
+                g_hi = k1;
+            }
+        }
+    };
     for (int j0 = 0; j0 < Lmax; j0 += 32) {
       lead_w = lead_word(j0 >> 5);
       if (MODE == 4) {
@@ -1109,6 +1226,59 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
               tw = sh ? __builtin_amdgcn_alignbit(trail_word(twi + 1), t0, (unsigned)sh) : t0;
           }
           P.cnt += __popc(lead_w);
+          if (GRID) {
+              if (!grid_on) {
+                  grid_begin();
+                  grid_on = true;
+              }
+              typedef short s16x2 __attribute__((ext_vector_type(2)));
+              // the (new, old) nibble pairs of the word: byte k of `even` = nibbles 2k, of `odd` = nibbles 2k + 1
+              const uint32_t odd = (lead_w & 0xF0F0F0F0u) | ((tw >> 4) & 0x0F0F0F0Fu);
+              const uint32_t even = ((lead_w << 4) & 0xF0F0F0F0u) | (tw & 0x0F0F0F0Fu);
+              const uint2 *walk = reinterpret_cast<const uint2 *>(fold_ring) + (threadIdx.x & (kWalkCopies - 1));
+              s16x2 run = {0, 0}, ext = {0, 0};  // {prefix, -prefix} so far; {lowest prefix, -(highest prefix)}
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                  const uint32_t idx = ((k & 1 ? odd : even) >> (8 * (k >> 1))) & 0xffu;
+                  const uint2 e = walk[idx * kWalkCopies];
+                  ext = __builtin_elementwise_min(ext, run + __builtin_bit_cast(s16x2, e.x));
+                  run = run + __builtin_bit_cast(s16x2, e.y);
+              }
+              const int mp = ext.x, xp = -(int)ext.y, t = run.x;
+              // not a no-op (a word of zeros on both edges changes nothing in any regime) and outside the regime: this lane's word in FP
+#ifdef FLX_FOLD_GRID_NOSLOW  // (timing experiment only: wrong results)
+              const bool slow = false;
+#else
+              const bool slow = (lead_w | tw) != 0u && !(g_c + mp >= g_lo && g_c + xp <= g_hi);
+#endif
+              if (!__any(slow)) {
+                  g_cmin = min(g_cmin, g_c + mp);
+                  g_c += t;
+                  continue;
+              }
+              if (!slow) {
+                  g_cmin = min(g_cmin, g_c + mp);
+                  g_c += t;
+                  lead_w = tw = 0;  // (32 exact no-ops below)
+              } else {
+                  grid_flush();
+              }
+              // (four rounds of eight steps, not 32 unrolled: unrolled, the compiler converts all 64 bits to doubles ahead of the chain
+              // and the kernel needs 122 registers, or spills)
+#pragma unroll 1
+              for (int i0 = 0; i0 < 32; i0 += 8) {
+#pragma unroll
+                  for (int i = 0; i < 8; ++i) {
+                      const double lb = (double)__builtin_amdgcn_ubfe(lead_w, i0 + i, 1);
+                      const double tb = (double)__builtin_amdgcn_ubfe(tw, i0 + i, 1);
+                      P.w = fma(tb, -delta, P.w);
+                      P.w = fma(lb, delta, P.w);
+                      P.mn = fmin(P.mn, P.w);
+                  }
+              }
+              if (slow) grid_begin();
+              continue;
+          }
           if (a.events) {
               // Round-3 review, item 5: only the positions where the two edges DIFFER change w for certain (one exact step each);
               // where both are 0 nothing happens, and where both are 1 the step is fl(fl(w - d) + d), which is w itself unless the
@@ -1166,6 +1336,13 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
           }
           continue;
       }
+      if (GRID && grid_on) {  // the steady state is over (the shortest read of the wave ends inside this word): back to the recurrence's own state
+          grid_flush();
+          grid_on = false;
+          g_ds = 0.0;
+          g_c = g_cmin = 0;
+          g_wb = P.w;
+      }
       for (int jj = 0; jj < 32; ++jj) {
         const int j = j0 + jj;
         if (j >= Lmax) break;
@@ -1222,6 +1399,7 @@ __global__ void __launch_bounds__(256) k_kmer_fold(const FoldArgs a) {
         }
       }
     }
+    if (GRID && grid_on) grid_flush();
     if (!live) return;
 
     if (MODE == 6) {  // the child's own scores (src/read.cpp:131-137 -> the Read constructor's folds on the child's slice)
@@ -1278,6 +1456,51 @@ __global__ void k_child_keys(uint64_t n, const int32_t *ranges, uint64_t *keys, 
 
 // the fold kernels: with the LDS ring when it fits (R words per lane; 4 waves per workgroup up to R = 64, one wave up to R = 512),
 // else (windows beyond ~15 000 positions) both streams from global memory
+// The grid table of a window size (GridTab, above): per binade of w the step d rounded to that binade's grid, the groups of binades
+// that share it, and whether the integer-grid steady state pays — the group that holds [1, 2) must reach down to 2^-3 at least (ws =
+// 250: 2^-4; ws = 1000: d rounds differently on either side of 1.0, where the window of a clean read sits — the FP kernel then).
+static bool build_grid_table(int ws, GridTab &g) {
+    memset(&g, 0, sizeof g);
+    if (ws < 8 || ws > (1 << 20)) return false;
+    volatile double one = 1.0, wsd = (double)ws;
+    const double delta = one / wsd;
+    uint64_t bits;
+    memcpy(&bits, &delta, 8);
+    const int e_d = (int)((bits >> 52) & 0x7ff) - 1023;
+    const uint64_t M = (bits & ((1ull << 52) - 1)) | (1ull << 52);  // delta = M * 2^(e_d - 52)
+    const int e_min = e_d - 2, e_max = 1;
+    const int n = e_max - e_min + 1;
+    if (n > GridTab::kMax) return false;
+    bool tie[GridTab::kMax];
+    for (int i = 0; i < n; ++i) {
+        const int shift = (e_min + i) - e_d;  // the grid of binade E is 2^shift ulps of delta
+        tie[i] = false;
+        if (shift <= 0) {
+            g.dstar[i] = delta;
+        } else {
+            const uint64_t rem = M & ((1ull << shift) - 1), half = 1ull << (shift - 1);
+            tie[i] = rem == half;
+            g.dstar[i] = ldexp((double)((M >> shift) + (rem > half ? 1 : 0)), shift + e_d - 52);
+        }
+    }
+    bool pays = false;
+    for (int i = 0; i < n;) {  // groups: maximal runs of binades without a tie that share d*
+        if (tie[i]) { g.dstar[i] = 0.0; g.lv[i] = 0.0; ++i; continue; }
+        int j = i;
+        while (j + 1 < n && !tie[j + 1] && g.dstar[j + 1] == g.dstar[i]) ++j;
+        const double bottom = std::max(ldexp(1.0, e_min + i), 4.0 * delta);
+        for (int k = i; k <= j; ++k) {
+            g.lv[k] = bottom;
+            g.top[k] = 1023 + e_min + j;
+        }
+        if (e_min + i <= -3 && e_min + j >= 0) pays = true;
+        i = j + 1;
+    }
+    g.e0 = 1023 + e_min;
+    g.n = n;
+    return pays;
+}
+
 template <int MODE>
 static int launch_fold(flx_ctx *ctx, FoldArgs &a) {
     int R = 32;
@@ -1287,13 +1510,20 @@ static int launch_fold(flx_ctx *ctx, FoldArgs &a) {
     const unsigned threads = (!ring || R <= 64) ? 256u : 64u;
     const unsigned nb = (unsigned)(((MODE == 6 ? a.n_children : a.n_reads) + threads - 1) / threads);
     a.ring_words = R;
-    if (ring) {
+    if (ring && a.grid && !a.events && (MODE == 0 || MODE == 3 || MODE == 6)) {  // the steady state on the integer grid (GridTab)
+        constexpr int M = (MODE == 0 || MODE == 3 || MODE == 6) ? MODE : 0;
+        ctx->last_kmer_fold_grid = true;
+        const size_t lds = (size_t)(threads / 64) * (size_t)R * 256 + 2048 * FLX_FOLD_WALK_COPIES + 1024;
+        FLX_HIP(ctx, hipFuncSetAttribute((const void *)k_kmer_fold<M, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_kmer_fold<M, true, true>), dim3(nb), dim3(threads), lds, ctx->stream, a);
+    } else if (ring) {
         const size_t lds = (size_t)(threads / 64) * (size_t)R * 256;
         FLX_HIP(ctx, hipFuncSetAttribute((const void *)k_kmer_fold<MODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_kmer_fold<MODE, true>), dim3(nb), dim3(threads), lds, ctx->stream, a);
     } else {
         hipLaunchKernelGGL((k_kmer_fold<MODE, false>), dim3(nb), dim3(threads), 0, ctx->stream, a);
     }
+    FLX_HIP(ctx, hipGetLastError());  // (a launch that fails must not pass for a kernel that wrote nothing)
     return FLX_OK;
 }
 
@@ -1398,6 +1628,9 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     {
         const char *ev_env = getenv("FLX_KMER_FOLD_EVENTS");
         a.events = ev_env && ev_env[0] == '1';
+        const char *grid_env = getenv("FLX_KMER_FOLD_GRID");  // "0": the floating-point steady state (the second implementation; tests, A/B)
+        a.grid = build_grid_table(params->window_size, a.gt) && !(grid_env && grid_env[0] == '0');
+        ctx->last_kmer_fold_grid = false;  // (launch_fold says so when a grid kernel really runs)
     }
     a.mean_q = out->mean_q;
     a.window_q = out->window_q;

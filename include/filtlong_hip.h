@@ -38,7 +38,8 @@ extern "C" {
 /* 2 (round 4): + flx_device_count, flx_reads2_gather(_dev) (added in round 3 under version 1), flx_last_kmer_locus; finalize of a
  * set built from an assembly also keeps the assembly as a text + seed table (0.5 B per base + 10 B per distinct 16-mer of device
  * memory beside the 512 MiB bitmap, 1 GiB pair table and 2 + 2 MiB prefilters); when that memory cannot be had the set works without */
-#define FLX_ABI_VERSION 2
+/* 3 (round 5): + flx_last_kmer_fold_grid */
+#define FLX_ABI_VERSION 3
 
 enum flx_status {
     FLX_OK = 0,
@@ -98,6 +99,10 @@ const char *flx_last_phred_kernel(const flx_ctx *ctx);
 /* 1 when the last k-mer-mode scoring call confirmed members along the reads' loci in the assembly text (sets built from an
  * assembly; FLX_KMER_LOCUS=0 switches it off), 0 otherwise.  Results are identical either way. */
 int flx_last_kmer_locus(const flx_ctx *ctx);
+/* 1 when the window recurrence of the last k-mer-mode scoring call ran on the integer grid (exact; window sizes whose step 1 / ws
+ * rounds alike on the binades from 2^-3 to 2 — the default 250 among them; FLX_KMER_FOLD_GRID=0 switches it off), 0 when every step
+ * was taken in floating point.  Results are identical either way. */
+int flx_last_kmer_fold_grid(const flx_ctx *ctx);
 int flx_timing_enable(flx_ctx *ctx, int on);
 int flx_timing_reset(flx_ctx *ctx);
 int flx_timing_get(flx_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches);

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_version_and_layout_helpers(lib):
     L = _lib.load()
-    assert L.flx_abi_version() == 2
+    assert L.flx_abi_version() == 3
     assert b"gfx950" in L.flx_version()
     import numpy as np
     from filtlong_amd import api

@@ -194,9 +194,33 @@ def test_kmer_mode_properties(short_reads, size):
                 assert torch.equal(t[k].view(torch.uint8), per_child[k].view(torch.uint8)), (variant, k)
             for k, per in (("crng", 2), ("cmean", 1), ("cwin", 1), ("cpass", 1)):
                 assert torch.equal(t[k][:per * n_word].view(torch.uint8), per_child[k][:per * n_word].view(torch.uint8)), (variant, k)
+    # the window folds on the integer grid (default at this window size, round 5) and in floating point step by step
+    # (FLX_KMER_FOLD_GRID=0) agree on every read and child of the batch
+    import os
+    assert ctx.last_kmer_fold_grid()
+    on_grid = {k: v.clone() for k, v in t.items()}
+    n_grid = int(s.n_children)
+    os.environ["FLX_KMER_FOLD_GRID"] = "0"
+    try:
+        for v in t.values():
+            v.zero_()
+        torch.cuda.synchronize()
+        assert ctx.score_kmer_dev(ks, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n,
+                                  params, s) == 0
+        torch.cuda.synchronize()
+        assert not ctx.last_kmer_fold_grid()
+    finally:
+        del os.environ["FLX_KMER_FOLD_GRID"]
+    assert int(s.n_children) == n_grid
+    for k in ("mean", "win", "pass", "first", "last", "coff"):
+        assert torch.equal(t[k].view(torch.uint8), on_grid[k].view(torch.uint8)), ("FP folds", k)
+    for k, per in (("crng", 2), ("cmean", 1), ("cwin", 1), ("cpass", 1)):
+        assert torch.equal(t[k][:per * n_grid].view(torch.uint8), on_grid[k][:per * n_grid].view(torch.uint8)), ("FP folds", k)
+    for k, v in on_grid.items():  # (the default kernels' results are what the rest of the test looks at)
+        t[k].copy_(v)
+    del on_grid
     # the two implementations of the coverage kernel (wave level with pair tables / round 2's workgroup-per-read kernel with one
     # bitmap lookup per candidate run end) agree on every read and child of the batch
-    import os
     wave_level = {k: v.clone() for k, v in t.items()}
     n_wave = int(s.n_children)
     os.environ["FLX_KMER_COVER"] = "v2"

@@ -707,3 +707,67 @@ def test_set_without_room_for_the_pair_table(ctx, be, synth, monkeypatch):
     got2 = be.score(reads, pkw, ks2)
     for (name, _s, _q), a, b in zip(reads, want2, got2):
         assert key(a) == key(b), name
+
+
+def test_integer_grid_folds_vs_oracle(ctx, monkeypatch):
+    """Round 5: the window recurrence's steady state on the integer grid (score_kmer.hip: GridTab; tools/sim_fold_grid.cpp is the same
+    logic on the host).  Reads whose coverage is engineered to sit ON the regime's edges — junk and clean stretches alternating with
+    periods from 16 to 3000 bases, so that the window count hovers around ws / 2, ws / 4, ..., falls to 0 and climbs back, reaches
+    the full window and leaves it — against the ORACLE (the plain recurrence on the CPU) bit for bit, parents and children, for the
+    default window and for window sizes with one wide group (500, 128: a power of two, d is exact), narrow groups (100), none that
+    pays (1000, 31: the FP kernel must have run) — and the grid kernel against the FP kernel (FLX_KMER_FOLD_GRID=0) on all of it."""
+    from filtlong_amd import synth as S
+    rng = np.random.RandomState(11)
+    ref = S.bases_read(S.STREAM_REF, 0, 0, 400_000)
+    oset = _oracle.KmerSet()
+    oset.add_assembly([ref.tobytes()])
+    ks = api.Kmers(ctx)
+    ks.add_assembly_fasta([ref.tobytes()])
+    ks.finalize()
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = []
+    periods = [(16, 16), (17, 15), (40, 40), (100, 20), (20, 100), (125, 125), (126, 124), (250, 250), (500, 300), (62, 190), (31, 219),
+               (15, 235), (8, 242), (3000, 900), (1000, 16), (249, 1), (1, 16), (64, 64), (33, 31), (700, 700)]
+    for k in range(400):
+        L = int(rng.randint(600, 9000))
+        start = int(rng.randint(0, len(ref) - L))
+        seq = ref[start:start + L].copy()
+        a, b = periods[k % len(periods)]
+        if k >= 2 * len(periods):  # later reads: the same periods with jitter, then sparse substitutions on top
+            a, b = max(1, a + int(rng.randint(-3, 4))), max(1, b + int(rng.randint(-3, 4)))
+        pos = int(rng.randint(0, a + b))
+        while pos < L:
+            pos += a
+            e = min(L, pos + b)
+            if pos < L:
+                seq[pos:e] = acgt[rng.randint(0, 4, e - pos)]
+            pos = e
+        if k % 3 == 2:
+            sub = rng.rand(L) < 0.02
+            seq[sub] = acgt[rng.randint(0, 4, int(sub.sum()))]
+        reads.append(seq.tobytes())
+    plane, offsets, lengths = api.pack_reads(reads)
+    order = api.length_order(lengths)
+    keys = ("mean_q", "window_q", "passed", "first", "last", "child_offsets", "child_ranges", "child_mean_q", "child_window_q", "child_passed")
+
+    def same(a, b, what):
+        for k in keys:
+            x, y = np.ascontiguousarray(a[k]), np.ascontiguousarray(b[k])
+            if x.dtype == np.float64:
+                x, y = x.view(np.uint64), np.asarray(y, dtype=np.float64).view(np.uint64)
+            assert x.shape == y.shape and (x == np.asarray(y, dtype=x.dtype).reshape(x.shape)).all(), (what, k)
+
+    for ws, grid in ((250, True), (500, True), (128, True), (64, True), (100, None), (96, None), (333, None), (1000, False), (31, False), (2047, None), (7, False)):
+        for pkw in (dict(window_size=ws), dict(window_size=ws, trim=True, split=max(32, ws // 2))):
+            monkeypatch.delenv("FLX_KMER_FOLD_GRID", raising=False)
+            dev = ctx.score_reads(plane, offsets, lengths, api.make_params(**pkw), kmers=ks, order=order)
+            if grid is not None:
+                assert ctx.last_kmer_fold_grid() == grid, (ws, pkw)
+            want = _oracle.score_plane_mt(plane, offsets, lengths, _oracle.make_params(**pkw), kmerset=oset, child_cap=300 * len(reads))
+            same(dev, want, ("oracle", ws, sorted(pkw)))
+            monkeypatch.setenv("FLX_KMER_FOLD_GRID", "0")
+            fp = ctx.score_reads(plane, offsets, lengths, api.make_params(**pkw), kmers=ks, order=order)
+            assert not ctx.last_kmer_fold_grid()
+            same(dev, fp, ("FP kernel", ws, sorted(pkw)))
+    monkeypatch.delenv("FLX_KMER_FOLD_GRID", raising=False)
+    ks.close()

@@ -89,7 +89,8 @@ def main():
     out = {"reads": n, "bases": bases, "set_size": len(ks), "set_build_s": round(build_s, 2), "ms_per_call": round(el * 1e3, 2),
            "cover_ms": round(cover_ms / args.steps, 2), "fold_ms": round(fold_ms / args.steps, 2),
            "Glookups_per_s": round(lookups / (cover_ms / args.steps * 1e-3) / 1e9, 2), "Mbases_per_s": round(bases / el / 1e6, 1),
-           "children": int(s.n_children), "mean_q_avg": float(t["mean"].mean().item()), "rc": rc}
+           "children": int(s.n_children), "mean_q_avg": float(t["mean"].mean().item()), "rc": rc,
+           "fold_on_integer_grid": ctx.last_kmer_fold_grid(), "locus": ctx.last_kmer_locus()}
     print(json.dumps(out))
 
 

@@ -57,7 +57,10 @@ static Table make_table(int ws) {
     return t;
 }
 
+// what the kernel does when a regime begins (score_kmer.hip: begin_regime) — same arithmetic, same corrections
 struct Regime { bool valid; double wb, dstar; long lo_c, hi_c; };
+static long g_reason[4];  // slow words by reason: 0 no regime, 1 below, 2 above
+static int g_ctz_rule = 1;  // the top of a regime: the highest binade on whose grid w_b already lies (0: the binade w_b is in)
 static Regime begin_regime(const Table &t, double w, int ws) {
     Regime r{false, w, 0, 1, -1};
     if (!(w > 0)) return r;
@@ -67,11 +70,34 @@ static Regime begin_regime(const Table &t, double w, int ws) {
     if (E < t.e_min || E > t.e_max) return r;
     const Binade &b = t.b[(size_t)(E - t.e_min)];
     if (b.group < 0) return r;
-    const double Lv = ldexp(1.0, t.glo[(size_t)b.group]), Uv = ldexp(1.0, E + 1);
+    // the bottom of the group, and never closer to 0 than 4 delta: a (1,1) step dips by delta and must stay within ONE binade of w
+    // the top: w must not reach a binade on whose grid w_b does NOT lie (there its low bits would be rounded away).  w_b lies on the
+    // grid of binade E + z, z = trailing zero bits of its mantissa (a window that has been full, w = 1.0, stays on the grid of [1, 2)
+    // whatever is subtracted: d* is a multiple of that grid) — up to the top of the group
+    int G = E;
+    if (g_ctz_rule) {
+        uint64_t bits;
+        memcpy(&bits, &w, 8);
+        const uint64_t m = (bits & ((1ull << 52) - 1)) | (1ull << 52);
+        G = std::min(E + (int)__builtin_ctzll(m), t.ghi[(size_t)b.group]);
+    }
+    const double Lv = std::max(ldexp(1.0, t.glo[(size_t)b.group]), 4.0 * t.delta), Uv = ldexp(1.0, G + 1);
+    const double ds = b.dstar, wsd = (double)ws;
+    // smallest k with w + k d* > Lv: the estimate (Lv - w) * ws is within 1e-9 of (Lv - w) / d*, so its floor is the answer or
+    // one or two below it; the values themselves decide (w + k d* is exact: a multiple of w's grid)
+    // (strictly above Lv: a step that lands exactly ON the bottom of the group's lowest binade has its true value, w - delta, a
+    // hair below it when delta > d* — in the binade underneath, which rounds on its own, finer grid)
+    long k0 = (long)floor((Lv - w) * wsd);
+    if (fma((double)k0, ds, w) <= Lv) ++k0;
+    if (fma((double)k0, ds, w) <= Lv) ++k0;
+    // largest k with w + k d* < Uv: the ceiling of the estimate is the answer or one or two above it
+    long k1 = (long)ceil((Uv - w) * wsd);
+    if (fma((double)k1, ds, w) >= Uv) --k1;
+    if (fma((double)k1, ds, w) >= Uv) --k1;
     r.valid = true;
-    r.dstar = b.dstar;
-    r.lo_c = (long)ceil((Lv - w) * ws + 1e-6) + 1;   // c - 1 steps below must still be >= Lv (the dip of a (1,1) step)
-    r.hi_c = (long)ceil((Uv - w) * ws - 1e-6) - 1;   // w_b + c d* < Uv
+    r.dstar = ds;
+    r.lo_c = k0;
+    r.hi_c = k1;
     return r;
 }
 
@@ -135,6 +161,7 @@ static Fold fold_grid(const std::vector<uint8_t> &q, int ws, const Table &t, std
         }
         flush();
         if (slow) slow->push_back(j >> 5);
+        ++g_reason[!r.valid ? 0 : (c + mp < r.lo_c ? 1 : 2)];
         for (int i = 0; i < 32; ++i) {
             w -= q[j + i - ws] ? d : 0.0;
             w += q[j + i] ? d : 0.0;
@@ -204,8 +231,12 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < t.b.size(); ++i) if (t.b[i].tie) printf(" 2^%d", t.e_min + (int)i);
         printf("\n");
     }
+    g_reason[0] = g_reason[1] = g_reason[2] = 0;
     // (2) slow words per wave, C3-like reads (gamma lengths, sorted descending, 64 per wave)
-    for (int ws : {250, 100, 1000}) {
+    for (int rule = 0; rule < 2; ++rule)
+    for (int ws : {250, 100, 500}) {
+        g_ctz_rule = rule;
+        printf("top of a regime %s: ", rule ? "by the grid w_b lies on" : "the binade w_b is in");
         const Table t = make_table(ws);
         const int n = 64 * 60;
         std::vector<int> len((size_t)n);
@@ -228,8 +259,9 @@ int main(int argc, char **argv) {
             for (char x : any) wave_slow += x;
             wave_words += (len[(size_t)w0] - ws) / 32;
         }
-        printf("ws %d: lane-words %ld, slow %ld (%.3f %%); wave-words %ld, with a slow lane %ld (%.1f %%)\n", ws, lane_words, lane_slow,
-               100.0 * lane_slow / lane_words, wave_words, wave_slow, 100.0 * wave_slow / wave_words);
+        printf("ws %d: lane-words %ld, slow %ld (%.3f %%); wave-words %ld, with a slow lane %ld (%.1f %%); reasons: no regime %ld, below %ld, above %ld\n", ws, lane_words, lane_slow,
+               100.0 * lane_slow / lane_words, wave_words, wave_slow, 100.0 * wave_slow / wave_words, g_reason[0], g_reason[1], g_reason[2]);
+        g_reason[0] = g_reason[1] = g_reason[2] = 0;
     }
     return bad != 0;
 }
