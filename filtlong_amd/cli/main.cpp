@@ -48,108 +48,11 @@
 
 #include "../../include/filtlong_hip.h"
 
-// ------------------------------------------------------------------------------------------------ formatting
-static std::string double_to_string(double n) {  // src/misc.cpp:24-32
-    std::stringstream ss;
-    ss << std::fixed << std::setprecision(2) << n;
-    std::string s = ss.str();
-    if (s.size() < 5) return std::string(5 - s.size(), ' ') + s;
-    return s;
-}
-
-static std::string int_to_string(long long n) {  // src/misc.cpp:35-40 (thousands grouping of the user's locale)
-    std::stringstream ss;
-    ss.imbue(std::locale(""));
-    ss << std::fixed << n;
-    return ss.str();
-}
-
-static std::string pad(const std::string &s, size_t width) { return width > s.size() ? s + std::string(width - s.size(), ' ') : s; }
-
+#include "format.h"
 #include "args.h"
 #include "fastx.h"
 #include "gzblocks.h"
-
-// FLX_CLI_PARSE_ONLY=seq|par|blk|unit|ranks:W: parse the input, print a digest of every field and exit (no GPU needed).  The CPU tests
-// compare the sequential parser with the concurrent one and with the block-wise reader on generated odd files.
-static int parse_only(const std::string &path, const char *mode) {
-    uint64_t h = 1469598103934665603ull;
-    auto mix = [&](const View &v) {
-        for (size_t i = 0; i < v.n; ++i) { h ^= (unsigned char)v.p[i]; h *= 1099511628211ull; }
-        h ^= 0xff; h *= 1099511628211ull;
-    };
-    auto mix_all = [&](const Parsed &pd) {
-        for (const Record &r : pd.recs) { mix(r.name); mix(r.comment); mix(r.seq); mix(r.qual); h ^= r.is_fastq; h *= 1099511628211ull; }
-    };
-    Parsed parsed;
-    bool par = false;
-    size_t n_records = 0;
-    if (mode[0] == 'b' || mode[0] == 'u') {  // blocks: the streaming reader, FLX_CLI_BLOCK_BYTES per block
-        BlockReader rd;
-        if (!rd.open(path, true)) { std::cerr << "Error reading " << path << "\n"; return 1; }
-        UnitIndex idx;
-        const uint64_t h_blocks_start = h;
-        while (rd.next(parsed)) {
-            mix_all(parsed);
-            for (const Record &r : parsed.recs) idx.note_record(rd.points, rd.offset_of(r.name.p - 1), n_records++);
-            if (parsed.status <= -2) break;
-        }
-        if (rd.io_error) { std::cerr << "Error reading " << path << "\n"; return 1; }
-        std::cerr << "inflate: " << rd.z.parallel_bytes() << " of " << rd.z.total_out() << " bytes from the parallel path (" << rd.z.zlib_tail_bytes() << " by zlib behind the marker decoder), " << rd.z.rounds()
-                  << " round(s), " << rd.z.dropped_chunks() << " chunk(s) dropped\n";
-        if (mode[0] == 'u' && parsed.status > -2) {
-            // units: every piece between two access points (FLX_CLI_SPAN_BYTES apart) inflated and parsed on its own, on
-            // several threads, as the output pass does; digest of the pieces in order
-            idx.finish(rd.points, rd.end_offset(), n_records);
-            std::vector<Parsed> got(idx.units());
-            std::vector<std::vector<char>> texts(idx.units());
-            std::vector<int> ok(idx.units(), 1);
-            parallel_for(idx.units(), [&](size_t j) {
-                if (idx.start[j + 1] == idx.start[j]) return;
-                if (!inflate_range(rd.file, rd.points[j], idx.start[j], idx.start[j + 1], texts[j])) { ok[j] = 0; return; }
-                Input view;
-                view.p = texts[j].data();
-                view.n = texts[j].size();
-                parse_sequential(view, got[j]);
-                if (got[j].recs.size() != idx.first_rec[j + 1] - idx.first_rec[j]) ok[j] = 0;
-            });
-            h = h_blocks_start;
-            for (size_t j = 0; j < idx.units(); ++j) {
-                if (!ok[j]) { std::cerr << "unit " << j << " failed\n"; return 1; }
-                mix_all(got[j]);
-            }
-            std::cerr << "units " << idx.units() << " points " << rd.points.size() << "\n";
-        }
-        std::cout << "records " << n_records << " status " << parsed.status << " bad " << parsed.bad.name << " parallel 0 digest " << h << "\n";
-        return 0;
-    }
-    Input data;
-    if (!data.open(path)) { std::cerr << "Error reading " << path << "\n"; return 1; }
-    if (strncmp(mode, "ranks:", 6) == 0) {
-        // ranks:W — every rank's share of the file (parse_rank_range), one after the other; accepted only if EVERY rank accepts its
-        // share, as the command line decides it from a sum over the ranks — else the whole file, as every rank would parse it then
-        const int world = std::max(1, atoi(mode + 6));
-        std::vector<Parsed> share((size_t)world);
-        bool all = data.map != nullptr;
-        for (int r = 0; r < world && all; ++r) all = parse_rank_range(data, r, world, share[(size_t)r]);
-        size_t n = 0;
-        if (all) {
-            for (const Parsed &sh : share) { mix_all(sh); n += sh.recs.size(); }
-        } else {
-            parse_all(data, parsed);
-            mix_all(parsed);
-            n = parsed.recs.size();
-        }
-        std::cout << "records " << n << " status " << parsed.status << " bad " << parsed.bad.name << " parallel " << (all ? 1 : 0) << " digest " << h << "\n";
-        return 0;
-    }
-    if (mode[0] == 's') parse_sequential(data, parsed);
-    else par = parse_all(data, parsed);
-    mix_all(parsed);
-    std::cout << "records " << parsed.recs.size() << " status " << parsed.status << " bad " << parsed.bad.name << " parallel "
-              << (par ? 1 : 0) << " digest " << h << "\n";
-    return 0;
-}
+#include "parse_only.h"
 
 // ------------------------------------------------------------------------------------------------ helpers
 #include <chrono>
@@ -182,172 +85,8 @@ static int fail_flx(flx_ctx *ctx, const char *what) {
 }
 
 #include "reference.h"
-
-// ---- ordered pieces ----------------------------------------------------------------------------------------------------
-// The output is produced as `n` independent pieces by several threads.  produce(j, piece) fills piece j and says whether it
-// could.  With `offsets` (n + 1 byte offsets, the sink a regular file that is not in append mode) every thread writes its
-// own pieces with pwrite at base + offsets[j] and the file position is moved behind the last one; without, this thread
-// writes the pieces in order as they become ready, and no more than 2 x threads of them exist at a time.
-static bool g_direct_pieces = false;  // write_pieces: the producers write their pieces themselves (pwrite at known offsets)
-static off_t g_direct_base = 0;
-static int g_shared_out = -1;         // ranks forked by --gpus N: a duplicate of the job's stdout (the SAME open file in every rank)
-// `forced_base` >= 0: the sink is a regular file shared with other processes and this process's pieces start at that offset (the
-// file position is then nobody's to move here)
-template <class Produce>
-static bool write_pieces(size_t n, Produce &&produce, FILE *sink, const std::vector<uint64_t> *offsets, off_t forced_base = -1) {
-    fflush(sink);
-    const int fd = fileno(sink);
-    struct stat st;
-    const int fl = fcntl(fd, F_GETFL);
-    const off_t base = forced_base >= 0 ? forced_base : lseek(fd, 0, SEEK_CUR);
-    const bool direct = offsets && (forced_base >= 0 || !getenv("FLX_CLI_ORDERED_OUTPUT")) && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 &&
-                        !(fl & O_APPEND) && base >= 0;
-    if (forced_base >= 0 && !direct) return false;
-    g_direct_pieces = direct;
-    g_direct_base = base;
-    std::vector<std::string> piece(n);
-    std::vector<char> state(n, 0);  // 1: ready (or written), 2: failed
-    std::mutex mu;
-    std::condition_variable cv;
-    std::atomic<size_t> next{0};
-    size_t written = 0;
-    const unsigned n_workers = (unsigned)std::max<size_t>(1, std::min<size_t>(host_threads(), n));
-    const size_t ahead = 2 * (size_t)n_workers;
-    auto worker = [&] {
-        for (;;) {
-            const size_t j = next.fetch_add(1);
-            if (j >= n) return;
-            if (!direct) {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return j < written + ahead; });
-            }
-            std::string &buf = piece[j];
-            if (offsets && !direct) buf.reserve((size_t)((*offsets)[j + 1] - (*offsets)[j]));
-            bool ok = produce(j, buf);
-            const bool self_written = direct && ok && buf.empty() && (*offsets)[j + 1] != (*offsets)[j];  // the producer used pwritev itself
-            if (offsets && !self_written) ok = ok && buf.size() == (*offsets)[j + 1] - (*offsets)[j];
-            if (direct) {
-                for (size_t done = 0; ok && done < buf.size();) {
-                    const ssize_t w = pwrite(fd, buf.data() + done, buf.size() - done, base + (off_t)((*offsets)[j] + done));
-                    if (w <= 0) ok = false;
-                    else done += (size_t)w;
-                }
-                std::string().swap(buf);
-            }
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                state[j] = ok ? 1 : 2;
-            }
-            cv.notify_all();
-        }
-    };
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < n_workers; ++t) pool.emplace_back(worker);
-    bool failed = false;
-    for (size_t j = 0; j < n; ++j) {
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return state[j] != 0; });
-            failed = failed || state[j] == 2;
-        }
-        if (!direct) {
-            if (!failed && fwrite(piece[j].data(), 1, piece[j].size(), sink) != piece[j].size()) failed = true;  // (the producers run dry below)
-            std::string().swap(piece[j]);
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                written = j + 1;
-            }
-            cv.notify_all();
-        }
-    }
-    for (auto &t : pool) t.join();
-    if (direct && forced_base < 0 && !failed && lseek(fd, base + (off_t)(*offsets)[n], SEEK_SET) < 0) failed = true;
-    return !failed;
-}
-
-// ---- rank 0 of `--gpus N`: the forked ranks, their pipes, the private directory of the output parts -------------------------
-// A watchdog thread reaps the children while rank 0 works: a child that dies early (no such device, RCCL missing, ...) would
-// otherwise leave rank 0 blocked inside a collective for ever — the job then ends at once with a message, and whichever way
-// main() is left no child and no file stays behind.
-struct Job {
-    std::vector<pid_t> children;
-    std::vector<int> id_pipes;
-    std::string dir;
-    std::thread watchdog;
-    std::mutex mu;
-    std::atomic<bool> stop{false};
-    std::vector<int> exited;  // exit status per child, -1 while it runs
-    Job() = default;
-    Job &operator=(Job &&o) {  // (a forked child drops its copy; no thread exists at that point)
-        children = std::move(o.children); id_pipes = std::move(o.id_pipes); dir = std::move(o.dir);
-        exited.clear();
-        return *this;
-    }
-    void remove_dir() {
-        if (dir.empty()) return;
-        for (size_t r = 0; r <= children.size(); ++r)
-            for (const char *kind : {"part", "vblocks", "vtable"}) unlink((dir + "/out." + kind + std::to_string(r)).c_str());
-        rmdir(dir.c_str());
-        dir.clear();
-    }
-    void kill_all() {
-        std::lock_guard<std::mutex> lk(mu);
-        for (size_t i = 0; i < children.size(); ++i)
-            if (exited.empty() || exited[i] < 0) kill(children[i], SIGKILL);
-    }
-    bool poll_once(bool block) {  // returns false when a child ended badly
-        bool ok = true;
-        std::lock_guard<std::mutex> lk(mu);
-        for (size_t i = 0; i < children.size(); ++i) {
-            if (exited[i] >= 0) { ok = ok && exited[i] == 0; continue; }
-            int st = 0;
-            const pid_t r = waitpid(children[i], &st, block ? 0 : WNOHANG);
-            if (r == children[i]) exited[i] = (WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0));
-            else if (r < 0) exited[i] = 255;
-            if (exited[i] > 0) ok = false;
-        }
-        return ok;
-    }
-    void start_watchdog() {
-        exited.assign(children.size(), -1);
-        watchdog = std::thread([this]() {
-            while (!stop.load()) {
-                if (!poll_once(false)) {
-                    int which = 0, status = 0;
-                    { std::lock_guard<std::mutex> lk(mu); for (size_t i = 0; i < exited.size(); ++i) if (exited[i] > 0) { which = (int)i + 1; status = exited[i]; } }
-                    const std::string msg = "\nError: rank " + std::to_string(which) + " ended early (status " + std::to_string(status) +
-                                            "): no GPU for it, or the RCCL library could not be loaded?\n";
-                    (void)!write(2, msg.data(), msg.size());
-                    kill_all();
-                    poll_once(true);
-                    remove_dir();
-                    _exit(1);
-                }
-                usleep(20000);
-            }
-        });
-    }
-    bool finish() {  // normal end: every child must have left with status 0
-        if (children.empty()) return true;
-        stop.store(true);
-        if (watchdog.joinable()) watchdog.join();
-        const bool ok = poll_once(true);
-        remove_dir();
-        children.clear();
-        return ok;
-    }
-};
-static Job g_job;
-struct JobGuard {
-    ~JobGuard() {  // an early return of rank 0
-        if (g_job.children.empty()) return;
-        g_job.stop.store(true);
-        if (g_job.watchdog.joinable()) g_job.watchdog.join();
-        g_job.kill_all();
-        g_job.poll_once(true);
-        g_job.remove_dir();
-    }
-};
+#include "output.h"
+#include "ranks.h"
 
 // The FLX_CLI_* environment variables this binary reads (test hooks and tuning knobs, README.md); any other FLX_CLI_* name is an
 // error — a mistyped switch must not be ignored silently.  (The library checks the rest of the FLX_* names: flx_ctx_create.)
@@ -381,63 +120,10 @@ int main(int argc, char **argv) {
     if (const int bad_env = check_cli_environment()) return bad_env;
     if (const char *po = getenv("FLX_CLI_PARSE_ONLY")) return parse_only(args.input_reads, po);
 
-    // ---- ranks: one process per GPU (north_star / SURVEY §8e) ---------------------------------------------------
-    // Either a launcher set RANK / WORLD_SIZE (/ LOCAL_RANK), or --gpus N forks N-1 copies of this process here, before
-    // any GPU state exists.  Reads are sharded by count in contiguous blocks of file order; every rank parses the (mapped)
-    // input's record index, scores its own block and takes part in the global stage through the library's RCCL
-    // communicator; rank 0 owns stderr and stdout.
-    // Launcher mode is an explicit opt-in — RANK + WORLD_SIZE + FLX_COMM_ID_FILE (a path unique to the job) all set: a bare
-    // WORLD_SIZE inherited from a SLURM / torchrun shell must not turn a plain run into a rank that waits for peers.
+    // ---- ranks: one process per GPU (north_star / SURVEY §8e; ranks.h) — under a launcher, or forked here by --gpus N ----
     std::string id_file;
     int id_pipe = -1;  // --gpus: the read end of this rank's pipe from rank 0
-    if (getenv("WORLD_SIZE") && getenv("RANK") && getenv("FLX_COMM_ID_FILE")) {
-        g_world = std::max(1, atoi(getenv("WORLD_SIZE")));
-        g_rank = atoi(getenv("RANK"));
-        id_file = getenv("FLX_COMM_ID_FILE");
-        g_part_prefix = id_file + ".out";
-    } else if (args.gpus > 1) {
-        if (!getenv("FLX_DEVICE")) {  // (FLX_DEVICE pins every rank to one device: the one-GPU tests of this path)
-            // the HIP runtime does not survive a fork, so the device count comes from a probe child
-            const pid_t probe = fork();
-            if (probe == 0) _exit(std::max(0, std::min(flx_device_count(), 255)));
-            int st = 0;
-            if (probe < 0 || waitpid(probe, &st, 0) < 0 || !WIFEXITED(st)) { std::cerr << "Error: cannot probe the GPUs\n"; return 1; }
-            if (WEXITSTATUS(st) < args.gpus) {
-                std::cerr << "Error: --gpus " << args.gpus << " but only " << WEXITSTATUS(st) << " GPU(s) visible\n";
-                return 1;
-            }
-        }
-        g_world = args.gpus;
-        // a private directory for the ranks' output parts (mkdtemp: mode 0700, unpredictable name)
-        const char *td = getenv("TMPDIR");
-        std::string tmpl = std::string(td && *td ? td : "/tmp") + "/flx_XXXXXX";
-        if (!mkdtemp(&tmpl[0])) { std::cerr << "Error: cannot create a temporary directory under " << (td && *td ? td : "/tmp") << "\n"; return 1; }
-        g_job.dir = tmpl;
-        g_part_prefix = tmpl + "/out";
-        // the communicator id reaches every rank through a pipe made before the fork
-        std::vector<int> wr;
-        for (int r = 1; r < g_world; ++r) {
-            int fds[2];
-            if (pipe(fds) != 0) { std::cerr << "Error: pipe failed\n"; return 1; }
-            const pid_t pid = fork();
-            if (pid < 0) { std::cerr << "Error: fork failed\n"; return 1; }
-            if (pid == 0) {
-                g_rank = r;
-                g_job = Job();  // a child owns neither children nor the directory
-                for (int w : wr) close(w);
-                close(fds[1]);
-                id_pipe = fds[0];
-                break;
-            }
-            close(fds[0]);
-            wr.push_back(fds[1]);
-            g_job.children.push_back(pid);
-        }
-        if (g_rank == 0) {
-            g_job.id_pipes = wr;
-            g_job.start_watchdog();
-        }
-    }
+    if (const int rc = start_ranks(args, id_file, id_pipe); rc >= 0) return rc;
     JobGuard job_guard;  // rank 0 of --gpus: whatever way main() is left, no child and no part file stays behind
     if (g_rank < 0 || g_rank >= g_world) { std::cerr << "Error: RANK " << g_rank << " outside WORLD_SIZE " << g_world << "\n"; return 1; }
     if (args.gpus > 1 && g_world > 1 && id_file.empty()) g_shared_out = dup(1);  // (forked ranks share the job's stdout: see the output pass)
@@ -483,56 +169,8 @@ int main(int argc, char **argv) {
         }
         return ctx != nullptr;
     };
-    if (g_world > 1) {
-        // the communicator's 128-byte id: --gpus hands it to every child through its pipe; under a launcher it travels through
-        // FLX_COMM_ID_FILE (rank 0: exclusive create of a temp name, never through a symlink, then rename; the others accept
-        // only a file written after they started — a stale one from a crashed earlier job is older)
-        unsigned char id[FLX_COMM_ID_BYTES];
-        if (g_rank == 0) {
-            if (flx_comm_unique_id(ctx, id) != FLX_OK) return fail_flx(ctx, "communicator");
-            if (!g_job.children.empty()) {
-                for (int w : g_job.id_pipes) {
-                    if (write(w, id, sizeof id) != (ssize_t)sizeof id) { std::cerr << "Error: cannot hand the communicator id to a rank\n"; return 1; }
-                    close(w);
-                }
-                g_job.id_pipes.clear();
-            } else {
-                const std::string tmp = id_file + ".tmp";
-                unlink(tmp.c_str());
-                const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
-                if (fd < 0 || write(fd, id, sizeof id) != (ssize_t)sizeof id) { std::cerr << "Error: cannot write " << tmp << "\n"; return 1; }
-                close(fd);
-                if (rename(tmp.c_str(), id_file.c_str()) != 0) { std::cerr << "Error: cannot create " << id_file << "\n"; return 1; }
-            }
-        } else if (id_pipe >= 0) {
-            size_t got = 0;
-            struct pollfd pfd = {id_pipe, POLLIN, 0};
-            while (got < sizeof id && poll(&pfd, 1, 120000) > 0) {  // rank 0 gone: EOF, at once
-                const ssize_t k = read(id_pipe, id + got, sizeof id - got);
-                if (k <= 0) break;
-                got += (size_t)k;
-            }
-            close(id_pipe);
-            if (got != sizeof id) return 1;
-        } else {
-            const time_t started = time(nullptr);
-            bool ok = false;
-            for (int tries = 0; tries < 6000 && !ok; ++tries) {  // up to 60 s
-                struct stat sb;
-                const int fd = open(id_file.c_str(), O_RDONLY | O_NOFOLLOW);
-                if (fd >= 0) {
-                    if (fstat(fd, &sb) == 0 && sb.st_mtime + 2 >= started) ok = read(fd, id, sizeof id) == (ssize_t)sizeof id;
-                    close(fd);
-                }
-                if (!ok) usleep(10000);
-            }
-            if (!ok) return 1;
-        }
-        if (flx_comm_init(ctx, id, g_rank, g_world) != FLX_OK) return fail_flx(ctx, "communicator");
-        uint64_t ready = 1;  // everybody has read the id
-        if (flx_comm_sum_u64(ctx, &ready, 1) != FLX_OK) return fail_flx(ctx, "communicator");
-        if (g_rank == 0 && !id_file.empty()) unlink(id_file.c_str());
-    }
+    if (g_world > 1)
+        if (const int rc = exchange_communicator_id(ctx, id_file, id_pipe); rc >= 0) return rc;
 
     stage("context");
     // ---- reference 16-mers (src/main.cpp:51-59, src/kmers.cpp:50-72) --------------------------------------

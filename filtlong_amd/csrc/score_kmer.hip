@@ -330,11 +330,52 @@ __device__ __forceinline__ uint32_t flx_from_right(uint32_t x, uint32_t lane63) 
 #define FLX_COVER_WAVES_PER_EU 8
 #endif
 #define FLX_COVER_OCC __attribute__((amdgpu_waves_per_eu(FLX_COVER_WAVES_PER_EU, FLX_COVER_WAVES_PER_EU)))
+struct CoverArgs {
+    const uint8_t *plane;
+    const uint64_t *offsets;
+    const int32_t *lengths;
+    const uint32_t *order;
+    uint64_t n_reads;
+    const uint8_t *exact15;
+    const uint8_t *pre11;
+    flx_locus loc;
+    uint32_t *cov;
+    const uint64_t *cov_off;
+    int32_t *count, *first, *last;
+};
+// A 64-bit kernel argument, read from the argument segment where it is used (s_load_dwordx2: the scalar cache).  The span loop
+// holds five table pointers, and the kernel has 78 scalar registers at 8 waves per SIMD: kept in registers they are spilled to
+// vector lanes and come back with two v_readlane each — vector instructions, which is what the kernel is bound by; a scalar load
+// costs none.  (asm volatile: neither hoisted out of the loop nor merged with a neighbour.)  MEASURED AND REJECTED (round 5):
+// 27 fewer spill instructions per span (39 -> 12), 10 fewer vector instructions in the loop — and 110.3 instead of 108.3 ms per
+// 1e11 positions: every reload waits for the scalar cache (s_waitcnt lgkmcnt(0)) on the wave's critical path.  -DFLX_COVER_ARGS_RELOAD
+// builds it.
+template <int OFFSET>
+__device__ __forceinline__ uint64_t flx_karg64() {
+    uint64_t v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"((uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFFSET));
+    return v;
+}
+// (the pointer comes out of an integer: without the global address space on it every access would be a flat load with a 64-bit
+// address built in vector registers — one more vector instruction per access, exactly what this is meant to remove)
+#define FLX_GLOBAL_PTR(elem) const elem __attribute__((address_space(1))) *
+#ifdef FLX_COVER_ARGS_RELOAD
+#define FLX_KARG_PTR(elem, field) ((FLX_GLOBAL_PTR(elem))flx_karg64<(int)offsetof(CoverArgs, field)>())
+#else
+#define FLX_KARG_PTR(elem, field) ((FLX_GLOBAL_PTR(elem))(uint64_t)(uintptr_t)(a.field))
+#endif
 template <bool HAS_PREFILTER, bool LOCUS>
-__global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_w(const uint8_t *plane, const uint64_t *offsets, const int32_t *lengths,
-                                                      const uint32_t *order, uint64_t n_reads, const uint8_t *exact15,
-                                                      const uint8_t *pre11, const flx_locus loc, uint32_t *cov, const uint64_t *cov_off,
-                                                      int32_t *count, int32_t *first, int32_t *last) {
+__global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_w(const CoverArgs a) {
+    const uint8_t *plane = a.plane;
+    const uint64_t *offsets = a.offsets;
+    const int32_t *lengths = a.lengths;
+    const uint32_t *order = a.order;
+    const uint64_t n_reads = a.n_reads;
+    uint32_t *cov = a.cov;
+    const uint64_t *cov_off = a.cov_off;
+    int32_t *count = a.count, *first = a.first, *last = a.last;
+    const uint32_t loc_n_alloc = a.loc.n_alloc, loc_seed_mask = a.loc.seed_mask;
+    const int loc_seed_shift = a.loc.seed_shift;
     const int lane = threadIdx.x & 63;
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -356,21 +397,23 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
         uint32_t c_mb = 0xffffffffu /* mismatches | piece starts << 16 of lane 63 */, c_us = 0 /* its U13 | S1 << 16 */, c_known15 = 0, c_twx = 0, c_twy = 0xffffu;
         uint2 tw = make_uint2(0, 0xffffu), tw_next = make_uint2(0, 0xffffu);
         uint32_t ts = 0, ts_next = 0, c_ts = 0;  // S1 bits of those text words (kmerset.h: safe1); lane 63's for the next span
-        const bool has_s1 = loc.safe1 != nullptr;
+        const bool has_s1 = a.loc.safe1 != nullptr;
         // the text word that holds the LAST base of the lane's 16 at this diagonal, for the lane whose 16 bases start at `base` +
         // 16 * lane (index clamped into the padded array).  The diagonal and `base` are wave-uniform: the 64-bit part of the index
         // is scalar work, a lane adds its number and clamps (the cover kernel is bound by its vector instructions)
         auto word_index = [&](long long dg, int base) -> uint32_t {
             long long u = ((dg + base + 15) >> 4) + (long long)kLocusPad;  // (16 * lane + c) >> 4 == lane + (c >> 4)
-            u = u < -64 ? -64 : (u > (long long)loc.n_alloc ? (long long)loc.n_alloc : u);
+            u = u < -64 ? -64 : (u > (long long)loc_n_alloc ? (long long)loc_n_alloc : u);
             const int w = (int)u + lane;
-            return (uint32_t)max(0, min(w, (int)loc.n_alloc - 1));
+            return (uint32_t)max(0, min(w, (int)loc_n_alloc - 1));
         };
         auto text_word = [&](long long dg, int base) -> uint2 {
-            return loc.text[word_index(dg, base)];  // (non-temporal here is slower: 14.2 vs 13.8 ms per 1e10 — a text word is used again by the next span's lane 0 and by reads of the same locus)
+            // (a 32-bit byte offset on a scalar base: one address register — the text has at most 2^28 positions, 2^27 bytes)
+            const uint64_t tv = *(FLX_GLOBAL_PTR(uint64_t))(FLX_KARG_PTR(uint8_t, loc.text) + (uint32_t)(word_index(dg, base) * 8u));
+            return make_uint2((uint32_t)tv, (uint32_t)(tv >> 32));  // (non-temporal here is slower: 14.2 vs 13.8 ms per 1e10 — a text word is used again by the next span's lane 0 and by reads of the same locus)
         };
         auto safe_word = [&](long long dg, int base) -> uint32_t {  // the S1 bits of that word
-            return has_s1 ? (uint32_t)loc.safe1[word_index(dg, base)] : 0u;
+            return has_s1 ? (uint32_t)*(FLX_GLOBAL_PTR(uint16_t))(FLX_KARG_PTR(uint8_t, loc.safe1) + (uint32_t)(word_index(dg, base) * 2u)) : 0u;
         };
 
         auto finalize = [&](int sp, uint32_t h, uint32_t right_of_63) {  // hits of span sp -> coverage bits, counts, row words
@@ -543,13 +586,20 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     }
                     uint32_t tpos = kLocusEmpty;
                     if (tries) {
-                        uint32_t h = flx_locus_hash(lo, loc.seed_shift);
+                        uint32_t h = flx_locus_hash(lo, loc_seed_shift);
+                        FLX_GLOBAL_PTR(uint32_t) seed_tab = FLX_KARG_PTR(uint32_t, loc.seed);
+                        FLX_GLOBAL_PTR(uint32_t) seed_text = FLX_KARG_PTR(uint32_t, loc.text);  // (.x of text word i at dword 2 i)
 #pragma unroll 1
                         for (int probe_no = 0; probe_no < 4; ++probe_no) {
-                            const uint32_t v = loc.seed[h];
+                            const uint32_t v = seed_tab[h];
                             if (v == kLocusEmpty) break;
-                            if (flx_locus_kmer_at(loc.text, v) == lo) { tpos = v; break; }
-                            h = (h + 1) & loc.seed_mask;
+                            {  // (flx_locus_kmer_at, kmerset.h, on the global-space pointer)
+                                const uint32_t tw_i = (v >> 4) + kLocusPad, ts_i = v & 15u;
+                                const uint32_t t0 = seed_text[2 * tw_i];
+                                const uint32_t at = ts_i == 0 ? t0 : __builtin_amdgcn_alignbit(t0, seed_text[2 * tw_i + 2], 32 - 2 * ts_i);
+                                if (at == lo) { tpos = v; break; }
+                            }
+                            h = (h + 1) & loc_seed_mask;
                         }
                     }
                     const unsigned long long found = __ballot(tpos != kLocusEmpty);
@@ -583,6 +633,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
 #else
                 // plain byte loads: non-temporal ones measured 8 % slower here (43.3 vs 40.1 ms per 1e10 positions), 4-byte loads
                 // 6 % slower — although a microbenchmark that mixes table and far lookups in one burst prefers nt (tools/tabench (7))
+                FLX_GLOBAL_PTR(uint8_t) exact15 = FLX_KARG_PTR(uint8_t, exact15);
                 if (top >= 0) g0 = exact15[__builtin_amdgcn_alignbit(hi, lo, 30 - 2 * a0) & 0x3FFFFFFFu];
                 if (bot >= 0) g1 = exact15[__builtin_amdgcn_alignbit(hi, lo, 30 - 2 * a1) & 0x3FFFFFFFu];
 #endif
@@ -629,6 +680,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             uint32_t p12 = 0xffffu;  // (a settled lane: every 12-mer of its last 16-mer is present, the others are not needed)
             if (HAS_PREFILTER && !LOCUS && !settled) {
                 uint32_t byte[8], sel[8];
+                FLX_GLOBAL_PTR(uint8_t) pre11 = FLX_KARG_PTR(uint8_t, pre11);
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     const uint32_t a = __builtin_amdgcn_alignbit(hi, lo, 28 - 4 * m);
@@ -662,6 +714,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 const uint64_t r64 = ((uint64_t)rc32(lo) << 32) | rc32(hi);
                 auto fetch = [&](uint32_t want, int parity) -> uint32_t {  // actual bits of the pairs m = parity, parity + 2, .. that hold a wanted position; 1 elsewhere
                     uint32_t byte[4], got = parity ? 0x3333u : 0xCCCCu;
+                    FLX_GLOBAL_PTR(uint8_t) pre11 = FLX_KARG_PTR(uint8_t, pre11);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int m = 2 * k + parity;
@@ -1581,21 +1634,17 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
             memset(&none, 0, sizeof none);
             ctx->last_kmer_locus = lp != nullptr;
             if (flx_kmerset_pre11(set) && lp)
-                hipLaunchKernelGGL((k_kmer_cover_w<true, true>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
-                                   flx_kmerset_exact15(set), flx_kmerset_pre11(set), *lp, (uint32_t *)d_cov, (const uint64_t *)d_covoff,
-                                   d_cnt, first, last);
+                { CoverArgs ca = {d_plane, d_offsets, d_lengths, d_order, n_reads, flx_kmerset_exact15(set), flx_kmerset_pre11(set), *lp, (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first, last};
+                  hipLaunchKernelGGL((k_kmer_cover_w<true, true>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, ca); }
             else if (flx_kmerset_pre11(set))
-                hipLaunchKernelGGL((k_kmer_cover_w<true, false>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
-                                   flx_kmerset_exact15(set), flx_kmerset_pre11(set), none, (uint32_t *)d_cov, (const uint64_t *)d_covoff,
-                                   d_cnt, first, last);
+                { CoverArgs ca = {d_plane, d_offsets, d_lengths, d_order, n_reads, flx_kmerset_exact15(set), flx_kmerset_pre11(set), none, (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first, last};
+                  hipLaunchKernelGGL((k_kmer_cover_w<true, false>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, ca); }
             else if (lp)
-                hipLaunchKernelGGL((k_kmer_cover_w<false, true>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
-                                   flx_kmerset_exact15(set), (const uint8_t *)nullptr, *lp, (uint32_t *)d_cov, (const uint64_t *)d_covoff,
-                                   d_cnt, first, last);
+                { CoverArgs ca = {d_plane, d_offsets, d_lengths, d_order, n_reads, flx_kmerset_exact15(set), (const uint8_t *)nullptr, *lp, (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first, last};
+                  hipLaunchKernelGGL((k_kmer_cover_w<false, true>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, ca); }
             else
-                hipLaunchKernelGGL((k_kmer_cover_w<false, false>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
-                                   flx_kmerset_exact15(set), (const uint8_t *)nullptr, none, (uint32_t *)d_cov, (const uint64_t *)d_covoff,
-                                   d_cnt, first, last);
+                { CoverArgs ca = {d_plane, d_offsets, d_lengths, d_order, n_reads, flx_kmerset_exact15(set), (const uint8_t *)nullptr, none, (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first, last};
+                  hipLaunchKernelGGL((k_kmer_cover_w<false, false>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, ca); }
         } else {
         hipLaunchKernelGGL(k_kmer_cover<256>, dim3(grid), dim3(256), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
                            flx_kmerset_bitmap(set), flx_kmerset_prefilter(set), (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first,
