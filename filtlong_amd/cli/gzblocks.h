@@ -92,6 +92,14 @@ struct BlockReader {
         for (;;) {
             if (!z.eof() && !z.error() && have < buf.size())
                 have += z.read(buf.data() + have, buf.size() - have, span ? &points : nullptr, span);
+            if (!file.gz() && buf_offset > dropped_ + ((uint64_t)64 << 20)) {
+                // a plain file: the pages of the mapping behind the window are not looked at again by this pass — given back, so
+                // that the resident set of a pass over a 20 GB file stays at the block's size (a later pass faults them in again
+                // from the page cache)
+                const uint64_t upto = buf_offset & ~(uint64_t)((2u << 20) - 1);
+                if (upto > dropped_) madvise((void *)(file.p + dropped_), (size_t)(upto - dropped_), MADV_DONTNEED);
+                dropped_ = upto;
+            }
             bool eof = z.eof();
             size_t released = eof ? have : (have > holdback ? have - holdback : 0);
             if (z.error()) {  // the bytes gzread would have delivered, then kseq's error state (fastx.h: Input::stream_error)
@@ -130,6 +138,7 @@ struct BlockReader {
     }
 
 private:
+    uint64_t dropped_ = 0;  // bytes of a plain file's mapping given back so far (a multiple of 2 MiB)
     size_t holdback = 0;
     Input view;  // non-owning window on buf
 };
