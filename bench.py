@@ -379,13 +379,13 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
     # round 4 at the full 1e7 reads; per-position figures scale to other batch sizes, the mix of reads is the same) — NOT measured
     # in this run, and only quoted while the kernel's source file still has the hash recorded with the pass
     req, req_src = None, None
-    fpath = os.path.join(ROOT, "profiles", "r04_kmer_requests.json")
-    if os.path.exists(fpath):
+    fpath = next((q for q in (os.path.join(ROOT, "profiles", r + "_kmer_requests.json") for r in ("r05", "r04")) if os.path.exists(q)), "")
+    if fpath:
         rec = json.load(open(fpath)).get(cfg)
         if rec and rec.get("kernel") == cover_kernel and rec.get("kernel_source_sha16") == source_sha16(*KMER_SOURCES):
             req = {"far_requests": rec["far_requests_per_base"] * b.bases, "traffic_bytes": rec["traffic_bytes_per_base"] * b.bases,
                    "l2_hits": rec["l2_hit_requests_per_base"] * b.bases}
-            req_src = "profiles/r04_kmer_requests.json (PMC passes of this command at %s reads%s; not this run)" % (
+            req_src = "profiles/" + os.path.basename(fpath) + " (PMC passes of this command at %s reads%s; not this run)" % (
                 "{:,}".format(rec["measured_at_reads"]), "" if rec["measured_at_reads"] == n else ", scaled per position")
     algo_bytes = b.bases + 33 * n + 25 * nc  # L + 8 + 25 per read, 8 + 17 per child
     achieved = algo_bytes / (cover * 1e-3) / 1e9
@@ -691,12 +691,12 @@ def main():
         # FETCH_SIZE x2 on gfx950 — calibrated for this kernel's 64-byte-per-read pattern on a known byte count,
         # profiles/r02_microbench.txt), recorded in profiles/ — NOT measured in this run; only quoted for the same workload.
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r04_traffic_c2.json")
-        if os.path.exists(tpath) and n == 10_000_000 and not args.fixed_len and args.window_size == 250 and profile == 0:
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", r + "_traffic_c2.json") for r in ("r05", "r04")) if os.path.exists(q)), "")
+        if tpath and n == 10_000_000 and not args.fixed_len and args.window_size == 250 and profile == 0:
             rec = json.load(open(tpath))
             # only quoted while it still describes this kernel: same kernel name AND the kernel's source file unchanged since the pass
             if rec.get("kernel") == kernel_name and rec.get("kernel_source_sha16") == source_sha16("score_phred_regs.hip"):
-                traffic, traffic_src = int(rec["traffic_bytes"]), "profiles/r04_traffic_c2.json (PMC pass of this command, not this run)"
+                traffic, traffic_src = int(rec["traffic_bytes"]), "profiles/" + os.path.basename(tpath) + " (PMC pass of this command, not this run)"
         info = ctx.device_info()
         out = {
             "metric": "Mbases/s scored+sorted",
@@ -836,12 +836,16 @@ def main():
             except Exception as e:
                 extras["end_to_end_cli_kmer"] = {"measured_in_this_run": False, "error": repr(e)}
             # the 20 GB and gzip runs are too long for the default bench: recorded by tools/bench_e2e_big.sh / bench_e2e_gz.sh
-            for key, path in (("end_to_end_cli_20GB_recorded", "r03_e2e_big.json"), ("end_to_end_cli_gzip_recorded", "r03_e2e_gz.json")):  # (round 3's runs: the ingest path did not change)
-                fp = os.path.join(ROOT, "profiles", path)
-                if os.path.exists(fp):
-                    e = json.load(open(fp))
-                    extras[key] = {"source": "profiles/%s (not measured in this run)" % path, "measured_in_this_run": False,
-                                   **{k: e[k] for k in e if k not in ("note",)}}
+            # (the newest recording there is; a figure of an earlier round says so — the ingest code has changed since)
+            for key, name in (("end_to_end_cli_20GB_recorded", "e2e_big.json"), ("end_to_end_cli_gzip_recorded", "e2e_gz.json")):
+                for rnd in ("r05", "r04", "r03"):
+                    fp = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))
+                    if os.path.exists(fp):
+                        e = json.load(open(fp))
+                        extras[key] = {"source": "profiles/%s_%s (not measured in this run; recorded in round %s%s)" % (
+                                           rnd, name, rnd[2:], "" if rnd == "r05" else ", on that round's ingest code"),
+                                       "measured_in_this_run": False, **{k: e[k] for k in e if k not in ("note",)}}
+                        break
             out["extras"] = extras
         print(json.dumps(out), flush=True)
     if multi:

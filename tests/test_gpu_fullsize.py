@@ -171,6 +171,7 @@ def test_kmer_mode_properties(short_reads, size):
     rc = ctx.score_kmer_dev(ks, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n, params, s)
     assert rc == 0
     torch.cuda.synchronize()
+    assert ctx.last_kmer_fold_grid()  # (the default at this window size: the folds' steady state on the integer grid)
     if short_reads:
         # one lane per child (default), the children inside their read's lane at word level (FLX_KMER_FOLD=words) and bit by bit
         # (FLX_KMER_FOLD=bits) are three implementations of src/read.cpp:86-141: they must agree on every one of the reads and
@@ -197,7 +198,6 @@ def test_kmer_mode_properties(short_reads, size):
     # the window folds on the integer grid (default at this window size, round 5) and in floating point step by step
     # (FLX_KMER_FOLD_GRID=0) agree on every read and child of the batch
     import os
-    assert ctx.last_kmer_fold_grid()
     on_grid = {k: v.clone() for k, v in t.items()}
     n_grid = int(s.n_children)
     os.environ["FLX_KMER_FOLD_GRID"] = "0"

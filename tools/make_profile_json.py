@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PFX = sys.argv[1] if len(sys.argv) > 1 else "r04"
+PFX = sys.argv[1] if len(sys.argv) > 1 else "r05"
 KMER_READS = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000  # reads of the k-mer PMC passes
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
@@ -76,7 +76,7 @@ def main():
     fe, _ = counters(os.path.join(G, "final", "pmc_fetch.txt"), "flx_score_phred_regs")
     wr, _ = counters(os.path.join(G, "final", "pmc_write.txt"), "flx_score_phred_regs")
     prev = os.path.join(P, PFX + "_traffic_c2.json")
-    old = json.load(open(prev if os.path.exists(prev) else os.path.join(P, "r03_traffic_c2.json")))
+    old = json.load(open(prev if os.path.exists(prev) else os.path.join(P, "r04_traffic_c2.json")))
     traffic = 2 * fe["FETCH_SIZE"] * 1024 + wr["WRITE_SIZE"] * 1024
     old.update({"kernel_source_sha16": sha16("score_phred_regs.hip"), "FETCH_SIZE_KiB": fe["FETCH_SIZE"], "WRITE_SIZE_KiB": wr["WRITE_SIZE"],
                 "traffic_bytes": traffic, "ratio": traffic / old["algorithmic_bytes"]})
