@@ -876,6 +876,7 @@ struct GridTab {
     int e0, n;
 };
 
+constexpr int kInlineChildren = 8;
 struct FoldArgs {
     GridTab gt;
     const uint32_t *cov;
@@ -897,6 +898,10 @@ struct FoldArgs {
     double *mean_q;
     double *window_q;
     uint8_t *passed;
+    // MODE 3 leaves the first kInlineChildren ranges of every read here ([n_reads][kInlineChildren][2], or NULL): they are moved to
+    // their places in the CSR once the counts have been scanned, and the ranges pass (MODE 5) only runs for a batch in which some
+    // read has more (round 5: MODE 5 walked every row again for ~1 child per read — 7.7 of C4's 33 ms of folds)
+    int32_t *inline_ranges;
     // MODE 5 / 6: one lane per child
     uint32_t *child_parent;         // [n_children] read index of every child (written by MODE 5, read by MODE 6)
     const uint32_t *child_order;    // [n_children] children by descending length (MODE 6)
@@ -1000,6 +1005,11 @@ __global__ void __launch_bounds__(256) FLX_FOLD_OCC k_kmer_fold(const FoldArgs a
             a.child_ranges[2 * at] = start;
             a.child_ranges[2 * at + 1] = end;
             a.child_parent[at] = rid;
+        }
+        if (MODE == 3 && a.inline_ranges && nchild < (uint32_t)kInlineChildren) {
+            int32_t *slot = a.inline_ranges + ((size_t)rid * kInlineChildren + nchild) * 2;
+            slot[0] = start;
+            slot[1] = end;
         }
         if (MODE == 2 || MODE == 4) {
             const int len = end - start;
@@ -1496,6 +1506,26 @@ __global__ void k_widen_u32_i64(uint64_t n, const uint32_t *in, int64_t *out) {
     if (i < n) out[i] = (int64_t)in[i];
 }
 
+// the ranges MODE 3 left inline -> their places in the CSR (+ every child's read); counts the reads that have more than fit inline
+__global__ void __launch_bounds__(256) k_children_from_inline(uint64_t n, const uint32_t *n_child, const uint64_t *child_offsets, const int32_t *inline_ranges,
+                                                              int32_t *child_ranges, uint32_t *child_parent, unsigned int *overflow) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t nc = n_child[i];
+    if (nc == 0) return;
+    if (nc > (uint32_t)kInlineChildren) {
+        atomicAdd(overflow, 1u);
+        return;
+    }
+    const uint64_t at = child_offsets[i];
+    const int32_t *src = inline_ranges + (size_t)i * kInlineChildren * 2;
+    for (uint32_t k = 0; k < nc; ++k) {
+        child_ranges[2 * (at + k)] = src[2 * k];
+        child_ranges[2 * (at + k) + 1] = src[2 * k + 1];
+        child_parent[at + k] = (uint32_t)i;
+    }
+}
+
 // sort key of a child: longest first (the lanes of a wave then run the same number of steps)
 __global__ void k_child_keys(uint64_t n, const int32_t *ranges, uint64_t *keys, uint32_t *vals) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1597,7 +1627,10 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     // batch once they have reached their size.
     const size_t scan_ws = flx_radix_sort_workspace(n_reads + 1);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t small_bytes = 2 * up((n_reads + 1) * 8) + 3 * up(n_reads * 4) + up((n_reads + 1) * 4) + up(scan_ws);
+    const char *fold_env0 = getenv("FLX_KMER_FOLD");
+    const bool inline_children = want_children && !(params->split_set && params->split < 32) && !fold_env0;  // (the one-lane-per-child path)
+    const size_t small_bytes = 2 * up((n_reads + 1) * 8) + 3 * up(n_reads * 4) + up((n_reads + 1) * 4) + up(scan_ws) +
+                               (inline_children ? up(n_reads * (size_t)kInlineChildren * 8) + up(64) : 0);
     void *small = nullptr;
     FLX_CHECK(flx_workspace(ctx, 0, small_bytes, &small));
     char *wp = (char *)small;
@@ -1609,6 +1642,8 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     int32_t *d_last_tmp = (int32_t *)carve(n_reads * 4);
     uint32_t *d_nchild = (uint32_t *)carve((n_reads + 1) * 4);
     void *d_scanws = carve(scan_ws);
+    int32_t *d_inline = inline_children ? (int32_t *)carve(n_reads * (size_t)kInlineChildren * 8) : nullptr;
+    unsigned int *d_overflow = inline_children ? (unsigned int *)carve(64) : nullptr;
     int32_t *first = out->first ? out->first : d_first_tmp, *last = out->last ? out->last : d_last_tmp;
     FLX_HIP(ctx, hipMemsetAsync(d_rowb, 0, (n_reads + 1) * 8, st));
     hipLaunchKernelGGL(k_cov_row_bytes, dim3(nb), dim3(256), 0, st, n_reads, d_lengths, d_rowb);
@@ -1685,6 +1720,7 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     a.window_q = out->window_q;
     a.passed = out->passed;
     a.n_child = nullptr;
+    a.inline_ranges = d_inline;
     a.child_parent = nullptr;
     a.child_order = nullptr;
     a.n_children = 0;
@@ -1747,7 +1783,15 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
             a.child_parent = (uint32_t *)carve(nc * 4);
             void *d_sortws = carve(sort_ws);
             a.n_children = nc;
-            FLX_CHECK(launch_fold<5>(ctx, a));
+            unsigned int overflow = 1;
+            if (d_inline) {  // the ranges MODE 3 left inline go to their places; a read with more than fit sends the batch through MODE 5
+                FLX_HIP(ctx, hipMemsetAsync(d_overflow, 0, 4, st));
+                hipLaunchKernelGGL(k_children_from_inline, dim3(nb), dim3(256), 0, st, n_reads, (const uint32_t *)d_nchild, (const uint64_t *)out->child_offsets,
+                                   (const int32_t *)d_inline, out->child_ranges, a.child_parent, d_overflow);
+                FLX_HIP(ctx, hipMemcpyAsync(&overflow, d_overflow, 4, hipMemcpyDeviceToHost, st));
+                FLX_HIP(ctx, hipStreamSynchronize(st));
+            }
+            if (overflow) FLX_CHECK(launch_fold<5>(ctx, a));
             flx_time_end(ctx);  // (the sort times its own passes)
             hipLaunchKernelGGL(k_child_keys, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, nc, out->child_ranges, keys0, vals0);
             uint64_t *skeys = nullptr;
