@@ -1278,6 +1278,14 @@ __global__ void __launch_bounds__(256) FLX_FOLD_OCC k_kmer_fold(const FoldArgs a
           }
       }
       if (MODE == 5) continue;
+      if ((MODE == 0 || MODE == 3 || MODE == 6) && j0 + 32 <= ws - 1 && j0 + 32 <= Lmin) {
+          // ---- the head, a word at a time: every position of the word lies in front of the first full window (j < ws - 1) and inside
+          // every read of the wave — the recurrence has not begun, only the covered bases are counted (src/read.cpp:221-225).  (The
+          // per-bit loop below spent ~20 instructions on each of these positions: a fifth of a 10 kbp read's fold once the steady state
+          // ran on the integer grid.)
+          P.cnt += __popc(lead_w);
+          continue;
+      }
       if ((MODE == 0 || MODE == 3 || MODE == 6) && j0 >= ws && j0 + 32 <= Lmin) {
           // ---- steady state, one window per lane: 32 positions, every lane active, no per-bit control flow ----
           uint32_t tw;
