@@ -414,9 +414,9 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
                 "model_ms": round((req["l2_hits"] / L2_LOOKUP_PEAK_G + req["far_requests"] / RANDOM_REQ_PEAK_G) / 1e6, 2),
                 "note": "model_ms = l2_lines / 261 G/s + far_requests / 55 G/s, the floor its two request classes set (the HBM-streaming "
                         "fraction above is small because the kernel asks, it does not stream).  Since the text, U13 and S1 cut the "
-                        "requests the kernel runs ABOVE that floor, on its vector instructions: 0.72 per position, the SIMDs issue "
-                        "one in >= 94 % of their cycles at the 2.4 GHz peak clock (profiles/r04_kmer_issue_mix_c3.txt: PMC passes at "
-                        "1e6 reads, not this run)"}},
+                        "requests the kernel runs ABOVE that floor, on its vector instructions (SQ_INSTS_VALU per position: "
+                        "profiles/r05_kmer_s_c3.txt, a PMC pass of this command, not this run; round 4: 0.72)"}},
+        "folds_on_integer_grid": bool(ctx.last_kmer_fold_grid()),
         "cut": {"target_bases": int(rep.target_bases), "kept_bases": int(rep.kept_bases), "outcome": int(rep.outcome)},
     }
     ks.close()
