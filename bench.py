@@ -241,13 +241,14 @@ def end_to_end_cli_kmer(n_reads):
 
 
 def _timed_child(argv, stdout_path, env):
-    """one command: wall clock, exit code and the child's own peak resident set (wait4)"""
-    t = time.perf_counter()
+    """one command: wall clock, exit code and the command's own peak resident set.  Through tools/timed.py, a fresh small interpreter
+    that does the wait4: a child forked from THIS process would carry the pages of its 3 GB (torch) in its ru_maxrss until it execs."""
+    rep = stdout_path + ".time"
     with open(stdout_path, "wb") as fo:
-        p = subprocess.Popen(argv, stdout=fo, stderr=subprocess.DEVNULL, env=env)
-        _, status, ru = os.wait4(p.pid, 0)
-        p.returncode = os.waitstatus_to_exitcode(status) if hasattr(os, "waitstatus_to_exitcode") else (status >> 8)
-    return time.perf_counter() - t, p.returncode, ru.ru_maxrss // 1024
+        rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "timed.py"), rep] + list(argv), stdout=fo, stderr=subprocess.DEVNULL,
+                            env=env).returncode
+    t = open(rep).read().split()  # "<seconds> s wall, <KiB> KiB peak RSS"
+    return float(t[0]), rc, int(t[3]) // 1024
 
 
 def end_to_end_cli_kmer_short(n_reads, n_pairs):
