@@ -95,7 +95,7 @@ static int check_cli_environment() {
         "FLX_CLI_BLOCK_BYTES", "FLX_CLI_BLOCK_MB", "FLX_CLI_CHUNK_BYTES", "FLX_CLI_CHUNK_MB", "FLX_CLI_CLEAN_EXIT", "FLX_CLI_FORCE_STREAM",
         "FLX_CLI_FAIL_WRITE_RANK", "FLX_CLI_INFLATE_THREADS", "FLX_CLI_NO_STREAM", "FLX_CLI_ORDERED_OUTPUT", "FLX_CLI_PARALLEL_PARSE_MIN", "FLX_CLI_PARSE_ONLY",
         "FLX_CLI_PINFLATE", "FLX_CLI_PINFLATE_AHEAD_MB", "FLX_CLI_PINFLATE_CHUNK", "FLX_CLI_PINFLATE_MIN", "FLX_CLI_PINFLATE_TIMING",
-        "FLX_CLI_RANK_RANGES", "FLX_CLI_REF_BATCH_BYTES", "FLX_CLI_SPAN_BYTES", "FLX_CLI_THREADS", "FLX_CLI_TIMING",
+        "FLX_CLI_RANK_RANGES", "FLX_CLI_RANK_STREAM", "FLX_CLI_REF_BATCH_BYTES", "FLX_CLI_SPAN_BYTES", "FLX_CLI_THREADS", "FLX_CLI_TIMING",
     };
     for (char **e = environ; e && *e; ++e) {
         if (strncmp(*e, "FLX_CLI_", 8) != 0) continue;
@@ -229,10 +229,36 @@ int main(int argc, char **argv) {
         const bool regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0;
         const bool gz = regular && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
         ::close(fd);
-        streamed = regular && world == 1 && !getenv("FLX_CLI_NO_STREAM") && (gz || getenv("FLX_CLI_FORCE_STREAM"));
+        // Several ranks (round 5): a gzip input is streamed by every rank as well — rank 0 counts the records in a pass of its own, the
+        // count fixes every rank's contiguous share, then every rank streams the file, runs the checks of src/main.cpp:84-117 over
+        // ALL records (they are per-record facts: every rank finds the same error at the same record) and packs and scores only its
+        // share.  Up to round 4 every rank inflated the whole file into its memory.  (--verbose keeps that path: on an error it
+        // scores the reads in front of it, all of them on rank 0.  FLX_CLI_RANK_STREAM=0: the old way.)
+        const char *rs_env = getenv("FLX_CLI_RANK_STREAM");
+        const bool rank_stream = !args.verbose && !(rs_env && rs_env[0] == '0');
+        streamed = regular && (world == 1 || rank_stream) && !getenv("FLX_CLI_NO_STREAM") && (gz || getenv("FLX_CLI_FORCE_STREAM"));
     }
     if (streamed ? !blocks.open(args.input_reads, true) : !data.open(args.input_reads)) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
     stage("read input file");
+    uint64_t share_lo = 0, share_n = UINT64_MAX;  // streamed input, several ranks: this rank's records [share_lo, share_lo + share_n) of file order
+    if (streamed && world > 1) {
+        uint64_t n_all[1] = {0};
+        if (rank == 0) {  // (a damaged stream counts the records in front of the damage: every rank ends there in its own pass)
+            BlockReader counter;
+            Parsed b;
+            if (counter.open(args.input_reads, false))
+                while (counter.next(b)) {
+                    n_all[0] += b.recs.size();
+                    if (b.status <= -2) break;
+                }
+        }
+        if (!ctx_ready()) return 1;
+        if (flx_comm_sum_u64(ctx, n_all, 1) != FLX_OK) return fail_flx(ctx, "exchange");
+        share_lo = n_all[0] / (uint64_t)world * (uint64_t)rank + std::min<uint64_t>((uint64_t)rank, n_all[0] % (uint64_t)world);
+        share_n = n_all[0] / (uint64_t)world + ((uint64_t)rank < n_all[0] % (uint64_t)world ? 1 : 0);
+        stage("count pass (rank 0)");
+    }
+    auto in_share = [&](uint64_t rec) { return rec >= share_lo && rec - share_lo < share_n; };
 
     flx_params prm;
     memset(&prm, 0, sizeof prm);
@@ -579,13 +605,13 @@ int main(int argc, char **argv) {
                 name = name_arena.back();
             }
             if (streamed ? !seen_names.insert(name).second : (uint64_t)(&r - recs.data()) == dup_at) {
-                if (streamed) names.push_back(name);  // the duplicate itself is scored and printed before the check (main.cpp:108-113)
+                if (streamed && in_share(n_records)) names.push_back(name);  // the duplicate itself is scored and printed before the check (main.cpp:108-113)
                 verbose_before_error(recs, (uint64_t)(&r - recs.data()) + 1, streamed);
                 std::cerr << "Error: duplicate read name: " << r.name << "\n";
                 return input_error_rc;
             }
             if (streamed) {
-                names.push_back(name);
+                if (in_share(n_records)) names.push_back(name);
                 units.note_record(blocks.points, blocks.offset_of(r.name.p - 1), n_records);
             }
             if (r.is_fastq) {
@@ -619,6 +645,13 @@ int main(int argc, char **argv) {
         if (!streamed) stage("record checks");
         // this rank's share of the batch: everything when streaming (one rank), else a contiguous block of file order by count
         uint64_t lo = 0, cnt = recs.size();
+        if (streamed && world > 1) {  // the part of this block that lies in the rank's share (n_records has moved behind the block)
+            const uint64_t first = n_records - recs.size(), last = n_records;
+            const uint64_t a0 = std::max(first, share_lo), a1 = std::min(last, share_lo + share_n);
+            lo = a0 < a1 ? a0 - first : 0;
+            cnt = a0 < a1 ? a1 - a0 : 0;
+            lo_rec = share_lo;
+        }
         if (!streamed) {
             const uint64_t n_all = recs.size();
             lo = n_all / (uint64_t)world * (uint64_t)rank + std::min<uint64_t>((uint64_t)rank, n_all % (uint64_t)world);
@@ -993,6 +1026,7 @@ int main(int argc, char **argv) {
         // Second pass over the compressed input (src/main.cpp:263-313 re-reads the file too), but not front to back on one
         // thread: pass 1 left access points in the deflate stream, the pieces between them (whole records, ~32 MiB of text)
         // are inflated and parsed concurrently and written in order.  Pieces without a passing read are not inflated at all.
+        if (world > 1 && !open_part()) return 1;  // (several ranks: every rank's records to its part file, rank 0 streams the parts out in order below)
         const size_t n_units = units.units();
         std::vector<uint64_t> r2_at(n_units + 1, n2);  // first reads2 entry of every unit (reads2 is in record order)
         {
@@ -1018,12 +1052,14 @@ int main(int argc, char **argv) {
             for (size_t k = 0; k < got.recs.size(); ++k) {
                 const uint64_t rec = units.first_rec[j] + k;
                 const Record &r = got.recs[k];
-                if (r.name.sv() != names[rec] || (int32_t)r.seq.size() != lengths[rec]) return false;
+                if (rec < lo_rec || rec - lo_rec >= n) continue;  // (several ranks: a unit at the edge of the share holds other ranks' records too)
+                if (r.name.sv() != names[rec - lo_rec] || (int32_t)r.seq.size() != lengths[rec - lo_rec]) return false;
                 for (; cur < r2_at[j + 1] && reads2[cur].rec == rec; ++cur) emit(buf, cur, r);
             }
             return true;
         }, sink, nullptr);
-        if (!ok) { std::cerr << "Error: " << args.input_reads << " could not be read a second time (did it change?)\n"; return 1; }
+        if (!ok && world == 1) { std::cerr << "Error: " << args.input_reads << " could not be read a second time (did it change?)\n"; return 1; }
+        pieces_ok = ok;  // (several ranks: to the exchange below, like a failed write)
     }
     // a sink that did not take everything (disk full, the reader of a pipe gone while SIGPIPE is ignored) ends the job with status 1
     const bool sink_ok = pieces_ok && fflush(sink) == 0 && !ferror(sink);

@@ -429,3 +429,48 @@ def test_cli_rank_that_cannot_write_its_share(tmp_path):
             assert res.stderr.count(b"Error: could not write the output") == 1, (failing, sink, res.stderr[-300:])
             assert b"ended early" not in res.stderr
             assert list(tmp.iterdir()) == []
+
+
+@pytest.mark.parametrize("gpus", ["2", "3", "8"])
+def test_cli_gzip_input_streamed_by_every_rank(tmp_path, gpus):
+    """Round 5: with several ranks a gzip input is no longer inflated whole into every rank's memory — rank 0 counts the records, every
+    rank streams the file block by block, checks every record and scores only its share (cli/main.cpp).  Same stdout and stderr as one
+    rank, with whole blocks and with blocks of a few records (shares that begin and end inside blocks and access-point units), Phred
+    and k-mer mode with children, more ranks than records, and an input whose last record is cut off."""
+    import gzip
+    shim_dir = os.path.join(ROOT, "tests", "shim")
+    subprocess.check_call(["make", "-s", "-C", shim_dir])
+    base = dict(os.environ, LANG="C", LC_ALL="C", FLX_RCCL_LIB=os.path.join(shim_dir, "libloopback_rccl.so"), FLX_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        base.pop(k, None)
+    c1 = _cases.c1_fastq_bytes()[:3_000_000].rsplit(b"\n@", 1)[0] + b"\n"
+    few = b"".join(c1.split(b"\n")[i] + b"\n" for i in range(8))  # two records
+    cut = c1[:200_000]  # ends inside a record
+    files = {}
+    for name, data in (("c1", c1), ("few", few), ("cut", cut)):
+        p = tmp_path / (name + ".fastq.gz")
+        with gzip.open(p, "wb", compresslevel=4) as g:
+            g.write(data)
+        files[name] = str(p)
+    inp = _e2e_checks.Inputs()
+    fa = tmp_path / "ref.fasta"
+    fa.write_bytes(_cases.fasta_bytes(inp.contigs))
+    kin = tmp_path / "kmer.fastq.gz"
+    with gzip.open(kin, "wb") as g:
+        g.write(_cases.long_fastq_bytes(inp.kreads))
+    runs = [(["--target_bases", "700000", files["c1"]], 0), (["--min_length", "100", "--keep_percent", "50", files["few"]], 0),
+            (["--target_bases", "50000", files["cut"]], 1), (["-a", str(fa), "--trim", "--split", "100", "--keep_percent", "80", str(kin)], 0)]
+    for argv, want_rc in runs:
+        one = subprocess.run([BIN] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=base)
+        assert one.returncode == want_rc, one.stderr[-300:]
+        for blocks in ({}, {"FLX_CLI_BLOCK_BYTES": "40000", "FLX_CLI_SPAN_BYTES": "15000", "FLX_CLI_PINFLATE_MIN": "1", "FLX_CLI_PINFLATE_CHUNK": "9000"}):
+            env = dict(base, FLX_CLI_TIMING="1", **blocks)
+            res = subprocess.run([BIN, "--gpus", gpus] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+            assert res.returncode == want_rc, (argv, blocks, res.stderr[-400:])
+            assert b"count pass (rank 0)" in res.stderr, (argv, blocks)  # the streamed path was taken
+            shown = b"\n".join(l for l in res.stderr.replace(b"\r", b"\n").split(b"\n") if not l.startswith(b"[timing]") and b"[timing]" not in l)
+            ref = b"\n".join(l for l in one.stderr.replace(b"\r", b"\n").split(b"\n"))
+            assert res.stdout == one.stdout, (argv, blocks)
+            assert [l for l in shown.split(b"\n") if l.strip()] == [l for l in ref.split(b"\n") if l.strip()], (argv, blocks, res.stderr[-400:])
+            old = subprocess.run([BIN, "--gpus", gpus] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(base, FLX_CLI_RANK_STREAM="0", **blocks), timeout=300)
+            assert old.returncode == want_rc and old.stdout == one.stdout and old.stderr == one.stderr, (argv, blocks, "in memory")
