@@ -464,7 +464,7 @@ def test_cli_gzip_input_streamed_by_every_rank(tmp_path, gpus):
         one = subprocess.run([BIN] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=base)
         assert one.returncode == want_rc, one.stderr[-300:]
         for blocks in ({}, {"FLX_CLI_BLOCK_BYTES": "40000", "FLX_CLI_SPAN_BYTES": "15000", "FLX_CLI_PINFLATE_MIN": "1", "FLX_CLI_PINFLATE_CHUNK": "9000"}):
-            env = dict(base, FLX_CLI_TIMING="1", **blocks)
+            env = dict(base, FLX_CLI_TIMING="1", FLX_CLI_RANK_STREAM="1", **blocks)  # (=1: also below the size from which it is the default)
             res = subprocess.run([BIN, "--gpus", gpus] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
             assert res.returncode == want_rc, (argv, blocks, res.stderr[-400:])
             assert b"count pass (rank 0)" in res.stderr, (argv, blocks)  # the streamed path was taken
