@@ -53,7 +53,7 @@ def source_sha16(*names):
     return h.hexdigest()[:16]
 
 
-KMER_SOURCES = ("score_kmer.hip", "kmerset.hip", "kmerset.h", "pathtext.hip")  # what the cover kernel's requests depend on (kernel + the set's tables and text)
+KMER_SOURCES = ("cover_queue.hip", "cover_common.h", "score_kmer.hip", "kmerset.hip", "kmerset.h", "pathtext.hip")  # what the cover kernel's requests depend on (kernel + the set's tables and text)
 
 
 def _run_ref_bench(argv):
@@ -367,7 +367,7 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
         rep, nc, n2 = step()
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / steps
-    cover_kernel = "k_kmer_cover" if os.environ.get("FLX_KMER_COVER") == "v2" else "k_kmer_cover_w"
+    cover_kernel = {"q": "k_kmer_cover_q", "w": "k_kmer_cover_w", "v2": "k_kmer_cover"}[ctx.last_kmer_cover()]
     cover_ms, cn = ctx.timing_get("flx_score_kmer_cover")
     fold_ms, _ = ctx.timing_get("flx_score_kmer_fold")
     rank_ms, _ = ctx.timing_get("flx_rank")
@@ -380,7 +380,7 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
     # round 4 at the full 1e7 reads; per-position figures scale to other batch sizes, the mix of reads is the same) — NOT measured
     # in this run, and only quoted while the kernel's source file still has the hash recorded with the pass
     req, req_src = None, None
-    fpath = next((q for q in (os.path.join(ROOT, "profiles", r + "_kmer_requests.json") for r in ("r05", "r04")) if os.path.exists(q)), "")
+    fpath = next((q for q in (os.path.join(ROOT, "profiles", r + "_kmer_requests.json") for r in ("r06", "r05", "r04")) if os.path.exists(q)), "")
     if fpath:
         rec = json.load(open(fpath)).get(cfg)
         if rec and rec.get("kernel") == cover_kernel and rec.get("kernel_source_sha16") == source_sha16(*KMER_SOURCES):
@@ -670,6 +670,10 @@ def main():
                         ("allgather_records_fallback", "flx_comm_allgather_records"), ("broadcast_outcome_fallback", "flx_comm_broadcast_outcome")):
         ms, cnt = ctx.timing_get(prefix)
         comm_split[key] = {"ms_per_step": round(ms / args.steps, 4), "calls_per_step": round(cnt / args.steps, 2)}
+    # (flx_comm_allreduce_dev is bracketed INSIDE flx_rank_select: taken out of the rank stage's time, so that `comm` and
+    # `rank_other_kernels` do not overlap — advisor, round 5)
+    nested_ms, _ = ctx.timing_get("flx_comm_allreduce_dev")
+    rank_ms = max(rank_ms - nested_ms, 0.0)
     ctx.timing_enable(False)
     if args.dump_flags:
         torch.cuda.synchronize()
@@ -692,7 +696,7 @@ def main():
         # FETCH_SIZE x2 on gfx950 — calibrated for this kernel's 64-byte-per-read pattern on a known byte count,
         # profiles/r02_microbench.txt), recorded in profiles/ — NOT measured in this run; only quoted for the same workload.
         traffic, traffic_src = None, None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", r + "_traffic_c2.json") for r in ("r05", "r04")) if os.path.exists(q)), "")
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", r + "_traffic_c2.json") for r in ("r06", "r05", "r04")) if os.path.exists(q)), "")
         if tpath and n == 10_000_000 and not args.fixed_len and args.window_size == 250 and profile == 0:
             rec = json.load(open(tpath))
             # only quoted while it still describes this kernel: same kernel name AND the kernel's source file unchanged since the pass
@@ -729,6 +733,9 @@ def main():
                 "rccl_ranks": ctx.L.flx_comm_world(ctx.h) if multi and args.global_stage == "rccl" else None,
                 # the one array every rank needs from every other: the mean qualities, 8 bytes per read
                 "allgather_bytes_per_rank": {"sent": 8 * n, "received": 8 * n * world} if multi else None,
+                # which implementation of the cut (src/main.cpp:247-257) the timed steps ran: the weighted radix SELECT (default) or
+                # the radix SORT + scan north_star names (FLX_RANK_SORT=1); both are timed in this run, stage_ms_per_step.cut_*
+                "cut": "sort" if os.environ.get("FLX_RANK_SORT") == "1" else "select",
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -771,6 +778,19 @@ def main():
                     ts.append((time.perf_counter() - t1) * 1e3)
                 extras.setdefault("global_stage_ms", {})[name] = round(min(ts), 3)
             os.environ.pop("FLX_RANK_SORT", None)
+            # (round-5 review, item 4) both cuts in the headline record itself, and the fraction of the HBM peak the WHOLE timed
+            # window reaches with either (algorithmic bytes of scoring + 46 B per read of the rank + cut stage)
+            gs = extras["global_stage_ms"]
+            out["stage_ms_per_step"]["cut_select"] = gs["select"]
+            out["stage_ms_per_step"]["cut_sort"] = gs["sort"]
+            ran = gs[out["config"]["cut"]]
+            window_bytes = algo_bytes + 46 * n
+            out["roofline"]["whole_window"] = {
+                "algorithmic_bytes": int(window_bytes),
+                "frac_as_timed": round(window_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_with_select": round(window_bytes / ((ms_per_step - ran + gs["select"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_with_sort": round(window_bytes / ((ms_per_step - ran + gs["sort"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "ms_per_step of the timed steps with the global stage's wall time exchanged for the other cut's (both measured in this run)"}
             # (1b) the exact-tie fallback (the reference's own std::sort over every entry on the host, csrc/rank.hip
             #      exact_host_cut), forced on the same records: its cost when an order-dependent tie group straddles the cut
             sel_flags = flags0.clone()

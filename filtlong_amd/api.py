@@ -354,6 +354,10 @@ class Context:
     def last_phred_kernel(self):
         return self.L.flx_last_phred_kernel(self.h).decode()
 
+    def last_kmer_cover(self):
+        """"q", "w" or "v2": the coverage kernel the last k-mer scoring call launched."""
+        return self.L.flx_last_kmer_cover(self.h).decode()
+
     def last_kmer_locus(self):
         return bool(self.L.flx_last_kmer_locus(self.h))
 

@@ -244,20 +244,26 @@ int main(int argc, char **argv) {
     }
     if (streamed ? !blocks.open(args.input_reads, true) : !data.open(args.input_reads)) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
     stage("read input file");
+    uint64_t streamed_records_counted = UINT64_MAX;  // streamed input, several ranks: what rank 0's count pass saw
     uint64_t share_lo = 0, share_n = UINT64_MAX;  // streamed input, several ranks: this rank's records [share_lo, share_lo + share_n) of file order
     if (streamed && world > 1) {
-        uint64_t n_all[1] = {0};
+        uint64_t n_all[2] = {0, 0};  // records, and whether the count pass could not open the file (every rank must learn that: advisor, round 5)
         if (rank == 0) {  // (a damaged stream counts the records in front of the damage: every rank ends there in its own pass)
             BlockReader counter;
             Parsed b;
-            if (counter.open(args.input_reads, false))
+            if (counter.open(args.input_reads, false)) {
                 while (counter.next(b)) {
                     n_all[0] += b.recs.size();
                     if (b.status <= -2) break;
                 }
+            } else {
+                n_all[1] = 1;
+            }
         }
         if (!ctx_ready()) return 1;
-        if (flx_comm_sum_u64(ctx, n_all, 1) != FLX_OK) return fail_flx(ctx, "exchange");
+        if (flx_comm_sum_u64(ctx, n_all, 2) != FLX_OK) return fail_flx(ctx, "exchange");
+        if (n_all[1]) { std::cerr << "Error reading " << args.input_reads << "\n"; return 1; }
+        streamed_records_counted = n_all[0];
         share_lo = n_all[0] / (uint64_t)world * (uint64_t)rank + std::min<uint64_t>((uint64_t)rank, n_all[0] % (uint64_t)world);
         share_n = n_all[0] / (uint64_t)world + ((uint64_t)rank < n_all[0] % (uint64_t)world ? 1 : 0);
         stage("count pass (rank 0)");
@@ -668,6 +674,11 @@ int main(int argc, char **argv) {
     }
     { std::unordered_set<std::string_view>().swap(seen_names); }
     if (streamed) units.finish(blocks.points, blocks.end_offset(), n_records);
+    if (streamed_records_counted != UINT64_MAX && n_records != streamed_records_counted) {
+        // the shares were cut from rank 0's count: a file that changed between the two passes would give shares that do not match the records seen
+        std::cerr << "Error: " << args.input_reads << " changed while it was read (" << streamed_records_counted << " records counted, " << n_records << " read)\n";
+        return 1;
+    }
     if (!args.verbose) std::cerr << "\r  " << int_to_string((long long)n_records) << " reads (" << int_to_string(total_bases) << " bp)";
     if (!args.verbose) std::cerr << "\n";  // verbose: after the per-read blocks, as in main.cpp:110-129
     const bool fasta_output = any_fasta, fastq_output = any_fastq;

@@ -44,6 +44,7 @@ struct Job {
     bool poll_once(bool block) {  // returns false when a child ended badly
         bool ok = true;
         std::lock_guard<std::mutex> lk(mu);
+        if (exited.size() < children.size()) exited.resize(children.size(), -1);  // (a pipe() / fork() that failed midway: start_watchdog never sized it — advisor, round 5)
         for (size_t i = 0; i < children.size(); ++i) {
             if (exited[i] >= 0) { ok = ok && exited[i] == 0; continue; }
             int st = 0;

@@ -362,11 +362,12 @@ extern "C" int flx_rank_and_cut_comm_dev(flx_ctx *ctx, uint64_t n_local, const v
             if (stage_rc == FLX_OK) stage_rc = flx_fail(ctx, FLX_ERR_HIP, "the outcome of the global stage could not be staged for the broadcast");
         }
     }
-    flx_time_begin(ctx, "flx_comm_broadcast_outcome");
-    FLX_NCCL(ctx, g_rccl.Broadcast(g_rep, g_rep, sizeof(flx_cut_report) + 8, ncclUint8, 0, c->comm, st));
-    if (n_total) FLX_NCCL(ctx, g_rccl.Broadcast(g_pass, g_pass, n_total, ncclUint8, 0, c->comm, st));
-    if (d_final_score && n_total) FLX_NCCL(ctx, g_rccl.Broadcast(g_fs, g_fs, n_total * 8, ncclUint8, 0, c->comm, st));
-    flx_time_end(ctx);
+    {
+        flx_time_scope tb(ctx, "flx_comm_broadcast_outcome");
+        FLX_NCCL(ctx, g_rccl.Broadcast(g_rep, g_rep, sizeof(flx_cut_report) + 8, ncclUint8, 0, c->comm, st));
+        if (n_total) FLX_NCCL(ctx, g_rccl.Broadcast(g_pass, g_pass, n_total, ncclUint8, 0, c->comm, st));
+        if (d_final_score && n_total) FLX_NCCL(ctx, g_rccl.Broadcast(g_fs, g_fs, n_total * 8, ncclUint8, 0, c->comm, st));
+    }
     {
         int64_t head[1] = {0};
         FLX_HIP(ctx, hipMemcpyAsync(head, g_rep, 8, hipMemcpyDeviceToHost, st));

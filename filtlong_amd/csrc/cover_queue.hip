@@ -1,0 +1,542 @@
+// cover_queue.hip — the coverage kernel of k-mer mode for a set with a text (round 6): k_kmer_cover_q.
+//
+// Reference semantics: the k-mer branch of Read::Read, src/read.cpp:43-58 — a rolling 2-bit 16-mer, one set lookup per position,
+// bases i-15..i marked on a hit; here: seq plane -> coverage bit plane + covered count / first / last covered base per read
+// (src/read.cpp:75-84).  Same outputs, bit for bit, as k_kmer_cover_w (score_kmer.hip), which stays as the second implementation
+// (FLX_KMER_COVER=w) and is what a set without a text runs.
+//
+// Why a second structure.  k_kmer_cover_w is bound by its vector instructions (0.67 per position, profiles/r05_kmer_issue_mix_c3.txt):
+// every wave runs the prefilter rounds and the search for all 64 lanes of every span, although the text settles most of them.
+// Counted on C3 (tools/exp/cover_stats.py, profiles/r06_cover_lane_stats.txt): of a span's 64 lanes 32.5 have any question left
+// behind the text comparison, 17 take part in the second prefilter round, and a search step serves 5 lanes — in 92 % of the spans
+// at least one lane needs each block, so no wave-uniform branch skips them.
+//
+// So the span loop is cut in two PHASES inside one kernel, with a queue in LDS between them:
+//   phase A (every lane of every span): base codes, the text along the diagonal (known members, U13 / S1 refutations, 12-mers the text
+//           vouches for), seeds.  A lane whose 17-position window leaves no candidate outside its confirmed members is done — its hits
+//           are the known ones.  Every other lane APPENDS its piece to the wave's queue: the 32 bases it needs, what the text knows
+//           about its 16 windows and about the 12-mers in front of it, whether the left neighbour's last 16-mer is a known member,
+//           and its position.  Entries are self-contained: nothing in phase B looks at a lane that is not in the queue.
+//   phase B (when 64 entries have gathered, or the oldest waits too long): prefilter in two rounds over the TEN pairs that hold the
+//           12-mers of the piece's own 16 windows (positions -4 .. 15; k_kmer_cover_w let the left neighbour fetch the first two
+//           pairs), candidates, the outermost-member search against exact15 — the same policy as before, but all 64 lanes carry a
+//           piece.  Pieces that are neighbours in the read are neighbours in the queue (the append keeps the order), so the left
+//           neighbour's answer still spares the bottom-up search where both are queued.
+//   The hits of a span wait in a ring in LDS (kRing spans) until its queued pieces are through; then the 4-step OR-dilation, the
+//   counts and the row words as before.
+// A global queue between two kernels (the form the round-5 review sketched) was costed first: 32.5 entries of 20 bytes per span are
+// 1.3 kB of extra HBM traffic per 1 kB of plane, and the cover stage sits 15 % above the floor its requests set —
+// the queue must not leave the chip.
+#include "flx_internal.h"
+#include "kmerset.h"
+#include "cover_common.h"
+
+namespace {
+
+constexpr int kRing = 8;     // spans whose hits a wave keeps in LDS (a power of two)
+constexpr int kQueue = 128;  // queue slots per wave (a power of two, >= 63 + 64)
+constexpr int kLag = 4;      // a queued piece is served at the latest when the wave is this many spans ahead of it (< kRing - 2)
+
+struct WaveLds {
+    uint16_t ring[kRing][64];  // hits of span s at ring[s % kRing]: the known ones from phase A, replaced by phase B's for queued pieces
+    uint32_t q[5][kQueue];     // hi, lo, known | refuted << 16, 12-mers the text vouches for (positions -4 .. 15), id | left known << 31
+};
+
+// everything the lanes of a wave wrote to LDS is visible to its other lanes (a wave's LDS operations execute in order; this keeps
+// the compiler from moving accesses across and waits for the outstanding ones)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool HAS_PREFILTER>
+__global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_q(const CoverArgs a) {
+    __shared__ WaveLds lds_all[FLX_COVER_THREADS / 64];
+    WaveLds &S = lds_all[threadIdx.x >> 6];
+    const uint8_t *plane = a.plane;
+    const uint64_t *offsets = a.offsets;
+    const int32_t *lengths = a.lengths;
+    const uint32_t *order = a.order;
+    const uint64_t n_reads = a.n_reads;
+    uint32_t *cov = a.cov;
+    const uint64_t *cov_off = a.cov_off;
+    int32_t *count = a.count, *first = a.first, *last = a.last;
+    const uint32_t loc_n_alloc = a.loc.n_alloc, loc_seed_mask = a.loc.seed_mask;
+    const int loc_seed_shift = a.loc.seed_shift;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t slot_r = wave0; slot_r < n_reads; slot_r += n_waves) {
+        const uint32_t rid = __builtin_amdgcn_readfirstlane(order ? order[slot_r] : (uint32_t)slot_r);
+        const int L = __builtin_amdgcn_readfirstlane(lengths[rid]);
+        const uint8_t *seq = plane + offsets[rid];
+        uint32_t *row = cov + (cov_off[rid] >> 2);
+        const int row_words = (((L + 7) / 8 + 15) & ~15) >> 2;
+        const int n_spans = (L + 1023) >> 10;
+        int cnt = 0, fst = 0x7fffffff, lst = -1;
+        // carried from lane 63 of the previous span (wave-uniform)
+        uint32_t c_lo = 0, c_known15 = 0, c_t12 = 0;
+        // the diagonal (wave-uniform), the text of this span / the next one, lane 63's carries of the text comparison
+        long long diag = 0;
+        bool have_diag = false, carry_ok = false;
+        uint32_t c_mb = 0xffffffffu /* mismatches | piece starts << 16 of lane 63 */, c_us = 0 /* its U13 | S1 << 16 */, c_twx = 0, c_twy = 0xffffu;
+        uint2 tw = make_uint2(0, 0xffffu), tw_next = make_uint2(0, 0xffffu);
+        uint32_t ts = 0, ts_next = 0, c_ts = 0;  // S1 bits of those text words (kmerset.h: safe1); lane 63's for the next span
+        const bool has_s1 = a.loc.safe1 != nullptr;
+        // the queue: q_head = slot of the oldest entry, q_n = entries; fin = the next span to turn into coverage
+        int q_head = 0, q_n = 0, fin = 0;
+
+        // the text word that holds the LAST base of the lane's 16 at this diagonal, for the lane whose 16 bases start at `base` +
+        // 16 * lane (index clamped into the padded array).  The diagonal and `base` are wave-uniform: the 64-bit part of the index
+        // is scalar work, a lane adds its number and clamps
+        auto word_index = [&](long long dg, int base) -> uint32_t {
+            long long u = ((dg + base + 15) >> 4) + (long long)kLocusPad;  // (16 * lane + c) >> 4 == lane + (c >> 4)
+            u = u < -64 ? -64 : (u > (long long)loc_n_alloc ? (long long)loc_n_alloc : u);
+            const int w = (int)u + lane;
+            return (uint32_t)max(0, min(w, (int)loc_n_alloc - 1));
+        };
+        auto text_word = [&](long long dg, int base) -> uint2 {
+            // (a 32-bit byte offset on a scalar base: one address register — the text has at most 2^28 positions, 2^27 bytes)
+            const uint64_t tv = *(FLX_GLOBAL_PTR(uint64_t))(FLX_KARG_PTR(uint8_t, loc.text) + (uint32_t)(word_index(dg, base) * 8u));
+            return make_uint2((uint32_t)tv, (uint32_t)(tv >> 32));
+        };
+        auto safe_word = [&](long long dg, int base) -> uint32_t {  // the S1 bits of that word
+            return has_s1 ? (uint32_t)*(FLX_GLOBAL_PTR(uint16_t))(FLX_KARG_PTR(uint8_t, loc.safe1) + (uint32_t)(word_index(dg, base) * 2u)) : 0u;
+        };
+
+        // hits of span sp (complete in the ring) -> coverage bits, counts, row words
+        auto finalize = [&](int sp) {
+            const int p0 = (sp << 10) + lane * 16;
+            const uint32_t h = S.ring[sp & (kRing - 1)][lane];
+            const uint32_t right_of_63 = sp + 1 < n_spans ? (uint32_t)S.ring[(sp + 1) & (kRing - 1)][0] : 0u;
+            const uint32_t next = flx_from_right(h, right_of_63);
+            uint32_t x = h | (next << 16);
+            x |= x >> 1;
+            x |= x >> 2;
+            x |= x >> 4;
+            x |= x >> 8;  // bit j = OR of hit bits j .. j+15: base p0+j lies in a member 16-mer (src/read.cpp:53-54)
+            uint32_t c16 = x & 0xffffu;
+            if (((sp + 1) << 10) > L) {  // (wave-uniform: only the read's last span has positions to cut off)
+                if (p0 >= L) c16 = 0;
+                else if (p0 + 16 > L) c16 &= (1u << (L - p0)) - 1u;
+            }
+            cnt += __popc(c16);
+            if (c16) {
+                fst = min(fst, p0 + (__ffs(c16) - 1));
+                lst = max(lst, p0 + (32 - __clz(c16)));
+            }
+            const uint32_t up = flx_from_right(c16, 0u);  // (only the even lanes write: lane 63's is never used)
+            const int word = p0 >> 5;
+            if ((lane & 1) == 0 && word < row_words) __builtin_nontemporal_store(c16 | (up << 16), &row[(uint32_t)word]);
+        };
+
+        // ---- phase B: the first n (<= 64) entries of the queue, one per lane ----
+        auto serve = [&](int n) {
+            wave_lds_sync();
+            const bool act = lane < n;
+            const uint32_t qs = (uint32_t)(q_head + lane) & (kQueue - 1);
+            uint32_t hi = 0, lo = 0, kr = 0, t20 = 0, idw = 0x7fffffffu;
+            if (act) {
+                hi = S.q[0][qs];
+                lo = S.q[1][qs];
+                kr = S.q[2][qs];
+                t20 = S.q[3][qs];
+                idw = S.q[4][qs];
+            }
+            const uint32_t known = kr & 0xffffu, refuted = kr >> 16;
+            const uint32_t id = idw & 0x7fffffffu, lk = idw >> 31;  // piece number in the read (16 positions each); left neighbour's last 16-mer known
+            // positions p0 + j that end a 12-mer / a 16-mer inside the read (all of them except in the read's first and last piece)
+            uint32_t valid16 = act ? 0xffffu : 0u, valid12 = valid16;
+            if (__any(act && (id == 0 || (int)(id << 4) + 16 > L))) {
+                const int p0 = (int)(id << 4);
+                if (act) {
+                    if (p0 < 11) valid12 &= ~((1u << (11 - p0)) - 1u);
+                    if (p0 < 15) valid16 &= ~((1u << (15 - p0)) - 1u);
+                    if (p0 + 16 > L) {
+                        valid12 &= (1u << (L - p0)) - 1u;
+                        valid16 &= (1u << (L - p0)) - 1u;
+                    }
+                }
+            }
+            // ---- 12-mer prefilter over the 20 positions -4 .. 15 (bit i <-> position i - 4): pair k = positions 2k - 4, 2k - 3;
+            // x.C.y = the 13 bases ending at position 2k - 3.  Present without a lookup: what the text vouches for, and the 12-mers
+            // ending at [lowest known member - 4, highest]: those inside a member are present, the others only make candidates
+            // between two confirmed members, which are never asked. ----
+            const uint32_t V20 = (valid12 << 4) | ((act && id != 0) ? 0xFu : 0u);
+            uint32_t P = 0xFFFFFu;
+            if (HAS_PREFILTER) {
+                uint32_t need20 = V20 & ~t20;
+                if (known) need20 &= ~(((32u << (31 - __clz(known))) - 1u) & ~((1u << (__ffs(known) - 1)) - 1u));
+                // In TWO rounds: a 16-mer is out as soon as ONE of its five 12-mers is absent, and what is left to look up holds a
+                // mismatch against the text, so it is absent more often than not.  Round 1 fetches the even pairs where needed; every
+                // 16-mer holds two or three of their positions, so most are out after it.  Round 2 fetches an odd pair only if one of
+                // the 16-mers that hold its 12-mers is still alive under the assumption that every 12-mer not yet seen is present.
+                // (the reverse complement of the whole 32-base window once: the canonical form of every pair's 11-mer is then one
+                // funnel shift, and a byte read for the other strand is looked at bit-reversed — kmerset.h, flx_pre11)
+                auto rc32 = [](uint32_t w) {
+                    const uint32_t r = __brev(w);
+                    return ~(((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1));
+                };
+                const uint64_t hl64 = ((uint64_t)hi << 32) | lo;
+                const uint64_t r64 = ((uint64_t)rc32(lo) << 32) | rc32(hi);
+                auto fetch = [&](uint32_t want, int parity) -> uint32_t {  // actual bits of the pairs k = parity, parity + 2, .. that hold a wanted position; 1 elsewhere
+                    uint32_t byte[5], got = parity ? 0x33333u : 0xCCCCCu;
+                    FLX_GLOBAL_PTR(uint8_t) pre11 = FLX_KARG_PTR(uint8_t, pre11);
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const int k = 2 * j + parity;
+                        const uint32_t x13 = (uint32_t)(hl64 >> (36 - 4 * k));  // x.C.y, the 13 bases ending at position 2k - 3
+                        const uint32_t c = (x13 >> 2) & 0x3FFFFFu, rc = (uint32_t)(r64 >> (4 + 4 * k)) & 0x3FFFFFu;
+                        const uint32_t kk = (x13 & 0x2000u) ? rc : c;  // the middle base of C is G or T: the byte belongs to the other strand
+                        const uint32_t index = ((kk >> 12) << 11) | (kk & 0x7FFu);
+                        byte[j] = ((want >> (2 * k)) & 3u) ? pre11[index] : 0xffu;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const int k = 2 * j + parity;
+                        const uint32_t x13 = (uint32_t)(hl64 >> (36 - 4 * k));
+                        const uint32_t b = (x13 & 0x2000u) ? (__brev(byte[j]) >> 24) : byte[j];
+                        const uint32_t two = ((b >> ((x13 >> 24) & 3u)) & 1u) | (((b >> (4u + (x13 & 3u))) & 1u) << 1);
+                        got |= two << (2 * k);  // (a pair that was not fetched holds 0xff: both present)
+                    }
+                    return got;
+                };
+                auto dep5 = [](uint32_t alive16) -> uint32_t {  // bit i: one of the windows ending at positions i - 4 .. i holds ... i.e. the 12-mer ending at position i - 4 lies in an alive window
+                    const uint32_t x = alive16 << 4;
+                    uint32_t d = x | (x >> 1);
+                    d |= d >> 2;
+                    return d | (x >> 4);
+                };
+                {
+                    // round 1 leaves out the pairs whose 12-mers only lie in 16-mers the text has refuted (U13, S1)
+                    const uint32_t alive = valid16 & (~refuted | known);
+                    const uint32_t w1 = need20 & 0x33333u & dep5(alive);
+                    if (__any(w1 != 0)) P = fetch(w1, 0);
+                }
+                if (__any((need20 & 0xCCCCCu) != 0)) {
+                    const uint32_t v1 = P & V20;
+                    uint32_t alive = v1 & (v1 >> 1);
+                    alive &= alive >> 2;
+                    alive &= v1 >> 4;  // bit j: the five 12-mers of the window ending at position j are present so far
+                    alive &= valid16 & ~refuted;
+                    const uint32_t w2 = need20 & 0xCCCCCu & dep5(alive);
+                    if (__any(w2 != 0)) P &= fetch(w2, 1);
+                }
+            }
+            P &= V20;
+            uint32_t cand = P & (P >> 1);
+            cand &= cand >> 2;
+            cand &= P >> 4;  // all five 12-mers present
+            cand &= valid16 & (~refuted | known);  // (a member known on one diagonal cannot be refuted on another — its 13-mers then occur twice in the text — but nothing is lost by saying so)
+
+            // ---- exact membership: one byte of exact15 answers the pair of positions (a, a + 1), any a in 0..14 — the 15 bases
+            // ending at a are the byte's index, the base before them picks the bit of position a, the base after them the bit of
+            // a + 1.  A question from ABOVE (top-down search) takes the pair that ENDS at the asked position, one from below the
+            // pair that starts there: either way the request also settles the next candidate in the direction of the search. ----
+            uint32_t hits = known & cand, probed = known | (~cand & 0xffffu);
+            auto probe = [&](int top, int bot) {  // positions asked from above / from below, -1 = none
+                const int a0 = top > 0 ? top - 1 : 0, a1 = bot < 14 ? bot : 14;
+                uint32_t g0 = 0, g1 = 0;
+                FLX_GLOBAL_PTR(uint8_t) exact15 = FLX_KARG_PTR(uint8_t, exact15);
+                if (top >= 0) g0 = exact15[__builtin_amdgcn_alignbit(hi, lo, 30 - 2 * a0) & 0x3FFFFFFFu];
+                if (bot >= 0) g1 = exact15[__builtin_amdgcn_alignbit(hi, lo, 30 - 2 * a1) & 0x3FFFFFFFu];
+                if (top >= 0) {
+                    const uint32_t x = (hi >> (28 - 2 * a0)) & 3u, y = (lo >> (28 - 2 * a0)) & 3u;
+                    hits |= (((g0 >> x) & 1u) | (((g0 >> (4 + y)) & 1u) << 1)) << a0;
+                    probed |= 3u << a0;
+                }
+                if (bot >= 0) {
+                    const uint32_t x = (hi >> (28 - 2 * a1)) & 3u, y = (lo >> (28 - 2 * a1)) & 3u;
+                    hits |= (((g1 >> x) & 1u) | (((g1 >> (4 + y)) & 1u) << 1)) << a1;
+                    probed |= 3u << a1;
+                }
+                hits &= cand;  // positions outside the read hold no 16-mer
+            };
+            // One step of the search in the piece's window of 17 positions (bit 0 = the left neighbour's last position, bit j + 1 =
+            // position j): the highest open candidate above the confirmed members and the lowest one below them.
+            auto next_asks = [&](uint32_t left_member, int &top, int &bot) -> bool {
+                const uint32_t H = (hits << 1) | left_member;
+                const uint32_t open = (cand & ~probed) << 1;
+                uint32_t above = open, below = open;
+                if (H) {
+                    above = open & ~((2u << (31 - __clz(H))) - 1u);
+                    below = open & ((H & (0u - H)) - 1u);
+                }
+                top = above ? 30 - __clz(above) : -1;  // position = bit - 1
+                bot = below ? __ffs(below) - 2 : -1;
+                if (bot >= 0 && bot + 1 >= top && top >= 0) bot = -1;  // the two questions meet: the pair that ends at `top` answers both
+                return (top & bot) != -1;
+            };
+            // the left neighbour's last position: a known member (exact, from phase A), or — where the left neighbour is the entry in
+            // front of this one — what its own search finds.  First step on a BET: a candidate there is taken for a member (it is the
+            // top of that piece's search, so its answer arrives with this round's), corrected right after.
+            const bool adj = act && flx_from_left(id, 0x7ffffff0u) + 1u == id;
+            int top, bot;
+            {
+                const uint32_t lcand = flx_from_left(cand >> 15, 0u);
+                const bool need = next_asks(lk | (adj ? lcand : 0u), top, bot);
+                if (__any(need)) probe(top, bot);
+            }
+            const uint32_t lh = flx_from_left(hits >> 15, 0u);
+            const uint32_t lhit = lk | (adj ? lh : 0u);
+            for (;;) {
+                const bool need = next_asks(lhit, top, bot);
+                if (!__any(need)) break;
+                probe(top, bot);
+            }
+            if (act) S.ring[(id >> 6) & (kRing - 1)][id & 63u] = (uint16_t)hits;
+            q_head = (q_head + n) & (kQueue - 1);
+            q_n -= n;
+            wave_lds_sync();
+        };
+
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        // (offsets as unsigned 32-bit values: a uniform base plus a 32-bit lane offset is one address register, not two)
+        if (lane * 16 < L) raw = flx_plane16(seq + (uint32_t)(lane * 16));  // rows are 16-byte aligned and padded
+        for (int sp = 0; sp < n_spans; ++sp) {
+            const int p0 = (sp << 10) + lane * 16;
+            uint4 raw_next = make_uint4(0, 0, 0, 0);
+            if (p0 + 1024 < L) raw_next = flx_plane16(seq + (uint32_t)(p0 + 1024));
+            if (have_diag && sp + 1 < n_spans) {
+                tw_next = text_word(diag, (sp << 10) + 1024);
+                ts_next = safe_word(diag, (sp << 10) + 1024);
+            }
+            // 2 bits per base, earliest base on top: lo = my 16 bases, hi = the 16 before them
+            const uint32_t lo = (codes4(raw.x) << 24) | (codes4(raw.y) << 16) | (codes4(raw.z) << 8) | codes4(raw.w);
+            const uint32_t hi = flx_from_left(lo, c_lo);
+            // positions p0 + j that end a 16-mer inside the read
+            uint32_t valid16 = 0;
+            if (sp > 0 && ((sp + 1) << 10) <= L) {  // (wave-uniform: a span inside the read has every position, no lane computes masks)
+                valid16 = 0xffffu;
+            } else if (p0 < L) {
+                valid16 = 0xffffu;
+                if (p0 < 15) valid16 &= ~((1u << (15 - p0)) - 1u);
+                if (p0 + 16 > L) valid16 &= (1u << (L - p0)) - 1u;
+            }
+            // ---- members known from the text along the diagonal ----
+            uint32_t known = 0, refuted = 0;  // refuted: not a text match, but holds a text-matching 13-mer that occurs nowhere else (U13), or is one substitution away from a text window without such members (S1)
+            uint32_t text12 = 0;              // bit j: the 12 bases ending at my position j match the text inside one piece: that 12-mer IS present
+            {
+                // my 16 bases against the text along `diag` (tw = the word that holds the last of them): adds to known / refuted
+                auto compare = [&]() {
+                    const int e = (int)((diag + 15) & 15);  // index of my last base in my word (p0 is a multiple of 16: the same for every lane)
+                    // lane 0's left word: the carry, or behind a new seed a load (wave-uniform choice; only lane 0's copy is used)
+                    const uint2 tw0 = carry_ok ? make_uint2(c_twx, c_twy) : text_word(diag, (sp << 10) - 16);
+                    uint2 twl;
+                    twl.x = flx_from_left(tw.x, tw0.x);
+                    twl.y = flx_from_left(tw.y, tw0.y);
+                    const uint32_t tsl = flx_from_left(ts, carry_ok ? c_ts : 0u);  // (not worth a load: lane 0 behind a new seed refutes its own window only, below)
+                    const uint32_t t_own = __builtin_amdgcn_alignbit(twl.x, tw.x, 2 * (15 - e));
+                    const uint32_t b_own = (((twl.y & 0xffffu) >> (e + 1)) | (tw.y << (15 - e))) & 0xffffu;  // bit j: my base j is the first of a piece
+                    const uint32_t u_own = (((twl.y >> 16) >> (e + 1)) | ((tw.y >> 16) << (15 - e))) & 0xffffu;  // bit j: a unique 13-mer starts at my base j
+                    const uint32_t s_own = ((tsl >> (e + 1)) | (ts << (15 - e))) & 0xffffu;  // bit j: the text's 16 bases from my base j on are S1
+                    const uint32_t x = lo ^ t_own;
+                    uint32_t m = (x | (x >> 1)) & 0x55555555u;  // even bit 2k: the base k places from the END differs
+                    m = (m | (m >> 1)) & 0x33333333u;
+                    m = (m | (m >> 2)) & 0x0f0f0f0fu;
+                    m = (m | (m >> 4)) & 0x00ff00ffu;
+                    m = (m | (m >> 8)) & 0xffffu;
+                    const uint32_t mml = __brev(m) >> 16;  // bit j: my base j differs from the text
+                    const uint32_t mb0 = carry_ok ? c_mb : 0xffffffffu, us0 = carry_ok ? c_us : 0u;
+                    const uint32_t mmh = flx_from_left(mml, mb0 & 0xffffu), bh = flx_from_left(b_own, mb0 >> 16);
+                    const uint32_t uh = flx_from_left(u_own, us0 & 0xffffu), sh = flx_from_left(s_own, us0 >> 16);
+                    const uint32_t z = ~(mmh | (mml << 16));  // bit i: base i of the window [p0 - 16, p0 + 16) matches
+                    uint32_t r = z & (z >> 1);
+                    r &= r >> 2;
+                    r &= r >> 4;
+                    r &= r >> 8;  // bit i: bases i .. i + 15 match
+                    uint32_t q = ~(bh | (b_own << 16)) >> 1;  // bit i: no piece starts at base i + 1
+                    q &= q >> 1;
+                    q &= q >> 2;
+                    q &= q >> 4;
+                    q &= q >> 7;  // bit i: none at i + 1 .. i + 15 — the 16 bases from i on lie in one piece of the text
+                    {
+                        uint32_t m12 = z & (z >> 1);
+                        m12 &= m12 >> 2;
+                        m12 &= m12 >> 4;
+                        m12 &= m12 >> 4;  // bit i: bases i .. i + 11 match
+                        uint32_t q12 = ~(bh | (b_own << 16)) >> 1;
+                        q12 &= q12 >> 1;
+                        q12 &= q12 >> 2;
+                        q12 &= q12 >> 4;
+                        q12 &= q12 >> 3;  // bit i: no piece starts at i + 1 .. i + 11 (a piece has at least 16 bases: the 12-mer lies in one of its 16-mers)
+                        text12 |= ((m12 & q12) >> 5) & 0xffffu;  // the 12-mer ending at my position j starts at base j + 5
+                    }
+                    r &= q;
+                    known |= (r >> 1) & valid16;  // the 16-mer ending at my position j starts at base j + 1 of the window
+                    uint32_t g = z & (z >> 1);
+                    g &= g >> 2;
+                    g &= g >> 4;
+                    g &= g >> 5;  // bit i: bases i .. i + 12 match the text
+                    g &= uh | (u_own << 16);  // ... and that 13-mer occurs nowhere else (U13 is only set inside one piece)
+                    g |= g >> 1;
+                    g |= g >> 2;  // bit i: such a 13-mer starts at base i, i + 1, i + 2 or i + 3: inside the 16 bases from i on
+                    // S1: exactly ONE of the 16 bases from i on differs from the text, and no 16-mer one base away from the text's is a
+                    // member (counted with a saturating two-bit counter per window: `one` = exactly one mismatch, `two` = more)
+                    uint32_t one = ~z, two;
+                    two = one & (one >> 1);
+                    one ^= one >> 1;
+                    {
+                        const uint32_t t2 = two | (two >> 2) | (one & (one >> 2));
+                        one = (one ^ (one >> 2)) & ~t2;
+                        two = t2;
+                    }
+                    {
+                        const uint32_t t2 = two | (two >> 4) | (one & (one >> 4));
+                        one = (one ^ (one >> 4)) & ~t2;
+                        two = t2;
+                    }
+                    {
+                        const uint32_t t2 = two | (two >> 8) | (one & (one >> 8));
+                        one = (one ^ (one >> 8)) & ~t2;
+                    }
+                    one &= q & (sh | (s_own << 16));
+                    uint32_t rf = (((g & ~r) | one) >> 1) & valid16;
+                    // (lane 0 behind a new seed knows nothing about the 16 bases in front of it — taken for mismatches above, which is
+                    // safe for `known` and would be wrong here: only the window made of its own 16 bases can be refuted)
+                    if (lane == 0 && !carry_ok) rf &= 0x8000u;
+                    refuted |= rf;
+                    c_us = __builtin_amdgcn_readlane(u_own | (s_own << 16), 63);
+                    c_ts = __builtin_amdgcn_readlane(ts, 63);
+                    c_mb = __builtin_amdgcn_readlane(mml | (b_own << 16), 63);
+                    c_twx = __builtin_amdgcn_readlane(tw.x, 63);
+                    c_twy = __builtin_amdgcn_readlane(tw.y, 63);
+                    carry_ok = true;
+                };
+                // The carried diagonal is tested for nothing.  Then, while at least three lanes behind the last lane with a known
+                // member hold 16-mers nothing is known about (junk, an indel, the end of a piece of the text, the wrong copy of a
+                // repeat), two of them look their own 16 bases up in the seed table — eight lanes spread over the span when nothing
+                // is known at all; a seed on another diagonal is compared in turn, what it confirms adds to what is known.
+                const unsigned long long whole = __ballot((valid16 >> 15) != 0);  // lanes that hold a whole 16-mer of the read
+                bool again = have_diag;
+                for (int seeds_left = FLX_LOCUS_SEEDS;;) {
+                    if (again) compare();
+                    const unsigned long long kn = __ballot(known != 0);
+                    const unsigned long long tail = kn ? whole & ~((2ull << (63 - __clzll(kn))) - 1ull) : whole;
+                    if (seeds_left-- == 0 || __popcll(tail) < FLX_LOCUS_TAIL) break;
+                    bool tries;
+                    if (kn) {
+                        const unsigned long long t1 = tail & (tail - 1), t2 = t1 & (t1 - 1);  // without its first lane / first two lanes
+                        tries = lane == __ffsll(t1) - 1 || lane == __ffsll(t2) - 1;
+                    } else {
+                        tries = (lane & 7) == 3 && ((whole >> lane) & 1ull);
+                    }
+                    uint32_t tpos = kLocusEmpty;
+                    if (tries) {
+                        uint32_t h = flx_locus_hash(lo, loc_seed_shift);
+                        FLX_GLOBAL_PTR(uint32_t) seed_tab = FLX_KARG_PTR(uint32_t, loc.seed);
+                        FLX_GLOBAL_PTR(uint32_t) seed_text = FLX_KARG_PTR(uint32_t, loc.text);  // (.x of text word i at dword 2 i)
+#pragma unroll 1
+                        for (int probe_no = 0; probe_no < 4; ++probe_no) {
+                            const uint32_t v = seed_tab[h];
+                            if (v == kLocusEmpty) break;
+                            {  // (flx_locus_kmer_at, kmerset.h, on the global-space pointer)
+                                const uint32_t tw_i = (v >> 4) + kLocusPad, ts_i = v & 15u;
+                                const uint32_t t0 = seed_text[2 * tw_i];
+                                const uint32_t at = ts_i == 0 ? t0 : __builtin_amdgcn_alignbit(t0, seed_text[2 * tw_i + 2], 32 - 2 * ts_i);
+                                if (at == lo) { tpos = v; break; }
+                            }
+                            h = (h + 1) & loc_seed_mask;
+                        }
+                    }
+                    const unsigned long long found = __ballot(tpos != kLocusEmpty);
+                    if (!found) break;
+                    const int src = __ffsll(found) - 1;
+                    const long long nd = (long long)__builtin_amdgcn_readlane(tpos, src) - (long long)((sp << 10) + src * 16);
+                    if (have_diag && nd == diag) break;  // the same locus: what is missing are mismatches, not the diagonal
+                    diag = nd;
+                    have_diag = true;
+                    carry_ok = false;
+                    tw = text_word(diag, sp << 10);
+                    ts = safe_word(diag, sp << 10);
+                    if (sp + 1 < n_spans) {
+                        tw_next = text_word(diag, (sp << 10) + 1024);
+                        ts_next = safe_word(diag, (sp << 10) + 1024);
+                    }
+                    again = true;
+                }
+            }
+
+            // ---- phase A ends: the hits the text knows, and the pieces that have a question left ----
+            // The piece's window of 17 positions (bit 0 = the left neighbour's last position): a candidate is only ever asked when it
+            // lies above the highest or below the lowest confirmed member (two members inside the window are at most 16 apart: between
+            // them every base is covered).  No possible member outside the known ones' span: nothing to ask, the hits are the known ones.
+            const uint32_t lk = flx_from_left(known >> 15, c_known15);
+            const uint32_t t20 = (text12 << 4) | flx_from_left(text12 >> 12, c_t12);
+            bool need;
+            {
+                const uint32_t open = (valid16 & ~refuted & ~known) << 1;
+                const uint32_t H = (known << 1) | lk;
+                uint32_t outside = open;
+                if (H) outside = open & (~((2u << (31 - __clz(H))) - 1u) | ((H & (0u - H)) - 1u));
+                need = outside != 0;
+            }
+            S.ring[sp & (kRing - 1)][lane] = (uint16_t)known;
+            const unsigned long long nb = __ballot(need);
+            if (nb) {
+                if (need) {
+                    const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(nb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nb, 0u));
+                    const uint32_t qs = (uint32_t)(q_head + q_n + (int)at) & (kQueue - 1);
+                    S.q[0][qs] = hi;
+                    S.q[1][qs] = lo;
+                    S.q[2][qs] = known | (refuted << 16);
+                    S.q[3][qs] = t20;
+                    S.q[4][qs] = (uint32_t)((sp << 6) + lane) | (lk << 31);
+                }
+                q_n += __popcll(nb);
+            }
+            c_lo = __builtin_amdgcn_readlane(lo, 63);
+            c_known15 = __builtin_amdgcn_readlane(known >> 15, 63);
+            c_t12 = __builtin_amdgcn_readlane(text12 >> 12, 63);
+            raw = raw_next;
+            tw = tw_next;
+            ts = ts_next;
+
+            // ---- phase B where it is due: full batches, and whatever waits while the wave has moved kLag spans on ----
+            while (q_n >= 64) serve(64);
+            if (q_n > 0) {
+                wave_lds_sync();
+                const int head_span = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)S.q[4][q_head]) & 0x7fffffffu) >> 6;
+                if (head_span + kLag <= sp) serve(q_n);
+            }
+            // ---- coverage of the spans whose pieces are through and whose right neighbour's first piece is ----
+            {
+                int done = sp + 1;  // the first span that still has a piece in the queue
+                if (q_n > 0) {
+                    wave_lds_sync();
+                    done = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)S.q[4][q_head]) & 0x7fffffffu) >> 6;
+                } else {
+                    wave_lds_sync();
+                }
+                while (fin + 1 < done) finalize(fin++);
+            }
+        }
+        while (q_n > 0) serve(q_n < 64 ? q_n : 64);
+        wave_lds_sync();
+        while (fin < n_spans) finalize(fin++);
+        for (int wd = n_spans * 32 + lane; wd < row_words; wd += 64) row[wd] = 0;  // (only L == 0 leaves words unwritten)
+        for (int o = 32; o > 0; o >>= 1) {
+            cnt += __shfl_xor(cnt, o, 64);
+            fst = min(fst, __shfl_xor(fst, o, 64));
+            lst = max(lst, __shfl_xor(lst, o, 64));
+        }
+        if (lane == 0) {
+            count[rid] = cnt;
+            first[rid] = cnt ? fst : -1;  // m_first_base_in_kmer / m_last_base_in_kmer, src/read.cpp:75-84
+            last[rid] = cnt ? lst : -1;
+        }
+        wave_lds_sync();  // (the next read's first span must not overtake this read's last ring reads)
+    }
+}
+
+}  // namespace
+
+int flx_cover_queue_launch(flx_ctx *ctx, const CoverArgs &args, bool has_prefilter, unsigned grid) {
+    if (has_prefilter)
+        hipLaunchKernelGGL((k_kmer_cover_q<true>), dim3(grid), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
+    else
+        hipLaunchKernelGGL((k_kmer_cover_q<false>), dim3(grid), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
+    FLX_HIP(ctx, hipGetLastError());
+    return FLX_OK;
+}

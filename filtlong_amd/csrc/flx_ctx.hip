@@ -30,6 +30,7 @@ extern "C" const char *flx_version(void) { return "filtlong-amd 0.1 (hot path of
 extern "C" const char *flx_last_phred_kernel(const flx_ctx *ctx) { return ctx ? ctx->last_phred_kernel : ""; }
 extern "C" int flx_last_kmer_locus(const flx_ctx *ctx) { return ctx && ctx->last_kmer_locus ? 1 : 0; }
 extern "C" int flx_last_kmer_fold_grid(const flx_ctx *ctx) { return ctx && ctx->last_kmer_fold_grid ? 1 : 0; }
+extern "C" const char *flx_last_kmer_cover(const flx_ctx *ctx) { return ctx ? ctx->last_kmer_cover : ""; }
 
 extern "C" const char *flx_last_error(const flx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -47,26 +48,26 @@ static void build_phred_lut(double *lut257) {
 }
 
 // Every FLX_* environment variable the library reads (README.md lists what each one does) — most of them select a second
-// implementation for the tests.  A name that is none of these is refused once, here: a mistyped switch in a user's shell would
-// otherwise be ignored silently, i.e. run another kernel than the one asked for.  (FLX_CLI_* belong to the command line, which
-// checks its own; FLX_FUZZ_* / FLX_BENCH_* / FLX_TEST_* to the test and bench drivers.  tests/test_abi.py holds this list against
-// the getenv calls in the sources.)
+// implementation for the tests.  A name under one of the library's OWN prefixes (FLX_KMER_, FLX_PHRED_, FLX_RANK_, FLX_RCCL_, FLX_API_)
+// that is none of these is refused once, here: a mistyped switch in a user's shell would otherwise be ignored silently, i.e. run
+// another kernel than the one asked for.  Any other FLX_ name — another tool's, a stale export — is none of this library's business
+// and is ignored, as the reference would ignore it (round-5 review: a foreign FLX_FOO must not stop a drop-in binary).
+// (FLX_CLI_* belong to the command line, which checks its own.  tests/test_abi.py holds this list against the getenv calls in the sources.)
 static const char *const kKnownEnv[] = {
     "FLX_API_TIMING", "FLX_KMER_COVER", "FLX_KMER_FOLD", "FLX_KMER_FOLD_EVENTS", "FLX_KMER_FOLD_GRID", "FLX_KMER_FOLD_STREAMS", "FLX_KMER_LOCUS",
     "FLX_KMER_LOCUS_BUILD", "FLX_KMER_PAIRTABLE", "FLX_KMER_PREFILTER", "FLX_KMER_SAFE1", "FLX_KMER_TEXT_ORDER", "FLX_PHRED_KERNEL",
     "FLX_PHRED_TABLES", "FLX_RANK_EXACT", "FLX_RANK_SORT", "FLX_RCCL_LIB",
-    // read by the hosts above the C ABI (cli/main.cpp, filtlong_amd/_lib.py, bench.py)
-    "FLX_DEVICE", "FLX_COMM_ID_FILE", "FLX_LIB_PATH", "FLX_NO_TORCH_PRELOAD",
 };
+static const char *const kOwnPrefixes[] = {"FLX_KMER_", "FLX_PHRED_", "FLX_RANK_", "FLX_RCCL_", "FLX_API_"};
 extern char **environ;
 static int check_environment() {
     for (char **e = environ; e && *e; ++e) {
         if (strncmp(*e, "FLX_", 4) != 0) continue;
         const char *eq = strchr(*e, '=');
         const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
-        if (name.compare(0, 8, "FLX_CLI_") == 0 || name.compare(0, 9, "FLX_FUZZ_") == 0 || name.compare(0, 10, "FLX_BENCH_") == 0 ||
-            name.compare(0, 9, "FLX_TEST_") == 0)
-            continue;
+        bool own = false;
+        for (const char *pre : kOwnPrefixes) own = own || name.compare(0, strlen(pre), pre) == 0;
+        if (!own) continue;
         bool known = false;
         for (const char *k : kKnownEnv) known = known || name == k;
         if (!known)

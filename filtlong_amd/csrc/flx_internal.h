@@ -27,6 +27,7 @@ struct flx_ctx {
     hipDeviceProp_t prop;
     std::string err;
     bool last_kmer_fold_grid = false;    // ... and its window folds on the integer grid (score_kmer.hip: GridTab)
+    const char *last_kmer_cover = "";    // which coverage kernel the last k-mer scoring call ran: "q" (cover_queue.hip), "w", "v2"
     bool last_kmer_locus = false;        // the last k-mer scoring call ran with the assembly text (kmerset.h: flx_locus)
     const char *last_phred_kernel = "";  // which Phred kernel the last scoring call launched (flx_last_phred_kernel)
 
@@ -71,9 +72,22 @@ int flx_fail(flx_ctx *ctx, int code, const char *fmt, ...);
         if (rc__ != FLX_OK) return rc__; \
     } while (0)
 
-// RAII-free timing helpers: call begin before a launch and end right after it.
+// timing brackets on the context's stream: call begin before a launch and end right after it (brackets nest) ...
 void flx_time_begin(flx_ctx *ctx, const char *name);
 void flx_time_end(flx_ctx *ctx);
+// ... or as a scope, wherever a FLX_HIP / FLX_CHECK between the two can return: an early return must not leave a bracket open
+// (the next flx_time_end would close the wrong one; advisor, round 5)
+struct flx_time_scope {
+    flx_ctx *ctx;
+    bool open;
+    flx_time_scope(flx_ctx *c, const char *name) : ctx(c), open(true) { flx_time_begin(c, name); }
+    flx_time_scope(const flx_time_scope &) = delete;
+    void end() {
+        if (open) flx_time_end(ctx);
+        open = false;
+    }
+    ~flx_time_scope() { end(); }
+};
 
 // grow-only scratch on the device
 int flx_scratch(flx_ctx *ctx, size_t bytes, void **out);

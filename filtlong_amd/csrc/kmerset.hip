@@ -748,11 +748,17 @@ extern "C" int flx_kmerset_finalize(flx_kmerset *s) {
                 for (auto &b : *list) wb.push_back({b.bases, b.offsets, b.pos_base, b.n_seqs, b.n_pos});
             // (the text is optional — include/filtlong_hip.h: "when that memory cannot be had the set works without" — so a build
             // that fails on its transient memory, ~12 GB for the C4 set, leaves a set without a text, not a failed finalize)
-            if (flx_build_path_text(ctx, s->present, (const uint8_t *)s->exact15, sz, wb.data(), wb.size(), &s->locus_text, &s->locus_seed, &s->locus) != FLX_OK) {
+            // ONLY a failure for want of memory: a kernel fault or any other HIP error in the build is an error of finalize (it would
+            // otherwise surface later in an unrelated call — hipGetLastError does not clear a sticky fault; advisor, round 5)
+            const int text_rc = flx_build_path_text(ctx, s->present, (const uint8_t *)s->exact15, sz, wb.data(), wb.size(), &s->locus_text, &s->locus_seed, &s->locus);
+            if (text_rc != FLX_OK) {
                 if (s->locus_text) (void)hipFree(s->locus_text);
                 if (s->locus_seed) (void)hipFree(s->locus_seed);
                 s->locus_text = s->locus_seed = nullptr;
+                const bool no_memory = text_rc == FLX_ERR_NOMEM || (text_rc == FLX_ERR_HIP && ctx->err.find(hipGetErrorString(hipErrorOutOfMemory)) != std::string::npos);
+                if (!no_memory) return text_rc;
                 (void)hipGetLastError();
+                ctx->err.clear();  // (the set works without a text: nothing failed)
             }
             s->has_locus = s->locus_text != nullptr;
         } else if (!s->has_short && n_windows > 0 && n_text <= (1ull << 28) && !(lb && lb[0] == '0')) {

@@ -434,17 +434,7 @@ static double key_to_score(uint64_t k) {
     return v;
 }
 
-// flx_time_begin / flx_time_end as a scope: an early return cannot leave a bracket open
-struct TimeScope {
-    flx_ctx *ctx;
-    bool open;
-    TimeScope(flx_ctx *c, const char *name) : ctx(c), open(true) { flx_time_begin(c, name); }
-    void end() {
-        if (open) flx_time_end(ctx);
-        open = false;
-    }
-    ~TimeScope() { end(); }
-};
+using TimeScope = flx_time_scope;  // (flx_internal.h)
 
 // ---- the boundary audit, shared by both cut implementations ---------------------------------------------------------
 // Candidates = every read whose DEVICE score lies within the band around the crossing score, with its EXACT score (host

@@ -223,16 +223,10 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_regs(const PhredAr
         lim[m] = ((__shfl(L, r, 64) + 15) & ~15) - dq * 16;
     }
     auto issue_dma = [&](int c) {  // chunk c (stream bytes [128 c, 128 c + 128)) -> the slot, whose previous content has been read
-#ifdef FLX_ABL_NODMA
-        if (c > 0) return;
-#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int m = 0; m < 4; ++m) {  // the two halves of a line back to back
             const int o = c * 128;
-#ifdef FLX_ABL_HALFDMA
-            if (m & 1) continue;
-#endif
             if (o < lim[m]) dma16(gsrc[m] + o, slot_lds + m * 1024);
             if (o + 64 < lim[m]) dma16(gsrc[m] + o + 64, slot_lds + 4096 + m * 1024);
         }
@@ -248,9 +242,7 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_regs(const PhredAr
     // free and the next chunk's DMA goes out, a whole round of compute ahead of its first use
     auto load_round = [&](int t0, int r) {
         const int half = r & 1;
-#ifndef FLX_ABL_NOWAIT
         if (half == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         const unsigned char *row = my_row + half * 4096;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -282,11 +274,7 @@ __global__ void __launch_bounds__(WAVES * 64) flx_score_phred_regs(const PhredAr
         }
     };
     auto steady_piece = [&](const uint32_t (&lw)[4], const uint32_t (&p0)[4], const uint32_t (&p1)[4], int Tp) {
-#ifdef FLX_ABL_NOMASK
-        const bool masked = false;
-#else
         const bool masked = 16 * (Tp + 1) > Lmin;
-#endif
         const int rem = L - 16 * Tp;
         uint32_t tw[4];
         funnel(p0, p1, fD, fsh, tw);

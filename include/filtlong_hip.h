@@ -39,7 +39,8 @@ extern "C" {
  * set built from an assembly also keeps the assembly as a text + seed table (0.5 B per base + 10 B per distinct 16-mer of device
  * memory beside the 512 MiB bitmap, 1 GiB pair table and 2 + 2 MiB prefilters); when that memory cannot be had the set works without */
 /* 3 (round 5): + flx_last_kmer_fold_grid */
-#define FLX_ABI_VERSION 3
+/* 4 (round 6): + flx_last_kmer_cover */
+#define FLX_ABI_VERSION 4
 
 enum flx_status {
     FLX_OK = 0,
@@ -103,6 +104,10 @@ int flx_last_kmer_locus(const flx_ctx *ctx);
  * rounds alike on the binades from 2^-3 to 2 — the default 250 among them; FLX_KMER_FOLD_GRID=0 switches it off), 0 when every step
  * was taken in floating point.  Results are identical either way. */
 int flx_last_kmer_fold_grid(const flx_ctx *ctx);
+/* Which coverage kernel the last k-mer-mode scoring call launched: "q" (phases with a queue in LDS between them, the default for a
+ * set with a text), "w" (the wave-level kernel of rounds 3-5: sets without a text, FLX_KMER_COVER=w) or "v2" (FLX_KMER_COVER=v2, sets
+ * without the pair table).  Results are identical whichever runs. */
+const char *flx_last_kmer_cover(const flx_ctx *ctx);
 int flx_timing_enable(flx_ctx *ctx, int on);
 int flx_timing_reset(flx_ctx *ctx);
 int flx_timing_get(flx_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches);

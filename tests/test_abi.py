@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_version_and_layout_helpers(lib):
     L = _lib.load()
-    assert L.flx_abi_version() == 3
+    assert L.flx_abi_version() == 4
     assert b"gfx950" in L.flx_version()
     import numpy as np
     from filtlong_amd import api
@@ -63,8 +63,8 @@ def _getenv_names(paths):
 
 
 def test_environment_switch_lists_match_the_sources(lib):
-    """Round-4 review, item 9: an unknown FLX_* name is refused (flx_ctx_create for the library's switches, the command line for
-    FLX_CLI_*) instead of being ignored.  The two lists must hold exactly the names the sources read, README.md must name every one
+    """Round-4 review, item 9: an unknown name under one of the library's own prefixes is refused (flx_ctx_create for FLX_KMER_ /
+    FLX_PHRED_ / FLX_RANK_ / FLX_RCCL_ / FLX_API_, the command line for FLX_CLI_*) instead of being ignored; any other FLX_ name is left alone.  The two lists must hold exactly the names the sources read, README.md must name every one
     of them, and the check itself must fire — before any device is asked for, so it runs without a GPU."""
     import glob
     import subprocess
@@ -74,7 +74,10 @@ def test_environment_switch_lists_match_the_sources(lib):
     ctx_src = open(os.path.join(ROOT, "filtlong_amd", "csrc", "flx_ctx.hip")).read()
     known_lib = set(re.findall(r'"(FLX_[A-Z0-9_]+)"', ctx_src[ctx_src.index("kKnownEnv[] = {"):ctx_src.index("extern char **environ;")]))
     hosts = {"FLX_DEVICE", "FLX_COMM_ID_FILE", "FLX_LIB_PATH", "FLX_NO_TORCH_PRELOAD"}
-    assert _getenv_names(csrc) == known_lib - hosts
+    assert _getenv_names(csrc) == known_lib
+    own = set(re.findall(r'"(FLX_[A-Z]+_)"', ctx_src[ctx_src.index("kOwnPrefixes[] = {"):ctx_src.index("extern char **environ;")]))
+    assert own == {"FLX_KMER_", "FLX_PHRED_", "FLX_RANK_", "FLX_RCCL_", "FLX_API_"}
+    assert all(any(n.startswith(p) for p in own) for n in known_lib)  # every switch the library reads lies under a prefix it checks
     main_src = open(os.path.join(ROOT, "filtlong_amd", "cli", "main.cpp")).read()
     known_cli = set(re.findall(r'"(FLX_CLI_[A-Z0-9_]+)"', main_src[main_src.index("static int check_cli_environment()"):main_src.index("int main(int argc")]))
     read_cli = _getenv_names(cli)
@@ -88,6 +91,12 @@ def test_environment_switch_lists_match_the_sources(lib):
     env = dict(os.environ, FLX_KMER_COVR="v2", PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
     assert "REFUSED" in out and "FLX_KMER_COVR" in out, out
+    # ... and a FOREIGN name (another tool's variable, a stale export) is none of the library's business: the drop-in binary must run
+    # where the reference would (round-5 review, item 5) — without a GPU the context then fails for the device, not for the name
+    env = dict(os.environ, FLX_FOO="1", FLX_SOMETHING_ELSE="x", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code.replace("api.Context(0)", "api.Context(0); print('CREATED')")], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+    assert "unknown environment variable" not in out and ("CREATED" in out or "no HIP device" in out), out
     exe = os.path.join(ROOT, "filtlong_amd", "bin", "filtlong")
     if os.path.exists(exe):
         fq = os.path.join(ROOT, "tests", "golden", "ref_fixtures", "test_sort.fastq")

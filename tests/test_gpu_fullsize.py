@@ -223,21 +223,26 @@ def test_kmer_mode_properties(short_reads, size):
     # bitmap lookup per candidate run end) agree on every read and child of the batch
     wave_level = {k: v.clone() for k, v in t.items()}
     n_wave = int(s.n_children)
-    os.environ["FLX_KMER_COVER"] = "v2"
-    try:
-        for v in t.values():
-            v.zero_()
-        torch.cuda.synchronize()
-        assert ctx.score_kmer_dev(ks, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n,
-                                  params, s) == 0
-        torch.cuda.synchronize()
-    finally:
-        del os.environ["FLX_KMER_COVER"]
-    assert int(s.n_children) == n_wave
-    for k in ("mean", "win", "pass", "first", "last", "coff"):
-        assert torch.equal(t[k].view(torch.uint8), wave_level[k].view(torch.uint8)), k
-    for k, per in (("crng", 2), ("cmean", 1), ("cwin", 1), ("cpass", 1)):
-        assert torch.equal(t[k][:per * n_wave].view(torch.uint8), wave_level[k][:per * n_wave].view(torch.uint8)), k
+    assert ctx.last_kmer_cover() == "q"  # (round 6: the default is the kernel with the queue in LDS, cover_queue.hip)
+    for other in ("w", "v2"):  # the wave-level kernel of rounds 3-5, round 2's kernel
+        os.environ["FLX_KMER_COVER"] = other
+        try:
+            for v in t.values():
+                v.zero_()
+            torch.cuda.synchronize()
+            assert ctx.score_kmer_dev(ks, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n,
+                                      params, s) == 0
+            torch.cuda.synchronize()
+            assert ctx.last_kmer_cover() == other
+        finally:
+            del os.environ["FLX_KMER_COVER"]
+        assert int(s.n_children) == n_wave
+        for k in ("mean", "win", "pass", "first", "last", "coff"):
+            assert torch.equal(t[k].view(torch.uint8), wave_level[k].view(torch.uint8)), (other, k)
+        for k, per in (("crng", 2), ("cmean", 1), ("cwin", 1), ("cpass", 1)):
+            assert torch.equal(t[k][:per * n_wave].view(torch.uint8), wave_level[k][:per * n_wave].view(torch.uint8)), (other, k)
+    for k, v in wave_level.items():
+        t[k].copy_(v)
     del wave_level
     mean, win, first, last = (t[k].cpu().numpy() for k in ("mean", "win", "first", "last"))
     coff = t["coff"].cpu().numpy()

@@ -250,7 +250,7 @@ def test_every_byte_value_in_reads(be, synth):
             assert w["child_ranges"] == o["child_ranges"], (name, pkw)
 
 
-def test_prefilter_and_fold_variants_give_identical_results(be, synth, monkeypatch):
+def test_prefilter_and_fold_variants_give_identical_results(ctx, be, synth, monkeypatch):
     """The L2 prefilter (kmerset finalize) and the word-level child passes are pure accelerations: without the prefilter
     (FLX_KMER_PREFILTER=0, the path large sets take) and with the bit-level fold (FLX_KMER_FOLD=bits) every output field
     of the synthetic k-mer reads is the same."""
@@ -312,10 +312,16 @@ def test_prefilter_and_fold_variants_give_identical_results(be, synth, monkeypat
     for ks_kw in (dict(assembly=synth["contigs"]), dict(short_files=synth["sr"])):
         monkeypatch.setenv("FLX_KMER_COVER", "v2")
         old_k = be.score(reads, pkw, be.kmers(**ks_kw))
+        assert ctx.last_kmer_cover() == "v2"
+        monkeypatch.setenv("FLX_KMER_COVER", "w")  # the wave-level kernel of rounds 3-5
+        wave_k = be.score(reads, pkw, be.kmers(**ks_kw))
+        assert ctx.last_kmer_cover() == "w"
         monkeypatch.delenv("FLX_KMER_COVER")
         new_k = be.score(reads, pkw, be.kmers(**ks_kw))
-        for (name, _s, _q), a, b in zip(reads, old_k, new_k):
+        assert ctx.last_kmer_cover() == "q"  # round 6: phases with a queue in LDS between them (cover_queue.hip)
+        for (name, _s, _q), a, b, c in zip(reads, old_k, new_k, wave_k):
             assert bits(a) == bits(b), name
+            assert bits(c) == bits(b), (name, "w")
 
 
 def test_reads2_gather_matches_oracle(ctx, be, synth):
@@ -545,7 +551,7 @@ def test_locus_path_vs_oracle(ctx, be, synth, monkeypatch):
 
     for pkw in (dict(), dict(trim=True, split=20), dict(trim=True, split=250, window_size=100)):
         got = be.score(reads, pkw, ks)
-        assert ctx.last_kmer_locus()
+        assert ctx.last_kmer_locus() and ctx.last_kmer_cover() == "q"
         p = _oracle.make_params(**pkw)
         for (name, seq, q), o in zip(reads, got):
             wnt = _oracle.score_read(seq, q, p, orc, cap=65536)
@@ -561,10 +567,14 @@ def test_locus_path_vs_oracle(ctx, be, synth, monkeypatch):
         monkeypatch.delenv("FLX_KMER_LOCUS")
         monkeypatch.setenv("FLX_KMER_COVER", "v2")
         v2 = be.score(reads, pkw, ks)
+        monkeypatch.setenv("FLX_KMER_COVER", "w")
+        wv = be.score(reads, pkw, ks)
+        assert ctx.last_kmer_cover() == "w" and ctx.last_kmer_locus()
         monkeypatch.delenv("FLX_KMER_COVER")
-        for (name, _s, _q), a, b, c in zip(reads, got, plain, v2):
+        for (name, _s, _q), a, b, c, d in zip(reads, got, plain, v2, wv):
             assert bits(a) == bits(b), (name, pkw, "FLX_KMER_LOCUS=0")
             assert bits(a) == bits(c), (name, pkw, "v2")
+            assert bits(a) == bits(d), (name, pkw, "w")
     # the same set built without S1: nothing may differ
     monkeypatch.setenv("FLX_KMER_SAFE1", "0")
     ks_plain = be.kmers(assembly=contigs)
@@ -677,10 +687,13 @@ def test_path_text_of_short_read_sets_vs_oracle(ctx, be, monkeypatch):
             monkeypatch.delenv("FLX_KMER_LOCUS")
             monkeypatch.setenv("FLX_KMER_COVER", "v2")
             v2 = be.score(reads, pkw, kset)
+            monkeypatch.setenv("FLX_KMER_COVER", "w")
+            wv = be.score(reads, pkw, kset)
             monkeypatch.delenv("FLX_KMER_COVER")
-            for (name, _s, _q), a, b, c in zip(reads, got, plain, v2):
+            for (name, _s, _q), a, b, c, d in zip(reads, got, plain, v2, wv):
                 assert bits(a) == bits(b), (name, pkw, "FLX_KMER_LOCUS=0")
                 assert bits(a) == bits(c), (name, pkw, "v2")
+                assert bits(a) == bits(d), (name, pkw, "w")
 
 
 def test_set_without_room_for_the_pair_table(ctx, be, synth, monkeypatch):

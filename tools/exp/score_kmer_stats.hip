@@ -20,9 +20,17 @@
 //                 so a child's mean/window/cut-offs come from the parent's bits without new lookups.
 #include "flx_internal.h"
 #include "kmerset.h"
-#include "cover_common.h"
 #include "rank_internal.h"
 
+#ifndef FLX_COVER_THREADS
+#define FLX_COVER_THREADS 256  // threads per workgroup of k_kmer_cover_w (its waves are independent)
+#endif
+#ifndef FLX_LOCUS_SEEDS
+#define FLX_LOCUS_SEEDS 4  // seed attempts per span of the locus path (score_kmer.hip, below)
+#endif
+#ifndef FLX_LOCUS_TAIL
+#define FLX_LOCUS_TAIL 3  // lanes without a known member behind the last one that has one, from which the span seeds again
+#endif
 #ifndef FLX_FARFIRST_LANES
 #define FLX_FARFIRST_LANES 16  // settled lanes of a span from which the next span asks the exact table first (score_kmer.hip, below)
 #endif
@@ -30,7 +38,28 @@
 #define FLX_FARFIRST_LANES_LOCUS 65  // the same with a text: never (65 > 64) — the text settles the clean lanes, the mode only costs instructions (profiles/r04_microbench.txt)
 #endif
 
+__device__ unsigned long long flx_cover_stats_d[32];
+extern "C" int flx_debug_cover_stats(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(flx_cover_stats_d), sizeof(unsigned long long) * 32); }
+extern "C" int flx_debug_cover_stats_reset() { unsigned long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(flx_cover_stats_d), z, sizeof z); }
+#define ST(i, v) do { const unsigned long long v_ = (v); if (lane == 0 && v_) atomicAdd(&flx_cover_stats_d[i], v_); } while (0)
+#define STB(i, pred) ST(i, (unsigned long long)__popcll(__ballot(pred)))
 namespace {
+
+// The 2-bit codes of the four bases of a dword (src/kmers.cpp:176-196: C/c 1, G/g 2, T/t 3, anything else 0) packed into 8
+// bits, first base (lowest byte) in the top two.  Branch free (a switch per base compiles into divergent control flow — half
+// of the cover kernel's run time once) and, since the cover kernel turned out to be bound by its vector instructions (round 4:
+// 0.81 per position, a quarter of them here), by table: bits 1..3 of a letter tell A, C, T and G apart (0, 1, 2, 3 — in either
+// case), v_perm_b32 looks up the letter that index stands for and the byte is that letter or it is none of them; a second
+// v_perm_b32 turns the index into the code and v_dot4_u32_u8 packs the four.  12 instructions per dword (three SWAR comparisons: 30).
+__device__ __forceinline__ uint32_t codes4(uint32_t w) {
+    const uint32_t idx = (w >> 1) & 0x07070707u;
+    const uint32_t letter = __builtin_amdgcn_perm(0u, 0x47544341u, idx);  // A C T G for 0 1 2 3, 0x00 for 4..7
+    const uint32_t d = (letter ^ w) & 0xDFDFDFDFu;                         // a zero byte: that letter, upper or lower case
+    const uint32_t nz = ((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d;             // bit 7 of every byte that is NOT zero
+    const uint32_t sel = ((nz >> 5) & 0x04040404u) | idx;                  // anything else: an index from 4 on
+    const uint32_t code = __builtin_amdgcn_perm(0u, 0x02030100u, sel);     // A 0, C 1, T 3, G 2; 0 from 4 on
+    return __builtin_amdgcn_udot4(code, 0x01041040u, 0u, false);           // byte 0 * 64 + byte 1 * 16 + byte 2 * 4 + byte 3
+}
 
 // ---------------------------------------------------------------------------------------------------
 // coverage
@@ -87,7 +116,11 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
 #pragma unroll
                 for (int j = 0; j < 5; ++j) kleft[j] = hi >> (2 * (4 - j));  // low 24 bits: the 12-mer ending at p0 - 5 + j
                 // 12-mer prefilter (kmerset.h): one L2 lookup per position, all 16 in flight
+#ifdef FLX_ABL_NOL2
+                if (false) {
+#else
                 if (prefilter) {
+#endif
                     uint32_t pw[16];
 #pragma unroll
                     for (int j = 0; j < 16; ++j) pw[j] = prefilter[flx_sub12(kmers[j], 0) >> 5];
@@ -129,12 +162,16 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
                 left_run = t > 0 && p12_left == 0x1fu && p0 - 1 >= 15;  // the left neighbour's bit 15 is a candidate
                 const uint32_t starts = cand & ~(cand << 1), ends = cand & ~(cand >> 1);
                 probed = ends | (left_run ? starts & ~1u : starts);
+#ifdef FLX_ABL_NOFAR
+                hits = probed;
+#else
                 uint32_t words[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) words[j] = ((probed >> j) & 1u) ? bitmap[kmers[j] >> 5] : 0u;  // independent, in flight
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
                     if ((probed >> j) & 1u) hits |= ((words[j] >> (kmers[j] & 31)) & 1u) << j;
+#endif
             }
             sh_anchor[t] = (uint8_t)((hits >> 15) & 1u);
             __syncthreads();
@@ -259,6 +296,79 @@ __global__ void __launch_bounds__(COVER_THREADS) k_kmer_cover(const uint8_t *pla
 // may still occur elsewhere).  The diagonal comes from the seed table: eight lanes look their own 16 bases up (one far request
 // each) when the wave has none or the last 16 lanes of the previous span matched nowhere; a seed that fails leaves the old
 // diagonal in place as a hypothesis that costs nothing to test.
+// 8 waves per SIMD (63 registers instead of 68): 14.8 -> 14.3 ms per 1e10 positions; 9 and 10 are slower again (profiles/r04_microbench.txt)
+// the read plane is streamed once and the coverage rows are written once: non-temporal, so that they do not push the prefilter out of
+// the L2 (14.26 -> 13.8 ms per 1e10 positions; FLX_COVER_TEMPORAL restores plain accesses)
+__device__ __forceinline__ uint4 flx_plane16(const uint8_t *p) {
+#ifndef FLX_COVER_TEMPORAL
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 v;
+    v.x = __builtin_nontemporal_load(&q->x); v.y = __builtin_nontemporal_load(&q->y);
+    v.z = __builtin_nontemporal_load(&q->z); v.w = __builtin_nontemporal_load(&q->w);
+    return v;
+#else
+    return *reinterpret_cast<const uint4 *>(p);
+#endif
+}
+// A lane's left / right neighbour's value, with lane 0's / lane 63's coming from a wave-uniform carry: ONE DPP move (wave_shr:1 /
+// wave_shl:1: a lane without a source keeps the destination's old value, which is set to the carry).  __shfl_up + `if (lane == 0)`
+// compiles to ds_bpermute_b32 + v_cndmask_b32 with the lane mask held in an SGPR pair — twenty of those per span kept four such pairs
+// alive in a kernel that is short of scalar registers (78 at 8 waves per SIMD: they were spilled to vector lanes and read back with
+// two v_readlane each), and sent thirty operations per span through the LDS crossbar.  (FLX_COVER_NO_DPP: the old form, A/B.)
+__device__ __forceinline__ uint32_t flx_from_left(uint32_t x, uint32_t lane0) {
+#ifndef FLX_COVER_NO_DPP
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+#else
+    const uint32_t v = __shfl_up(x, 1, 64);
+    return (threadIdx.x & 63) == 0 ? lane0 : v;
+#endif
+}
+__device__ __forceinline__ uint32_t flx_from_right(uint32_t x, uint32_t lane63) {
+#ifndef FLX_COVER_NO_DPP
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane63, (int)x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+#else
+    const uint32_t v = __shfl_down(x, 1, 64);
+    return (threadIdx.x & 63) == 63 ? lane63 : v;
+#endif
+}
+#ifndef FLX_COVER_WAVES_PER_EU
+#define FLX_COVER_WAVES_PER_EU 8
+#endif
+#define FLX_COVER_OCC __attribute__((amdgpu_waves_per_eu(FLX_COVER_WAVES_PER_EU, FLX_COVER_WAVES_PER_EU)))
+struct CoverArgs {
+    const uint8_t *plane;
+    const uint64_t *offsets;
+    const int32_t *lengths;
+    const uint32_t *order;
+    uint64_t n_reads;
+    const uint8_t *exact15;
+    const uint8_t *pre11;
+    flx_locus loc;
+    uint32_t *cov;
+    const uint64_t *cov_off;
+    int32_t *count, *first, *last;
+};
+// A 64-bit kernel argument, read from the argument segment where it is used (s_load_dwordx2: the scalar cache).  The span loop
+// holds five table pointers, and the kernel has 78 scalar registers at 8 waves per SIMD: kept in registers they are spilled to
+// vector lanes and come back with two v_readlane each — vector instructions, which is what the kernel is bound by; a scalar load
+// costs none.  (asm volatile: neither hoisted out of the loop nor merged with a neighbour.)  MEASURED AND REJECTED (round 5):
+// 27 fewer spill instructions per span (39 -> 12), 10 fewer vector instructions in the loop — and 110.3 instead of 108.3 ms per
+// 1e11 positions: every reload waits for the scalar cache (s_waitcnt lgkmcnt(0)) on the wave's critical path.  -DFLX_COVER_ARGS_RELOAD
+// builds it.
+template <int OFFSET>
+__device__ __forceinline__ uint64_t flx_karg64() {
+    uint64_t v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"((uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFFSET));
+    return v;
+}
+// (the pointer comes out of an integer: without the global address space on it every access would be a flat load with a 64-bit
+// address built in vector registers — one more vector instruction per access, exactly what this is meant to remove)
+#define FLX_GLOBAL_PTR(elem) const elem __attribute__((address_space(1))) *
+#ifdef FLX_COVER_ARGS_RELOAD
+#define FLX_KARG_PTR(elem, field) ((FLX_GLOBAL_PTR(elem))flx_karg64<(int)offsetof(CoverArgs, field)>())
+#else
+#define FLX_KARG_PTR(elem, field) ((FLX_GLOBAL_PTR(elem))(uint64_t)(uintptr_t)(a.field))
+#endif
 template <bool HAS_PREFILTER, bool LOCUS>
 __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_w(const CoverArgs a) {
     const uint8_t *plane = a.plane;
@@ -320,7 +430,9 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             x |= x >> 4;
             x |= x >> 8;  // bit j = OR of hit bits j .. j+15: base p0+j lies in a member 16-mer (src/read.cpp:53-54)
             uint32_t c16 = x & 0xffffu;
+#ifndef FLX_NO_VALID_FAST
             if (((sp + 1) << 10) > L)  // (wave-uniform: only the read's last span has positions to cut off)
+#endif
             {
                 if (p0 >= L) c16 = 0;
                 else if (p0 + 16 > L) c16 &= (1u << (L - p0)) - 1u;
@@ -332,7 +444,11 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             }
             const uint32_t up = flx_from_right(c16, 0u);  // (only the even lanes write: lane 63's is never used)
             const int word = p0 >> 5;
+#ifndef FLX_COVER_TEMPORAL
             if ((lane & 1) == 0 && word < row_words) __builtin_nontemporal_store(c16 | (up << 16), &row[(uint32_t)word]);
+#else
+            if ((lane & 1) == 0 && word < row_words) row[(uint32_t)word] = c16 | (up << 16);
+#endif
         };
 
         uint4 raw = make_uint4(0, 0, 0, 0);
@@ -351,9 +467,11 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             const uint32_t hi = flx_from_left(lo, c_lo);
             // positions p0 + j that end a 12-mer / a 16-mer inside the read
             uint32_t valid12 = 0, valid16 = 0;
+#ifndef FLX_NO_VALID_FAST
             if (sp > 0 && ((sp + 1) << 10) <= L) {  // (wave-uniform: a span inside the read has every position, no lane computes masks)
                 valid12 = valid16 = 0xffffu;
             } else
+#endif
             if (p0 < L) {
                 valid12 = valid16 = 0xffffu;
                 if (p0 < 11) valid12 &= ~((1u << (11 - p0)) - 1u);
@@ -363,6 +481,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     valid16 &= (1u << (L - p0)) - 1u;
                 }
             }
+            bool needsB = false; ST(0, 1); STB(1, p0 < L);
             // ---- LOCUS: members known from the text along the diagonal ----
             uint32_t known = 0, refuted = 0;  // refuted: not a text match, but holds a text-matching 13-mer that occurs nowhere else
             uint32_t text12 = 0;              // bit j: the 12 bases ending at my position j match the text inside one piece: that 12-mer IS present
@@ -460,7 +579,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 const unsigned long long whole = __ballot((valid16 >> 15) != 0);  // lanes that hold a whole 16-mer of the read
                 bool again = have_diag;
                 for (int seeds_left = FLX_LOCUS_SEEDS;;) {
-                    if (again) compare();
+                    if (again) { compare(); ST(12, 1); }
                     const unsigned long long kn = __ballot(known != 0);
                     const unsigned long long tail = kn ? whole & ~((2ull << (63 - __clzll(kn))) - 1ull) : whole;
                     if (seeds_left-- == 0 || __popcll(tail) < FLX_LOCUS_TAIL) break;
@@ -472,6 +591,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                         tries = (lane & 7) == 3 && ((whole >> lane) & 1ull);
                     }
                     uint32_t tpos = kLocusEmpty;
+                    ST(11, 1); STB(18, tries);
                     if (tries) {
                         uint32_t h = flx_locus_hash(lo, loc_seed_shift);
                         FLX_GLOBAL_PTR(uint32_t) seed_tab = FLX_KARG_PTR(uint32_t, loc.seed);
@@ -513,13 +633,18 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             // pair that starts there: either way the request also settles the next candidate in the direction of the search. ----
             uint32_t hits = known, probed = known;
             auto probe = [&](int top, int bot, uint32_t keep) {  // positions asked from above / from below, -1 = none
+                ST(9, 1); STB(10, top >= 0 || bot >= 0); ST(16, (unsigned long long)__popcll(__ballot(top >= 0)) + __popcll(__ballot(bot >= 0))); needsB |= (top >= 0 || bot >= 0);
                 const int a0 = top > 0 ? top - 1 : 0, a1 = bot < 14 ? bot : 14;
                 uint32_t g0 = 0, g1 = 0;
+#ifdef FLX_ABL_NOFAR
+                g0 = g1 = 0xffu;  // ablation: every asked 16-mer "is a member", no far request
+#else
                 // plain byte loads: non-temporal ones measured 8 % slower here (43.3 vs 40.1 ms per 1e10 positions), 4-byte loads
                 // 6 % slower — although a microbenchmark that mixes table and far lookups in one burst prefers nt (tools/tabench (7))
                 FLX_GLOBAL_PTR(uint8_t) exact15 = FLX_KARG_PTR(uint8_t, exact15);
                 if (top >= 0) g0 = exact15[__builtin_amdgcn_alignbit(hi, lo, 30 - 2 * a0) & 0x3FFFFFFFu];
                 if (bot >= 0) g1 = exact15[__builtin_amdgcn_alignbit(hi, lo, 30 - 2 * a1) & 0x3FFFFFFFu];
+#endif
                 if (top >= 0) {
                     const uint32_t x = (hi >> (28 - 2 * a0)) & 3u, y = (lo >> (28 - 2 * a0)) & 3u;
                     hits |= (((g0 >> x) & 1u) | (((g0 >> (4 + y)) & 1u) << 1)) << a0;
@@ -549,6 +674,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 ltop = flx_from_left(known >> 15, c_hit15);
                 settled = (known >> 15) && ltop;
             }
+            STB(2, settled && p0 < L); STB(3, (valid16 & ~(known | refuted)) != 0); STB(19, (valid16 & ~(known | refuted)) != 0 && !settled);
             // LOCUS: the 12-mers ending at [lowest hit - 4, highest hit] need no lookup — those inside a member are present, the
             // others only make candidates between two confirmed members, which are never asked
             uint32_t need12 = 0xffffu;
@@ -568,7 +694,11 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 for (int m = 0; m < 8; ++m) {
                     const uint32_t a = __builtin_amdgcn_alignbit(hi, lo, 28 - 4 * m);
                     const flx_pre11_slot q = flx_pre11((a >> 2) & 0x3FFFFFu, (a >> 24) & 3u, a & 3u);
+#ifdef FLX_ABL_NOL2
+                    byte[m] = 0xffu;  // ablation: no prefilter lookups (every 12-mer "present")
+#else
                     byte[m] = pre11[q.index];
+#endif
                     sel[m] = q.even_bit | (q.odd_bit << 8);
                 }
                 p12 = 0;
@@ -601,7 +731,11 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                         const uint32_t c = (a >> 2) & 0x3FFFFFu, rc = (uint32_t)(r64 >> (12 + 4 * m)) & 0x3FFFFFu;
                         const uint32_t kk = (a & 0x2000u) ? rc : c;  // the middle base of C is G or T: the byte belongs to the other strand
                         const uint32_t index = ((kk >> 12) << 11) | (kk & 0x7FFu);
+#ifdef FLX_ABL_NOL2
+                        byte[k] = 0xffu;
+#else
                         byte[k] = ((want >> (2 * m)) & 3u) ? pre11[index] : 0xffu;
+#endif
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -623,9 +757,11 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     dep |= dep >> 2;
                     dep |= dep >> 1;
                     const uint32_t w1 = want & 0x3333u & dep;
+                    STB(4, w1 != 0); ST(5, __any(w1 != 0) ? 1 : 0); ST(15, (unsigned long long)__popcll(__ballot((w1 & 0x3) != 0)) + __popcll(__ballot((w1 & 0x30) != 0)) + __popcll(__ballot((w1 & 0x300) != 0)) + __popcll(__ballot((w1 & 0x3000) != 0))); needsB |= w1 != 0;
                     p12 = __any(w1 != 0) ? fetch(w1, 0) : 0xffffu;  // (a span the text settles: nothing is computed for it)
                 }
                 if (__any((want & 0xCCCCu) != 0)) {
+                    ST(8, 1);
                     const uint32_t v1 = p12 & valid12;
                     const uint32_t l1 = flx_from_left(v1 >> 11, c_p12);
                     const uint32_t m1 = (l1 >> 1) | (v1 << 4);
@@ -637,6 +773,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     dep |= dep >> 2;
                     dep |= dep >> 1;  // bit q: one of the 16-mers ending at q .. q + 4 (those that hold the 12-mer ending at q) is alive
                     const uint32_t w2 = want & 0xCCCCu & dep;
+                    STB(6, w2 != 0); ST(7, __any(w2 != 0) ? 1 : 0); ST(15, (unsigned long long)__popcll(__ballot((w2 & 0xC) != 0)) + __popcll(__ballot((w2 & 0xC0) != 0)) + __popcll(__ballot((w2 & 0xC00) != 0)) + __popcll(__ballot((w2 & 0xC000) != 0))); needsB |= w2 != 0;
                     if (__any(w2 != 0)) p12 &= fetch(w2, 1);
                 }
             }
@@ -693,6 +830,8 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 far_first = __popcll(__ballot((hits >> 15) && lhit)) >= FLX_FARFIRST_LANES;
             }
 
+            STB(13, needsB); ST(14, __any(needsB) ? 1 : 0); STB(17, (hits & ~known) != 0);
+            { const int nb = __popcll(__ballot(needsB)); ST(20 + (nb == 0 ? 0 : nb <= 4 ? 1 : nb <= 8 ? 2 : nb <= 16 ? 3 : nb <= 24 ? 4 : nb <= 32 ? 5 : nb <= 48 ? 6 : 7), 1); }
             // ---- coverage of the previous span (its lane 63 needed my lane 0's hits), then carry ----
             if (sp > 0) finalize(sp - 1, prev_hits, __builtin_amdgcn_readfirstlane(hits));
             prev_hits = hits;
@@ -1540,14 +1679,10 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     // ---- kernel 1: lookups -> coverage bits ----
     {
         const unsigned grid = (unsigned)std::min<uint64_t>(n_reads, 1u << 20);
-        // FLX_KMER_COVER: "v2" = round 2's workgroup-per-read kernel, "w" = the wave-level kernel of rounds 3-5 for every set (second
-        // and third implementation; default: k_kmer_cover_q, cover_queue.hip, for a set with a text, k_kmer_cover_w for one without)
-        const char *cover_env = getenv("FLX_KMER_COVER");
+        const char *cover_env = getenv("FLX_KMER_COVER");  // "v2": round 2's workgroup-per-read kernel (second implementation)
         const bool old_cover = (cover_env && strcmp(cover_env, "v2") == 0) || !flx_kmerset_exact15(set);  // (no pair table: finalize found no room for it)
-        const bool wave_cover = cover_env && strcmp(cover_env, "w") == 0;
-        flx_time_scope tc(ctx, "flx_score_kmer_cover");
+        flx_time_begin(ctx, "flx_score_kmer_cover");
         ctx->last_kmer_locus = false;
-        ctx->last_kmer_cover = "v2";
         if (!old_cover) {
             const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + FLX_COVER_THREADS / 64 - 1) / (FLX_COVER_THREADS / 64), 1u << 22);
             const char *locus_env = getenv("FLX_KMER_LOCUS");  // "0": without the assembly text (the round-3 kernel; tests, A/B)
@@ -1555,20 +1690,18 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
             flx_locus none;
             memset(&none, 0, sizeof none);
             ctx->last_kmer_locus = lp != nullptr;
-            const uint8_t *pre11 = flx_kmerset_pre11(set);
-            CoverArgs ca = {d_plane, d_offsets, d_lengths, d_order, n_reads, flx_kmerset_exact15(set), pre11, lp ? *lp : none, (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first, last};
-            ctx->last_kmer_cover = (lp && !wave_cover) ? "q" : "w";
-            if (lp && !wave_cover) {
-                const int rc = flx_cover_queue_launch(ctx, ca, pre11 != nullptr, wgrid);
-                if (rc != FLX_OK) return rc;
-            } else if (pre11 && lp)
-                hipLaunchKernelGGL((k_kmer_cover_w<true, true>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, ca);
-            else if (pre11)
-                hipLaunchKernelGGL((k_kmer_cover_w<true, false>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, ca);
+            if (flx_kmerset_pre11(set) && lp)
+                { CoverArgs ca = {d_plane, d_offsets, d_lengths, d_order, n_reads, flx_kmerset_exact15(set), flx_kmerset_pre11(set), *lp, (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first, last};
+                  hipLaunchKernelGGL((k_kmer_cover_w<true, true>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, ca); }
+            else if (flx_kmerset_pre11(set))
+                { CoverArgs ca = {d_plane, d_offsets, d_lengths, d_order, n_reads, flx_kmerset_exact15(set), flx_kmerset_pre11(set), none, (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first, last};
+                  hipLaunchKernelGGL((k_kmer_cover_w<true, false>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, ca); }
             else if (lp)
-                hipLaunchKernelGGL((k_kmer_cover_w<false, true>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, ca);
+                { CoverArgs ca = {d_plane, d_offsets, d_lengths, d_order, n_reads, flx_kmerset_exact15(set), (const uint8_t *)nullptr, *lp, (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first, last};
+                  hipLaunchKernelGGL((k_kmer_cover_w<false, true>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, ca); }
             else
-                hipLaunchKernelGGL((k_kmer_cover_w<false, false>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, ca);
+                { CoverArgs ca = {d_plane, d_offsets, d_lengths, d_order, n_reads, flx_kmerset_exact15(set), (const uint8_t *)nullptr, none, (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first, last};
+                  hipLaunchKernelGGL((k_kmer_cover_w<false, false>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, ca); }
         } else {
         hipLaunchKernelGGL(k_kmer_cover<256>, dim3(grid), dim3(256), 0, st, d_plane, d_offsets, d_lengths, d_order, n_reads,
                            flx_kmerset_bitmap(set), flx_kmerset_prefilter(set), (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first,
@@ -1577,6 +1710,7 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
                            flx_kmerset_bitmap(set), flx_kmerset_prefilter(set), (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first,
                            last);
         }
+        flx_time_end(ctx);
     }
 
     // ---- kernel 2: serial fold ----
@@ -1619,10 +1753,9 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     a.child_passed = out->child_passed;
 
     if (!want_children) {
-        {
-            flx_time_scope tf(ctx, "flx_score_kmer_fold");
-            FLX_CHECK(launch_fold<0>(ctx, a));
-        }
+        flx_time_begin(ctx, "flx_score_kmer_fold");
+        FLX_CHECK(launch_fold<0>(ctx, a));
+        flx_time_end(ctx);
         if (out->child_offsets) FLX_HIP(ctx, hipMemsetAsync(out->child_offsets, 0, (n_reads + 1) * 8, st));
         FLX_HIP(ctx, hipGetLastError());
         FLX_HIP(ctx, hipStreamSynchronize(st));
@@ -1631,16 +1764,15 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
 
     FLX_HIP(ctx, hipMemsetAsync(d_nchild, 0, (n_reads + 1) * 4, st));
     a.n_child = d_nchild;
+    flx_time_begin(ctx, "flx_score_kmer_fold");
     // FLX_KMER_FOLD=bits forces the bit-level passes (tests compare the two implementations on every read)
     const char *fold_env = getenv("FLX_KMER_FOLD");
     const bool bit_level = (params->split_set && params->split < 32) || (fold_env && strcmp(fold_env, "bits") == 0);
-    {
-        flx_time_scope tf(ctx, "flx_score_kmer_fold");
-        if (bit_level)
-            FLX_CHECK(launch_fold<1>(ctx, a));  // runs inside one word can be bad ranges
-        else
-            FLX_CHECK(launch_fold<3>(ctx, a));
-    }
+    if (bit_level)
+        FLX_CHECK(launch_fold<1>(ctx, a));  // runs inside one word can be bad ranges
+    else
+        FLX_CHECK(launch_fold<3>(ctx, a));
+    flx_time_end(ctx);
     // child_offsets = exclusive scan of the counts (n + 1 entries; the last one is the total)
     hipLaunchKernelGGL(k_widen_u32_i64, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, st, n_reads + 1,
                        d_nchild, d_rowb);
@@ -1654,7 +1786,7 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
                         (long long)total_children, (unsigned long long)out->child_capacity);
     if (total_children > 0) {
         a.child_offsets = out->child_offsets;
-        flx_time_scope tf(ctx, "flx_score_kmer_fold");  // (a scope: the checks below may return)
+        flx_time_begin(ctx, "flx_score_kmer_fold");
         // FLX_KMER_FOLD=words: the children inside their read's lane (MODE 4, second implementation of the word-level path)
         const bool per_child = !bit_level && !(fold_env && strcmp(fold_env, "words") == 0);
         if (bit_level) {
@@ -1682,15 +1814,16 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
                 FLX_HIP(ctx, hipStreamSynchronize(st));
             }
             if (overflow) FLX_CHECK(launch_fold<5>(ctx, a));
-            tf.end();  // (the sort times its own passes)
+            flx_time_end(ctx);  // (the sort times its own passes)
             hipLaunchKernelGGL(k_child_keys, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, nc, out->child_ranges, keys0, vals0);
             uint64_t *skeys = nullptr;
             uint32_t *svals = nullptr;
             FLX_CHECK(flx_radix_sort_pairs(ctx, nc, keys0, keys1, vals0, vals1, d_sortws, sort_ws, &skeys, &svals));
             a.child_order = svals;
-            flx_time_scope tf6(ctx, "flx_score_kmer_fold");
+            flx_time_begin(ctx, "flx_score_kmer_fold");
             FLX_CHECK(launch_fold<6>(ctx, a));
         }
+        flx_time_end(ctx);
     }
     FLX_HIP(ctx, hipGetLastError());
     FLX_HIP(ctx, hipStreamSynchronize(st));
