@@ -368,9 +368,9 @@ class Context:
         self._check(self.L.flx_synth_qual_profile_dev(self.h, seed, profile, d_plane, plane_bytes, d_offsets, d_lengths,
                                                       d_read_ids, n))
 
-    def synth_seq_dev(self, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n, d_ref, ref_len):
-        self._check(self.L.flx_synth_seq_dev(self.h, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n, d_ref,
-                                             ref_len))
+    def synth_seq_dev(self, seed, d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n, d_ref, ref_len, profile=0):
+        self._check(self.L.flx_synth_seq_profile_dev(self.h, seed, int(profile), d_plane, plane_bytes, d_offsets, d_lengths, d_read_ids, n, d_ref,
+                                                     ref_len))
 
     def score_kmer_dev(self, kmers, d_plane, plane_bytes, d_offsets, d_lengths, d_order, n, params, scores):
         """flx_score_batch_dev in k-mer mode; `scores` is a filled _lib.Scores with device pointers."""

@@ -33,9 +33,16 @@
 
 namespace {
 
-constexpr int kRing = 8;     // spans whose hits a wave keeps in LDS (a power of two)
-constexpr int kQueue = 128;  // queue slots per wave (a power of two, >= 63 + 64)
-constexpr int kLag = 4;      // a queued piece is served at the latest when the wave is this many spans ahead of it (< kRing - 2)
+#ifndef FLX_COVER_RING
+#define FLX_COVER_RING 8
+#endif
+#ifndef FLX_COVER_LAG
+#define FLX_COVER_LAG 4
+#endif
+constexpr int kRing = FLX_COVER_RING;  // spans whose hits a wave keeps in LDS (a power of two)
+constexpr int kQueue = 128;            // queue slots per wave (a power of two, >= 63 + 64)
+constexpr int kLag = FLX_COVER_LAG;    // a queued piece is served at the latest when the wave is this many spans ahead of it (<= kRing - 3)
+static_assert((kRing & (kRing - 1)) == 0 && kLag >= 1 && kLag <= kRing - 3, "ring / lag");
 
 struct WaveLds {
     uint16_t ring[kRing][64];  // hits of span s at ring[s % kRing]: the known ones from phase A, replaced by phase B's for queued pieces

@@ -14,6 +14,7 @@ SEED = 20250919
 
 STREAM_LEN, STREAM_MU, STREAM_QUAL, STREAM_BASE = 1, 2, 3, 4
 STREAM_REF, STREAM_START, STREAM_ERATE, STREAM_SUB, STREAM_JUNK = 5, 6, 7, 8, 9
+STREAM_INDEL, STREAM_UNREL = 10, 11
 
 _M = np.uint64
 _C1 = _M(0x9E3779B97F4A7C15)
@@ -72,19 +73,44 @@ def bases_read(stream, read, start, length, seed=SEED):
     return np.frombuffer(b"ACGT", dtype=np.uint8)[idx.astype(np.int64)]
 
 
-def seq_read(read, length, ref, seed=SEED):
-    """k-mer-mode long read (uint8[length]) drawn from reference genome `ref` (uint8 array of ASCII ACGT); same
-    definition as k_synth_seq in csrc/synth.hip."""
+def seq_read(read, length, ref, seed=SEED, profile=0):
+    """k-mer-mode long read (uint8[length]) drawn from reference genome `ref` (uint8 array of ASCII ACGT); same definition as
+    flx_synth_seq_read in oracle/synth.h and k_synth_seq in csrc/synth.hip.  profile 0: SURVEY §8(d) (substitutions only);
+    1: a third of the errors insertions and a third deletions of 1-3 bases; 2: 30 % of the reads unrelated to the reference."""
     L = int(length)
     ref_len = len(ref)
     start = int(mix(seed, STREAM_START, read, 0) % _M(ref_len - L)) if ref_len > L else 0
     erate = int(mix(seed, STREAM_ERATE, read, 0) % _M(13))
     pos = np.arange(L, dtype=np.uint64)
-    out = ref[(start + pos.astype(np.int64)) % ref_len].copy()
+    if profile == 2 and int(mix(seed, STREAM_UNREL, read, 0) % _M(10)) < 3:
+        return bases_read(STREAM_BASE, read, 0, L, seed)
     h = mix(seed, STREAM_SUB, read, pos >> _M(2))
     f = (h >> (_M(16) * (pos & _M(3)))) & _M(0xFFFF)
-    sub = (f & _M(0xFF)) % _M(100) < _M(erate)
-    out[sub] = np.frombuffer(b"ACGT", dtype=np.uint8)[((f >> _M(8)) & _M(3)).astype(np.int64)][sub]
+    if profile == 1:
+        nblk = (L + 7) // 8
+        g = mix(seed, STREAM_INDEL, read, np.arange(nblk, dtype=np.uint64))
+        has = ((g & _M(0xFFFF)) % _M(300)) < _M(16 * erate)
+        dele = ((g >> _M(16)) & _M(1)).astype(bool)
+        size = 1 + ((g >> _M(17)) % _M(3)).astype(np.int64)
+        off = ((g >> _M(20)) & _M(7)).astype(np.int64)
+        sp = np.minimum(size, 8 - off)
+        consumed = np.where(~has, 8, np.where(dele, 8 + size, 8 - sp))
+        base0 = np.concatenate([[0], np.cumsum(consumed)[:-1]]) if nblk else np.zeros(0, np.int64)
+        b = (pos >> _M(3)).astype(np.int64)
+        j = (pos & _M(7)).astype(np.int64)
+        ins = has[b] & ~dele[b]
+        dl = has[b] & dele[b]
+        inserted = ins & (j >= off[b]) & (j < off[b] + sp[b])
+        r = base0[b] + j - np.where(ins & (j >= off[b] + sp[b]), sp[b], 0) + np.where(dl & (j >= off[b]), size[b], 0)
+        out = ref[(start + r) % ref_len].copy()
+        sub = (f & _M(0x3FFF)) % _M(300) < _M(erate)
+        out[sub] = np.frombuffer(b"ACGT", dtype=np.uint8)[((f >> _M(14)) & _M(3)).astype(np.int64)][sub]
+        rnd = bases_read(STREAM_BASE, read, 0, L, seed)
+        out[inserted] = rnd[inserted]
+    else:
+        out = ref[(start + pos.astype(np.int64)) % ref_len].copy()
+        sub = (f & _M(0xFF)) % _M(100) < _M(erate)
+        out[sub] = np.frombuffer(b"ACGT", dtype=np.uint8)[((f >> _M(8)) & _M(3)).astype(np.int64)][sub]
     if L > 3000 and int(mix(seed, STREAM_JUNK, read, 0) % _M(10)) < 3:
         js = 500 + int(mix(seed, STREAM_JUNK, read, 1) % _M(L - 2000))
         je = min(js + 800, L)

@@ -39,7 +39,7 @@ extern "C" {
  * set built from an assembly also keeps the assembly as a text + seed table (0.5 B per base + 10 B per distinct 16-mer of device
  * memory beside the 512 MiB bitmap, 1 GiB pair table and 2 + 2 MiB prefilters); when that memory cannot be had the set works without */
 /* 3 (round 5): + flx_last_kmer_fold_grid */
-/* 4 (round 6): + flx_last_kmer_cover */
+/* 4 (round 6): + flx_last_kmer_cover, flx_synth_seq_profile_dev */
 #define FLX_ABI_VERSION 4
 
 enum flx_status {
@@ -330,6 +330,12 @@ int flx_synth_qual_profile_dev(flx_ctx *ctx, uint64_t seed, int profile, void *d
 int flx_synth_seq_dev(flx_ctx *ctx, uint64_t seed, void *d_plane, uint64_t plane_bytes, const void *d_offsets,
                       const void *d_lengths, const void *d_read_ids, uint64_t n_reads, const void *d_ref,
                       uint64_t ref_len);
+/* the same with a profile: 0 = the SURVEY §8(d) definition (what flx_synth_seq_dev writes: substitutions only), 1 = "indels": the same
+ * per-read error rate, a third of the errors insertions and a third deletions of 1-3 bases, 2 = "unrelated": 30 % of the reads are
+ * random bases with no relation to the reference (oracle/synth.h: flx_synth_seq_read; bench.py's extras.c3_indels / .c3_unrelated) */
+int flx_synth_seq_profile_dev(flx_ctx *ctx, uint64_t seed, int profile, void *d_plane, uint64_t plane_bytes, const void *d_offsets,
+                              const void *d_lengths, const void *d_read_ids, uint64_t n_reads, const void *d_ref,
+                              uint64_t ref_len);
 
 #ifdef __cplusplus
 }

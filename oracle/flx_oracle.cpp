@@ -593,6 +593,10 @@ extern "C" void flo_synth_bases(uint64_t seed, uint64_t stream, uint64_t read, u
     for (uint64_t i = 0; i < length; ++i) out[i] = flx_synth_base(seed, stream, read, start + i);
 }
 
+extern "C" void flo_synth_seq(uint64_t seed, int profile, uint64_t read, int length, const uint8_t *ref, uint64_t ref_len, uint8_t *out) {
+    flx_synth_seq_read(seed, profile, read, length, ref, ref_len, out);
+}
+
 // ---------------------------------------------------------------------------
 // bench support ("port" CPU baseline): score + rank n synthetic Phred-only reads
 // with the restatement above, in memory, timed.  Used by bench.py only when the

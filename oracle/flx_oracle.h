@@ -102,6 +102,8 @@ int flo_rank_and_cut(uint64_t n, double *mean_q, double *window_q, const int32_t
 uint64_t flo_synth_mix(uint64_t seed, uint64_t stream, uint64_t read, uint64_t pos);
 void flo_synth_qual(uint64_t seed, uint64_t read, uint64_t length, uint8_t *out);
 void flo_synth_bases(uint64_t seed, uint64_t stream, uint64_t read, uint64_t start, uint64_t length, uint8_t *out);
+/* k-mer-mode long read of profile 0 / 1 / 2 (synth.h: flx_synth_seq_read) */
+void flo_synth_seq(uint64_t seed, int profile, uint64_t read, int length, const uint8_t *ref, uint64_t ref_len, uint8_t *out);
 
 int flo_bench_phred(uint64_t n, uint64_t seed, uint64_t first_read, int64_t target_bases, double *score_s,
                     double *rank_s, int64_t *total_bases_out, int64_t *kept_out);

@@ -105,6 +105,7 @@ def lib():
     L.flo_synth_mix.argtypes = [C.c_uint64] * 4
     L.flo_synth_qual.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
     L.flo_synth_bases.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.flo_synth_seq.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
     _lib = L
     return L
 

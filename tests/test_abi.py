@@ -72,7 +72,7 @@ def test_environment_switch_lists_match_the_sources(lib):
     csrc = glob.glob(os.path.join(ROOT, "filtlong_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "filtlong_amd", "csrc", "*.h"))
     cli = glob.glob(os.path.join(ROOT, "filtlong_amd", "cli", "*.h")) + glob.glob(os.path.join(ROOT, "filtlong_amd", "cli", "*.cpp"))
     ctx_src = open(os.path.join(ROOT, "filtlong_amd", "csrc", "flx_ctx.hip")).read()
-    known_lib = set(re.findall(r'"(FLX_[A-Z0-9_]+)"', ctx_src[ctx_src.index("kKnownEnv[] = {"):ctx_src.index("extern char **environ;")]))
+    known_lib = set(re.findall(r'"(FLX_[A-Z0-9_]+)"', ctx_src[ctx_src.index("kKnownEnv[] = {"):ctx_src.index("static const char *const kOwnPrefixes[]")]))
     hosts = {"FLX_DEVICE", "FLX_COMM_ID_FILE", "FLX_LIB_PATH", "FLX_NO_TORCH_PRELOAD"}
     assert _getenv_names(csrc) == known_lib
     own = set(re.findall(r'"(FLX_[A-Z]+_)"', ctx_src[ctx_src.index("kOwnPrefixes[] = {"):ctx_src.index("extern char **environ;")]))

@@ -334,3 +334,86 @@ def test_kmer_mode_properties(short_reads, size):
     assert np.allclose(r2["fs"].cpu().numpy()[:n2], want["final_score"], rtol=1e-12, atol=0, equal_nan=True)
     ks.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("profile", [1, 2], ids=["indels", "unrelated"])
+def test_kmer_read_profiles_whole_population(profile):
+    """Round-5 review, item 2: reads the SURVEY §8(d) generator does not make — profile 1: a third of the errors insertions and a
+    third deletions of 1-3 bases (every indel moves the read's diagonal in the set's text), profile 2: 30 % of the reads unrelated
+    to the reference (oracle/synth.h: flx_synth_seq_read).  10^5 reads / 10^9 bases against the 5 Mbp reference, assembly set and
+    --trim --split 500: the oracle re-scores the device's own plane bytes on every host core — every mean, window, first / last,
+    pass flag, child range and child score bit for bit (src/read.cpp:25-144) — and the three coverage kernels agree on every byte."""
+    import os
+    import torch
+    from filtlong_amd import _lib
+    ctx = api.Context(0)
+    dev = torch.device("cuda", 0)
+    n, ref_len = 100_000, 5_000_000
+    ref = synth.bases_read(synth.STREAM_REF, 0, 0, ref_len)
+    ks = api.Kmers(ctx)
+    oset = _oracle.KmerSet()
+    ks.add_assembly_fasta([ref.tobytes()])
+    oset.add_assembly([ref.tobytes()])
+    ks.finalize()
+    assert len(ks) == len(oset)
+    lengths = synth.lengths(n)
+    offsets = np.zeros(n, dtype=np.uint64)
+    pb = C.c_uint64()
+    ctx.L.flx_plane_layout(lengths.ctypes.data, n, offsets.ctypes.data, C.byref(pb))
+    order = api.length_order(lengths)
+    d_plane = torch.empty(pb.value, dtype=torch.uint8, device=dev)
+    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    d_len = torch.from_numpy(lengths).to(dev)
+    d_ord = torch.from_numpy(order.view(np.int32)).to(dev)
+    d_ref = torch.from_numpy(ref).to(dev)
+    d_ids = torch.arange(n, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx.synth_seq_dev(synth.SEED, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ids.data_ptr(), n,
+                      d_ref.data_ptr(), ref_len, profile=profile)
+    plane = d_plane.cpu().numpy()
+    for i in (0, 1, 17, n - 1):  # the device generator wrote what the host definition says
+        o, L = int(offsets[i]), int(lengths[i])
+        assert (plane[o:o + L] == synth.seq_read(i, L, ref, profile=profile)).all(), i
+    cap = 4 * n
+    t = {k: torch.zeros(sz, dtype=dt, device=dev) for k, sz, dt in (
+        ("mean", n, torch.float64), ("win", n, torch.float64), ("pass", n, torch.uint8), ("first", n, torch.int32),
+        ("last", n, torch.int32), ("coff", n + 1, torch.int64), ("crng", 2 * cap, torch.int32), ("cmean", cap, torch.float64),
+        ("cwin", cap, torch.float64), ("cpass", cap, torch.uint8))}
+    s = _lib.Scores()
+    s.mean_q, s.window_q, s.passed, s.first, s.last = (t["mean"].data_ptr(), t["win"].data_ptr(), t["pass"].data_ptr(),
+                                                      t["first"].data_ptr(), t["last"].data_ptr())
+    s.child_offsets, s.child_ranges, s.child_mean_q, s.child_window_q, s.child_passed = (
+        t["coff"].data_ptr(), t["crng"].data_ptr(), t["cmean"].data_ptr(), t["cwin"].data_ptr(), t["cpass"].data_ptr())
+    s.child_capacity = cap
+    for pkw in (dict(), dict(trim=True, split=500)):
+        params = api.make_params(**pkw)
+        w = _oracle.score_plane_mt(plane, offsets, lengths, _oracle.make_params(**pkw), kmerset=oset)
+        nc = w["n_children"]
+        if profile == 2 and not pkw:
+            assert 0.25 * n < int((w["mean_q"] < 1.0).sum()) < 0.35 * n  # the unrelated reads share (next to) no 16-mer with the reference
+        for cover in (None, "w", "v2"):
+            if cover:
+                os.environ["FLX_KMER_COVER"] = cover
+            try:
+                for v in t.values():
+                    v.fill_(0x5A if v.dtype == torch.uint8 else 0)
+                torch.cuda.synchronize()
+                assert ctx.score_kmer_dev(ks, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ord.data_ptr(), n,
+                                          params, s) == 0
+                torch.cuda.synchronize()
+                assert ctx.last_kmer_cover() == (cover or "q")
+            finally:
+                os.environ.pop("FLX_KMER_COVER", None)
+            tag = (profile, pkw, cover)
+            assert int(s.n_children) == nc, tag
+            assert (w["mean_q"].view(np.uint64) == t["mean"].cpu().numpy().view(np.uint64)).all(), tag
+            assert (w["window_q"].view(np.uint64) == t["win"].cpu().numpy().view(np.uint64)).all(), tag
+            assert (w["first"] == t["first"].cpu().numpy()).all() and (w["last"] == t["last"].cpu().numpy()).all(), tag
+            assert (w["passed"] == t["pass"].cpu().numpy()).all(), tag
+            assert (w["child_offsets"] == t["coff"].cpu().numpy().view(np.uint64)).all(), tag
+            assert (w["child_ranges"] == t["crng"].cpu().numpy()[:2 * nc].reshape(-1, 2)).all(), tag
+            assert (w["child_mean_q"].view(np.uint64) == t["cmean"].cpu().numpy()[:nc].view(np.uint64)).all(), tag
+            assert (w["child_window_q"].view(np.uint64) == t["cwin"].cpu().numpy()[:nc].view(np.uint64)).all(), tag
+            assert (w["child_passed"] == t["cpass"].cpu().numpy()[:nc]).all(), tag
+    ks.close()
+    ctx.close()

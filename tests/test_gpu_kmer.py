@@ -156,8 +156,8 @@ def test_device_seq_generator_matches_numpy(ctx):
     import torch
     from filtlong_amd import synth
     ref = synth.bases_read(synth.STREAM_REF, 0, 0, 60000)
-    lens = np.array([16, 200, 3500, 9000, 4097, 31], dtype=np.int32)
-    ids = np.array([0, 7, 11, 123456789, 3, 2], dtype=np.uint64)
+    lens = np.array([16, 200, 3500, 9000, 4097, 31, 1, 8, 9, 30000], dtype=np.int32)
+    ids = np.array([0, 7, 11, 123456789, 3, 2, 5, 6, 8, 40], dtype=np.uint64)
     plane, offsets, _ = api.pack_reads([b"\0" * int(L) for L in lens])
     d_plane = torch.zeros(plane.nbytes, dtype=torch.uint8, device="cuda")
     d_off = torch.from_numpy(offsets.astype(np.int64)).cuda()
@@ -165,12 +165,15 @@ def test_device_seq_generator_matches_numpy(ctx):
     d_ids = torch.from_numpy(ids.astype(np.int64)).cuda()
     d_ref = torch.from_numpy(ref).cuda()
     torch.cuda.synchronize()
-    ctx.synth_seq_dev(synth.SEED, d_plane.data_ptr(), plane.nbytes, d_off.data_ptr(), d_len.data_ptr(), d_ids.data_ptr(),
-                      len(lens), d_ref.data_ptr(), len(ref))
-    got = d_plane.cpu().numpy()
-    for i, L in enumerate(lens):
-        o = int(offsets[i])
-        assert (got[o:o + L] == synth.seq_read(int(ids[i]), int(L), ref)).all(), i
+    for profile in (0, 1, 2):  # SURVEY §8(d); a third of the errors insertions and a third deletions; 30 % unrelated reads
+        d_plane.fill_(0xEE)
+        ctx.synth_seq_dev(synth.SEED, d_plane.data_ptr(), plane.nbytes, d_off.data_ptr(), d_len.data_ptr(), d_ids.data_ptr(),
+                          len(lens), d_ref.data_ptr(), len(ref), profile=profile)
+        got = d_plane.cpu().numpy()
+        for i, L in enumerate(lens):
+            o = int(offsets[i])
+            assert (got[o:o + L] == synth.seq_read(int(ids[i]), int(L), ref, profile=profile)).all(), (profile, i)
+            assert (got[o + L:o + ((L + 15) & ~15)] == 0).all(), (profile, i)  # the row's padding
 
 
 def test_bloom_false_positive_rule(be):

@@ -27,3 +27,30 @@ def test_lengths_distribution():
     assert ln.min() >= 200 and ln.max() <= 200000
     assert abs(ln.mean() - 10000) < 100 and abs(ln.std() - 5000) < 150
     assert (synth.lengths(10, fixed=5000) == 5000).all()
+
+
+def test_seq_profiles_match_c():
+    """The k-mer-mode long reads, every profile (0: SURVEY §8(d), substitutions only; 1: a third of the errors insertions and a third
+    deletions of 1-3 bases; 2: 30 % of the reads unrelated to the reference): numpy == C, byte for byte — and the profiles do what they
+    say (the device generator is held against numpy in tests/test_gpu_kmer.py)."""
+    L = _oracle.lib()
+    ref = synth.bases_read(synth.STREAM_REF, 0, 0, 200000)
+    for profile in (0, 1, 2):
+        for read in (0, 1, 2, 3, 5, 17, 40, 41, 99, 1234567):
+            for n in (1, 7, 8, 9, 200, 3001, 12345):
+                out = np.zeros(n, dtype=np.uint8)
+                L.flo_synth_seq(synth.SEED, profile, read, n, ref.ctypes.data, len(ref), out.ctypes.data)
+                assert (out == synth.seq_read(read, n, ref, profile=profile)).all(), (profile, read, n)
+    # profile 1: indels shift the read against the reference (profile 0 never does)
+    shifted = 0
+    for read in range(30):
+        erate = int(synth.mix(synth.SEED, synth.STREAM_ERATE, read, 0) % np.uint64(13))
+        a, b = synth.seq_read(read, 2000, ref, profile=0), synth.seq_read(read, 2000, ref, profile=1)
+        if erate == 0:
+            assert (a == b).all()
+        elif (a[-200:] != b[-200:]).mean() > 0.5:
+            shifted += 1
+    assert shifted >= 15
+    # profile 2: about 30 % of the reads share nothing with their profile-0 form beyond chance
+    unrelated = sum((synth.seq_read(r, 1000, ref, profile=0) != synth.seq_read(r, 1000, ref, profile=2)).mean() > 0.5 for r in range(200))
+    assert 40 <= unrelated <= 80

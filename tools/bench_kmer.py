@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--trim-split", action="store_true", help="--trim --split 500 (C4)")
     ap.add_argument("--short-reads", action="store_true", help="reference = 40x of error-free 100 bp pairs (C4) instead of the assembly")
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--profile", type=int, default=0, help="read profile (filtlong_amd/synth.py: seq_read): 0 substitutions only, 1 indels, 2 30 %% unrelated reads")
     args = ap.parse_args()
     import torch
     from filtlong_amd import api, synth, _lib
@@ -61,7 +62,7 @@ def main():
     d_ids = torch.arange(n, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
     ctx.synth_seq_dev(synth.SEED, d_plane.data_ptr(), pb.value, d_off.data_ptr(), d_len.data_ptr(), d_ids.data_ptr(), n,
-                      d_ref.data_ptr(), args.ref_len)
+                      d_ref.data_ptr(), args.ref_len, profile=args.profile)
     cap = 4 * n
     t = {k: torch.zeros(sz, dtype=dt, device=dev) for k, sz, dt in (
         ("mean", n, torch.float64), ("win", n, torch.float64), ("pass", n, torch.uint8), ("first", n, torch.int32),
@@ -90,7 +91,7 @@ def main():
            "cover_ms": round(cover_ms / args.steps, 2), "fold_ms": round(fold_ms / args.steps, 2),
            "Glookups_per_s": round(lookups / (cover_ms / args.steps * 1e-3) / 1e9, 2), "Mbases_per_s": round(bases / el / 1e6, 1),
            "children": int(s.n_children), "mean_q_avg": float(t["mean"].mean().item()), "rc": rc,
-           "fold_on_integer_grid": ctx.last_kmer_fold_grid(), "locus": ctx.last_kmer_locus()}
+           "fold_on_integer_grid": ctx.last_kmer_fold_grid(), "locus": ctx.last_kmer_locus(), "cover_kernel": ctx.last_kmer_cover(), "profile": args.profile}
     print(json.dumps(out))
 
 
