@@ -310,8 +310,9 @@ class Batch:
         self.d_ids = torch.arange(first, first + n, dtype=torch.int64, device=dev)
 
 
-def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
-    """C3 / C4 on one GPU: k-mer scoring + reads2 gather + global stage; returns the result dictionary."""
+def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0, profile=0):
+    """C3 / C4 on one GPU: k-mer scoring + reads2 gather + global stage; returns the result dictionary.  profile: the reads (filtlong_amd/synth.py:
+    seq_read) — 0 = SURVEY §8(d), 1 = a third of the errors insertions and a third deletions, 2 = 30 % of the reads unrelated to the reference."""
     from filtlong_amd import api, synth, _lib
     ref = synth.bases_read(synth.STREAM_REF, 0, 0, REF_LEN)
     t0 = time.time()
@@ -327,7 +328,7 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
     d_ref = torch.from_numpy(ref).to(dev)
     torch.cuda.synchronize()
     ctx.synth_seq_dev(synth.SEED, b.d_plane.data_ptr(), b.plane_bytes, b.d_off.data_ptr(), b.d_len.data_ptr(),
-                      b.d_ids.data_ptr(), n, d_ref.data_ptr(), REF_LEN)
+                      b.d_ids.data_ptr(), n, d_ref.data_ptr(), REF_LEN, profile=profile)
     trim_split = cfg == "c4"
     cap = 4 * n if trim_split else 16
     t = {k: torch.zeros(sz, dtype=dt, device=dev) for k, sz, dt in (
@@ -382,7 +383,7 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
     req, req_src = None, None
     fpath = next((q for q in (os.path.join(ROOT, "profiles", r + "_kmer_requests.json") for r in ("r06", "r05", "r04")) if os.path.exists(q)), "")
     if fpath:
-        rec = json.load(open(fpath)).get(cfg)
+        rec = json.load(open(fpath)).get(cfg + {0: "", 1: "_indels", 2: "_unrelated"}[profile])
         if rec and rec.get("kernel") == cover_kernel and rec.get("kernel_source_sha16") == source_sha16(*KMER_SOURCES):
             req = {"far_requests": rec["far_requests_per_base"] * b.bases, "traffic_bytes": rec["traffic_bytes_per_base"] * b.bases,
                    "l2_hits": rec["l2_hit_requests_per_base"] * b.bases}
@@ -391,8 +392,9 @@ def run_kmer(ctx, torch, dev, cfg, n, steps, warmup, target_frac, fixed_len=0):
     algo_bytes = b.bases + 33 * n + 25 * nc  # L + 8 + 25 per read, 8 + 17 per child
     achieved = algo_bytes / (cover * 1e-3) / 1e9
     out = {
-        "workload": "%s: %s reads x gamma(k=4) mean 10 kbp from a 5 Mbp reference, %s, --target_bases %d" % (
-            cfg.upper(), "{:,}".format(n),
+        "workload": "%s%s: %s reads x gamma(k=4) mean 10 kbp from a 5 Mbp reference, %s, --target_bases %d" % (
+            cfg.upper(), {0: "", 1: " with indels (a third of the errors insertions, a third deletions of 1-3 bases: synth profile 1)",
+                          2: " with 30 % of the reads unrelated to the reference (synth profile 2)"}[profile], "{:,}".format(n),
             "-1/-2 short-read reference, --trim --split 500" if trim_split else "-a assembly", target),
         "value": round(b.bases / el / 1e6, 1), "unit": "Mbases/s", "ms_per_step": round(el * 1e3, 2),
         "bases": b.bases, "set_size": len(ks), "set_build_s_device": round(build_s, 2), "children": nc, "reads2": n2,
@@ -491,6 +493,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=("c2", "c2wide", "c3", "c4"), default="c2")
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (default: the C2 workload)")
+    ap.add_argument("--read-profile", type=int, default=0, choices=(0, 1, 2), help="--config c3 / c4: 0 = the SURVEY reads, 1 = with indels, 2 = 30 %% unrelated reads")
     ap.add_argument("--fixed-len", type=int, default=0, help="fixed read length (C1 uses 5000); 0 = gamma lengths")
     ap.add_argument("--target-frac", type=float, default=0.5, help="--target_bases as a fraction of all bases")
     ap.add_argument("--cpu-sample-reads", type=int, default=100_000)
@@ -562,7 +565,7 @@ def main():
     if args.config in ("c3", "c4"):
         if multi:
             sys.exit("bench.py --config %s is a single-GPU configuration" % args.config)
-        r = run_kmer(ctx, torch, dev, args.config, n, args.steps, args.warmup, args.target_frac, args.fixed_len)
+        r = run_kmer(ctx, torch, dev, args.config, n, args.steps, args.warmup, args.target_frac, args.fixed_len, profile=args.read_profile)
         info = ctx.device_info()
         out = {"metric": "Mbases/s scored+sorted", "value": r["value"], "unit": "Mbases/s", "n_gpus": 1, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
@@ -841,6 +844,17 @@ def main():
                     extras[cfg] = r
                 except Exception as e:  # an extra must not cost the headline line
                     extras[cfg] = {"error": repr(e)}
+                torch.cuda.empty_cache()
+            # (3b) C3 on reads the SURVEY §8(d) generator does not make (round-5 review, item 2) — beside C3, never instead of it:
+            #      insertions / deletions (every one moves the read's diagonal in the set's text), and reads unrelated to the reference
+            for key, prof in (("c3_indels", 1), ("c3_unrelated", 2)):
+                try:
+                    r = run_kmer(ctx, torch, dev, "c3", n, 2, 1, args.target_frac, profile=prof)
+                    if isinstance(extras.get("c3"), dict) and "ms_per_step" in extras["c3"]:
+                        r["ms_per_step_over_c3"] = round(r["ms_per_step"] / extras["c3"]["ms_per_step"], 3)
+                    extras[key] = r
+                except Exception as e:
+                    extras[key] = {"error": repr(e)}
                 torch.cuda.empty_cache()
             # (4) end to end (file -> stdout) through the C++ CLI, MEASURED IN THIS RUN: a 2 GB FASTQ of the same synthetic
             #     Phred workload, the drop-in binary and the reference binary on the same file, stdout compared byte for byte

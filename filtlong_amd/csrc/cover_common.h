@@ -70,6 +70,8 @@ struct CoverArgs {
     uint32_t *cov;
     const uint64_t *cov_off;
     int32_t *count, *first, *last;
+    // k_kmer_cover_q: a mark per slot of the processing order — the reads the first kernel hands to the one with a diagonal per lane
+    uint8_t *redo;
 };
 // (a pointer out of an integer: without the global address space on it every access would be a flat load with a 64-bit address
 // built in vector registers — one more vector instruction per access)

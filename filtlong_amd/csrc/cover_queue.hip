@@ -47,6 +47,10 @@ static_assert((kRing & (kRing - 1)) == 0 && kLag >= 1 && kLag <= kRing - 3, "rin
 struct WaveLds {
     uint16_t ring[kRing][64];  // hits of span s at ring[s % kRing]: the known ones from phase A, replaced by phase B's for queued pieces
     uint32_t q[5][kQueue];     // hi, lo, known | refuted << 16, 12-mers the text vouches for (positions -4 .. 15), id | left known << 31
+    // the text of the current span, staged for lanes that follow a diagonal of their own (reads with insertions / deletions, below):
+    // words W0 - 3 .. W0 + 65 at slots 0 .. 68, W0 = lane 0's word on the wave's diagonal
+    uint32_t tx[72], ty[72];
+    uint16_t tss[72];
 };
 
 // everything the lanes of a wave wrote to LDS is visible to its other lanes (a wave's LDS operations execute in order; this keeps
@@ -57,7 +61,149 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool HAS_PREFILTER>
+// ---- reads with insertions and deletions: a diagonal per lane (phase A of k_kmer_cover_q, below) ---------------------------------
+// Stages the span's text in LDS, searches every lane's own diagonal among the 33 shifts -16 .. +16 around the wave's, and compares
+// the lane's 32-base window with the text on its own diagonal and on its left neighbour's.  Returns what that adds to the lane's
+// known members / refutations / text-vouched 12-mers, the lane's shift and whether the search found one.
+struct LaneDiag {
+    uint32_t known_refuted;  // known | refuted << 16
+    uint32_t text12;
+    int dl;
+    int matched;
+};
+typedef __attribute__((address_space(3))) WaveLds *LdsPtr;
+__device__ __attribute__((noinline)) LaneDiag lane_diagonals(LdsPtr Sp, int lane, int e, uint32_t lo, uint32_t hi, uint32_t valid16, uint32_t twx,
+                                                             uint32_t twy, uint32_t ts, uint32_t xwx, uint32_t xwy, uint32_t xs, int c_dl) {
+    auto &S = *Sp;
+    uint32_t known = 0, refuted = 0, text12 = 0;
+    wave_lds_sync();
+    S.tx[lane + 3] = twx;
+    S.ty[lane + 3] = twy;
+    S.tss[lane + 3] = (uint16_t)ts;
+    if (lane < 5) {
+        const int slot_x = lane < 3 ? lane : lane + 64;
+        S.tx[slot_x] = xwx;
+        S.ty[slot_x] = xwy;
+        S.tss[slot_x] = (uint16_t)xs;
+    }
+    wave_lds_sync();
+    // the search: the text's 48 bases around my 16, aligned to them
+    int dl = 0;
+    bool matched;
+    {
+        const uint32_t x0 = S.tx[lane + 1], x1 = S.tx[lane + 2], x2 = S.tx[lane + 3], x3 = S.tx[lane + 4];
+        const uint32_t am = __builtin_amdgcn_alignbit(x0, x1, 2 * (15 - e));  // the 16 bases in front of mine on the wave's diagonal
+        const uint32_t a0 = __builtin_amdgcn_alignbit(x1, x2, 2 * (15 - e));  // mine
+        const uint32_t ap = __builtin_amdgcn_alignbit(x2, x3, 2 * (15 - e));  // the 16 behind
+        uint32_t best = 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < 33; ++r) {  // shift 0 first, then -1, +1, -2, ..: the smallest key wins, ties go to the nearer shift
+            const int sh = (r & 1) ? -((r + 1) >> 1) : (r >> 1);
+            const uint32_t t = sh == -16 ? am : sh < 0 ? __builtin_amdgcn_alignbit(am, a0, -2 * sh) : sh == 0 ? a0 : __builtin_amdgcn_alignbit(a0, ap, 32 - 2 * sh);
+            best = min(best, (uint32_t)__popc(lo ^ t) * 64u + (uint32_t)r);
+        }
+        // (6 of 32 bits: three or four substitutions; 16 random bases come that close at one of 33 shifts once in 80 lanes)
+        matched = (valid16 >> 15) != 0 && (best >> 6) <= 6u;
+        const int r = (int)(best & 63u);
+        const int mine = matched ? ((r & 1) ? -((r + 1) >> 1) : (r >> 1)) : 0x7f;
+        const int left = (int)flx_from_left((uint32_t)mine, (uint32_t)c_dl);
+        dl = matched ? mine : (left != 0x7f ? left : 0);  // (a lane without a diagonal of its own looks where its left neighbour does)
+    }
+    // my 32-base window against the text on the diagonal `diag + d`: adds to known / refuted / text12
+    auto compare_at = [&](int d) {
+        d = max(-16, min(16, d));
+        const int ed = e + d;                 // -16 .. 31
+        const int el = ed & 15;               // index of my last base in its word
+        const int j2 = lane + 3 + (ed >> 4);  // the slot of that word
+        const uint32_t w0x = S.tx[j2 - 2], w1x = S.tx[j2 - 1], w2x = S.tx[j2];
+        const uint32_t w0y = S.ty[j2 - 2], w1y = S.ty[j2 - 1], w2y = S.ty[j2];
+        const uint32_t w0s = S.tss[j2 - 2], w1s = S.tss[j2 - 1], w2s = S.tss[j2];
+        const uint32_t t_own = __builtin_amdgcn_alignbit(w1x, w2x, 2 * (15 - el));
+        const uint32_t t_hi = __builtin_amdgcn_alignbit(w0x, w1x, 2 * (15 - el));
+        // per-base flags of the window's 32 bases: bit i = base i (base 0 = the first of the 16 in front of mine)
+        auto flags32 = [&](uint32_t f0, uint32_t f1, uint32_t f2) -> uint32_t {
+            const uint64_t f = (uint64_t)((f0 & 0xffffu) | (f1 << 16)) | ((uint64_t)(f2 & 0xffffu) << 32);
+            return (uint32_t)(f >> (el + 1));
+        };
+        const uint32_t b32 = flags32(w0y, w1y, w2y);                    // base i is the first of a piece
+        const uint32_t u32 = flags32(w0y >> 16, w1y >> 16, w2y >> 16);  // a unique 13-mer starts at base i
+        const uint32_t s32 = flags32(w0s, w1s, w2s);                    // the text's 16 bases from base i on are S1
+        auto mismatches = [](uint32_t x) -> uint32_t {  // bit j: base j of the 16 differs
+            uint32_t m = (x | (x >> 1)) & 0x55555555u;
+            m = (m | (m >> 1)) & 0x33333333u;
+            m = (m | (m >> 2)) & 0x0f0f0f0fu;
+            m = (m | (m >> 4)) & 0x00ff00ffu;
+            m = (m | (m >> 8)) & 0xffffu;
+            return __brev(m) >> 16;
+        };
+        const uint32_t z = ~(mismatches(hi ^ t_hi) | (mismatches(lo ^ t_own) << 16));  // bit i: base i of the window matches
+        uint32_t r = z & (z >> 1);
+        r &= r >> 2;
+        r &= r >> 4;
+        r &= r >> 8;  // bit i: bases i .. i + 15 match
+        uint32_t q = ~b32 >> 1;  // bit i: no piece starts at base i + 1
+        q &= q >> 1;
+        q &= q >> 2;
+        q &= q >> 4;
+        q &= q >> 7;  // bit i: none at i + 1 .. i + 15 — the 16 bases from i on lie in one piece of the text
+        {
+            uint32_t m12 = z & (z >> 1);
+            m12 &= m12 >> 2;
+            m12 &= m12 >> 4;
+            m12 &= m12 >> 4;  // bit i: bases i .. i + 11 match
+            uint32_t q12 = ~b32 >> 1;
+            q12 &= q12 >> 1;
+            q12 &= q12 >> 2;
+            q12 &= q12 >> 4;
+            q12 &= q12 >> 3;  // bit i: no piece starts at i + 1 .. i + 11
+            text12 |= ((m12 & q12) >> 5) & 0xffffu;
+        }
+        r &= q;
+        known |= (r >> 1) & valid16;
+        uint32_t g = z & (z >> 1);
+        g &= g >> 2;
+        g &= g >> 4;
+        g &= g >> 5;  // bit i: bases i .. i + 12 match the text
+        g &= u32;     // ... and that 13-mer occurs nowhere else
+        g |= g >> 1;
+        g |= g >> 2;
+        uint32_t one = ~z, two;  // S1: exactly one of the 16 bases from i on differs (saturating two-bit counter per window)
+        two = one & (one >> 1);
+        one ^= one >> 1;
+        {
+            const uint32_t t2 = two | (two >> 2) | (one & (one >> 2));
+            one = (one ^ (one >> 2)) & ~t2;
+            two = t2;
+        }
+        {
+            const uint32_t t2 = two | (two >> 4) | (one & (one >> 4));
+            one = (one ^ (one >> 4)) & ~t2;
+            two = t2;
+        }
+        {
+            const uint32_t t2 = two | (two >> 8) | (one & (one >> 8));
+            one = (one ^ (one >> 8)) & ~t2;
+        }
+        one &= q & s32;
+        refuted |= (((g & ~r) | one) >> 1) & valid16;
+    };
+    compare_at(dl);
+    const int dleft = (int)flx_from_left((uint32_t)dl, (uint32_t)c_dl);
+    if (__any(dleft != dl)) compare_at(dleft);  // windows that begin in front of an indel lie on the left neighbour's diagonal
+    LaneDiag out;
+    out.known_refuted = known | (refuted << 16);
+    out.text12 = text12;
+    out.dl = dl;
+    out.matched = matched ? 1 : 0;
+    return out;
+}
+
+// INDELS = false: the kernel every read goes through.  A read whose diagonal jumps by a few bases — a seed found within 64 bases of
+// the diagonal the wave already had: an insertion or a deletion, not junk (whose seeds fail) and not the same locus behind
+// substitutions (whose seed finds the same diagonal) — is handed over: the wave drops it and appends it to a list (a.redo).  INDELS = true runs on that list afterwards and lets every lane follow a diagonal of its own (lane_diagonals
+// above).  Two kernels of one source because the lane-diagonal code inside the span loop cost the loop 21 spilled vector registers
+// and C3 a quarter of its speed (a cold call instead: a fifth — measured, profiles/r06_microbench.txt).
+template <bool HAS_PREFILTER, bool INDELS>
 __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_q(const CoverArgs a) {
     __shared__ WaveLds lds_all[FLX_COVER_THREADS / 64];
     WaveLds &S = lds_all[threadIdx.x >> 6];
@@ -74,7 +220,12 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
     const int lane = threadIdx.x & 63;
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t slot_r = wave0; slot_r < n_reads; slot_r += n_waves) {
+    // INDELS: the wave takes 64 slots of the processing order at a time and serves the ones the first kernel has marked
+    for (uint64_t slot_0 = wave0 * (INDELS ? 64 : 1); slot_0 < n_reads; slot_0 += n_waves * (INDELS ? 64 : 1)) {
+      unsigned long long marked = 1ull;
+      if (INDELS) marked = __ballot(slot_0 + (uint64_t)lane < n_reads && a.redo[slot_0 + (uint64_t)lane] != 0);
+      for (; marked; marked &= marked - 1) {
+        const uint64_t slot_r = slot_0 + (INDELS ? (uint64_t)(__ffsll((long long)marked) - 1) : 0ull);
         const uint32_t rid = __builtin_amdgcn_readfirstlane(order ? order[slot_r] : (uint32_t)slot_r);
         const int L = __builtin_amdgcn_readfirstlane(lengths[rid]);
         const uint8_t *seq = plane + offsets[rid];
@@ -91,6 +242,11 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
         uint2 tw = make_uint2(0, 0xffffu), tw_next = make_uint2(0, 0xffffu);
         uint32_t ts = 0, ts_next = 0, c_ts = 0;  // S1 bits of those text words (kmerset.h: safe1); lane 63's for the next span
         const bool has_s1 = a.loc.safe1 != nullptr;
+        // a read with insertions / deletions: every lane follows a diagonal of its own (below); c_dl = lane 63's shift against the
+        // wave's diagonal as the next span sees it
+        bool indel_mode = false;
+        int c_dl = 0;
+        bool handed_over = false;  // INDELS = false: a seed was found within 64 bases of the diagonal the wave had
         // the queue: q_head = slot of the oldest entry, q_n = entries; fin = the next span to turn into coverage
         int q_head = 0, q_n = 0, fin = 0;
 
@@ -110,6 +266,15 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
         };
         auto safe_word = [&](long long dg, int base) -> uint32_t {  // the S1 bits of that word
             return has_s1 ? (uint32_t)*(FLX_GLOBAL_PTR(uint16_t))(FLX_KARG_PTR(uint8_t, loc.safe1) + (uint32_t)(word_index(dg, base) * 2u)) : 0u;
+        };
+
+        // the five words around the span's 64 that lanes on a shifted diagonal reach into: lanes 0..2 fetch W0 - 3 .. W0 - 1, lanes 3 and 4
+        // W0 + 64 and W0 + 65 (the others fetch a clamped word nobody uses)
+        auto edge_index = [&](long long dg, int base) -> uint32_t {
+            long long u = ((dg + base + 15) >> 4) + (long long)kLocusPad;
+            u = u < -64 ? -64 : (u > (long long)loc_n_alloc ? (long long)loc_n_alloc : u);
+            const int w = (int)u + (lane < 3 ? lane - 3 : lane + 61);
+            return (uint32_t)max(0, min(w, (int)loc_n_alloc - 1));
         };
 
         // hits of span sp (complete in the ring) -> coverage bits, counts, row words
@@ -170,6 +335,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             // x.C.y = the 13 bases ending at position 2k - 3.  Present without a lookup: what the text vouches for, and the 12-mers
             // ending at [lowest known member - 4, highest]: those inside a member are present, the others only make candidates
             // between two confirmed members, which are never asked. ----
+            const bool adj = act && flx_from_left(id, 0x7ffffff0u) + 1u == id;  // the entry in front of this one is its left neighbour in the read
             const uint32_t V20 = (valid12 << 4) | ((act && id != 0) ? 0xFu : 0u);
             uint32_t P = 0xFFFFFu;
             if (HAS_PREFILTER) {
@@ -215,11 +381,19 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     d |= d >> 2;
                     return d | (x >> 4);
                 };
+                // Where the piece in front of this one is the entry in front of it (`adj`), the positions -4 .. -1 are that piece's 12 .. 15:
+                // it fetches them (what this one wants of them travels left, the bits come back), so that a pair shared by two queued
+                // neighbours is looked up once (measured: a tenth of the kernel's L2 requests were such doubles)
+                const uint32_t radj = flx_from_right(adj ? 1u : 0u, 0u);  // the entry behind this one is its right neighbour in the read
                 {
                     // round 1 leaves out the pairs whose 12-mers only lie in 16-mers the text has refuted (U13, S1)
                     const uint32_t alive = valid16 & (~refuted | known);
                     const uint32_t w1 = need20 & 0x33333u & dep5(alive);
-                    if (__any(w1 != 0)) P = fetch(w1, 0);
+                    const uint32_t from_r = flx_from_right(w1 & 0x3u, 0u);
+                    const uint32_t mine = (adj ? (w1 & ~0x3u) : w1) | (radj ? (from_r << 16) : 0u);
+                    if (__any(mine != 0)) P = fetch(mine, 0);
+                    const uint32_t from_l = flx_from_left(P >> 16, 0xFu);
+                    if (adj) P = (P & ~0x3u) | (from_l & 0x3u);
                 }
                 if (__any((need20 & 0xCCCCCu) != 0)) {
                     const uint32_t v1 = P & V20;
@@ -228,7 +402,11 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     alive &= v1 >> 4;  // bit j: the five 12-mers of the window ending at position j are present so far
                     alive &= valid16 & ~refuted;
                     const uint32_t w2 = need20 & 0xCCCCCu & dep5(alive);
-                    if (__any(w2 != 0)) P &= fetch(w2, 1);
+                    const uint32_t from_r = flx_from_right(w2 & 0xCu, 0u);
+                    const uint32_t mine = (adj ? (w2 & ~0xCu) : w2) | (radj ? (from_r << 16) : 0u);
+                    if (__any(mine != 0)) P &= fetch(mine, 1);
+                    const uint32_t from_l = flx_from_left(P >> 16, 0xFu);
+                    if (adj) P = (P & ~0xCu) | (from_l & 0xCu);
                 }
             }
             P &= V20;
@@ -278,7 +456,6 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             // the left neighbour's last position: a known member (exact, from phase A), or — where the left neighbour is the entry in
             // front of this one — what its own search finds.  First step on a BET: a candidate there is taken for a member (it is the
             // top of that piece's search, so its answer arrives with this round's), corrected right after.
-            const bool adj = act && flx_from_left(id, 0x7ffffff0u) + 1u == id;
             int top, bot;
             {
                 const uint32_t lcand = flx_from_left(cand >> 15, 0u);
@@ -305,7 +482,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             const int p0 = (sp << 10) + lane * 16;
             uint4 raw_next = make_uint4(0, 0, 0, 0);
             if (p0 + 1024 < L) raw_next = flx_plane16(seq + (uint32_t)(p0 + 1024));
-            if (have_diag && sp + 1 < n_spans) {
+            if (have_diag && !indel_mode && sp + 1 < n_spans) {  // (indel mode: the diagonal moves at the end of the span, the words are fetched there)
                 tw_next = text_word(diag, (sp << 10) + 1024);
                 ts_next = safe_word(diag, (sp << 10) + 1024);
             }
@@ -325,6 +502,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             uint32_t known = 0, refuted = 0;  // refuted: not a text match, but holds a text-matching 13-mer that occurs nowhere else (U13), or is one substitution away from a text window without such members (S1)
             uint32_t text12 = 0;              // bit j: the 12 bases ending at my position j match the text inside one piece: that 12-mer IS present
             {
+                int mm_cnt = 0;  // my bases that differ from the text on the wave's diagonal (last comparison)
                 // my 16 bases against the text along `diag` (tw = the word that holds the last of them): adds to known / refuted
                 auto compare = [&]() {
                     const int e = (int)((diag + 15) & 15);  // index of my last base in my word (p0 is a multiple of 16: the same for every lane)
@@ -345,6 +523,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     m = (m | (m >> 4)) & 0x00ff00ffu;
                     m = (m | (m >> 8)) & 0xffffu;
                     const uint32_t mml = __brev(m) >> 16;  // bit j: my base j differs from the text
+                    mm_cnt = __popc(mml);
                     const uint32_t mb0 = carry_ok ? c_mb : 0xffffffffu, us0 = carry_ok ? c_us : 0u;
                     const uint32_t mmh = flx_from_left(mml, mb0 & 0xffffu), bh = flx_from_left(b_own, mb0 >> 16);
                     const uint32_t uh = flx_from_left(u_own, us0 & 0xffffu), sh = flx_from_left(s_own, us0 >> 16);
@@ -417,7 +596,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 // is known at all; a seed on another diagonal is compared in turn, what it confirms adds to what is known.
                 const unsigned long long whole = __ballot((valid16 >> 15) != 0);  // lanes that hold a whole 16-mer of the read
                 bool again = have_diag;
-                for (int seeds_left = FLX_LOCUS_SEEDS;;) {
+                for (int seeds_left = FLX_LOCUS_SEEDS; !indel_mode;) {
                     if (again) compare();
                     const unsigned long long kn = __ballot(known != 0);
                     const unsigned long long tail = kn ? whole & ~((2ull << (63 - __clzll(kn))) - 1ull) : whole;
@@ -452,6 +631,10 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     const int src = __ffsll(found) - 1;
                     const long long nd = (long long)__builtin_amdgcn_readlane(tpos, src) - (long long)((sp << 10) + src * 16);
                     if (have_diag && nd == diag) break;  // the same locus: what is missing are mismatches, not the diagonal
+                    if (!INDELS && have_diag && nd - diag >= -64 && nd - diag <= 64) {
+                        handed_over = true;  // the diagonal has moved by a few bases: an insertion or a deletion, more will follow
+                        break;
+                    }
                     diag = nd;
                     have_diag = true;
                     carry_ok = false;
@@ -463,7 +646,62 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     }
                     again = true;
                 }
+
+                // ---- reads with insertions and deletions: a diagonal per lane (round 6; the round-5 review's item 2).  One diagonal
+                // per wave, re-seeded four times per span, follows substitutions and the odd junk block; a nanopore read has an indel
+                // every 20-50 bases, each one moves the diagonal by a base or three, and behind the first of a span everything went
+                // through the prefilter and the exact table (3x the time, measured: profiles/r06_microbench.txt).  So where lanes that
+                // hold a whole 16-mer look nothing like the text on the wave's diagonal (>= 6 of 16 bases differ: a wrong diagonal, not
+                // substitutions), every lane SEARCHES its own: its 16 bases against the text at the 33 shifts -16 .. +16 around the
+                // wave's diagonal (three funnel shifts align the four words around it, then one funnel shift, one XOR and one bit
+                // count per shift: no request), takes the closest (<= 8 differing bits) and compares its 32-base window with the text
+                // there and on its left neighbour's diagonal — known members, U13, S1 and text-vouched 12-mers exactly as on the wave's
+                // diagonal: every one of those statements is about the TEXT at that place and true whatever the read's real locus is.
+                // The text words come out of LDS (staged once per span) because a lane's window then starts in any of five words.  The
+                // wave's diagonal moves on with the last lane that found one. ----
+                const bool was_indel_mode = indel_mode;
+                bool lane_diag = INDELS && indel_mode;
+                if (INDELS && !indel_mode && have_diag) lane_diag = __popcll(__ballot(((valid16 >> 15) != 0) && mm_cnt >= 6)) >= 4;
+                if (INDELS && lane_diag && have_diag) {
+                    const int e = (int)((diag + 15) & 15);
+                    const uint32_t xi = edge_index(diag, sp << 10);
+                    uint2 xw = make_uint2(0, 0xffffu);
+                    uint32_t xs = 0;
+                    if (lane < 5) {
+                        const uint64_t tv = *(FLX_GLOBAL_PTR(uint64_t))(FLX_KARG_PTR(uint8_t, loc.text) + (uint32_t)(xi * 8u));
+                        xw = make_uint2((uint32_t)tv, (uint32_t)(tv >> 32));
+                        if (has_s1) xs = (uint32_t)*(FLX_GLOBAL_PTR(uint16_t))(FLX_KARG_PTR(uint8_t, loc.safe1) + (uint32_t)(xi * 2u));
+                    }
+                    // (a function of its own, not inlined: inside the span loop its registers cost the loop 21 spilled vector registers
+                    // and C3 a quarter of its speed — measured; the call is on the cold side of a wave-uniform branch)
+                    const LaneDiag ld = lane_diagonals((LdsPtr)&S, lane, e, lo, hi, valid16, tw.x, tw.y, ts, xw.x, xw.y, xs, c_dl);
+                    known |= ld.known_refuted & 0xffffu;
+                    refuted |= ld.known_refuted >> 16;
+                    text12 |= ld.text12;
+                    const int dl = ld.dl;
+                    const bool matched = ld.matched != 0;
+                    // the wave's diagonal follows the last lane that found one; a span in which (next to) none did goes back to the seeds
+                    const unsigned long long got = __ballot(matched);
+                    const bool shifted = __popcll(__ballot(matched && dl != 0)) >= 4;
+                    if (!indel_mode && shifted) indel_mode = true;
+                    if (indel_mode && __popcll(got) < 4) indel_mode = false;
+                    int step = 0;
+                    if (indel_mode && got) step = (int)__builtin_amdgcn_readlane((uint32_t)dl, 63 - __clzll(got));
+                    c_dl = max(-16, min(16, (int)__builtin_amdgcn_readlane((uint32_t)dl, 63) - step));
+                    carry_ok = false;  // (the carries of the wave-diagonal comparison are not kept up here)
+                    if (was_indel_mode || indel_mode) {  // (the span's own prefetch was left out, or the diagonal has moved)
+                        diag += step;
+                        if (sp + 1 < n_spans) {
+                            tw_next = text_word(diag, (sp << 10) + 1024);
+                            ts_next = safe_word(diag, (sp << 10) + 1024);
+                        }
+                    }
+                } else {
+                    c_dl = 0;
+                }
             }
+
+            if (!INDELS && handed_over) break;  // (wave-uniform: the read goes to the other kernel, whatever was written for it is written again)
 
             // ---- phase A ends: the hits the text knows, and the pieces that have a question left ----
             // The piece's window of 17 positions (bit 0 = the left neighbour's last position): a candidate is only ever asked when it
@@ -519,6 +757,11 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 while (fin + 1 < done) finalize(fin++);
             }
         }
+        if (!INDELS && handed_over) {
+            if (lane == 0) a.redo[slot_r] = 1;  // (a mark per slot, not a list: a million appends to one counter took 10 ms)
+            wave_lds_sync();
+            continue;
+        }
         while (q_n > 0) serve(q_n < 64 ? q_n : 64);
         wave_lds_sync();
         while (fin < n_spans) finalize(fin++);
@@ -534,16 +777,25 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             last[rid] = cnt ? lst : -1;
         }
         wave_lds_sync();  // (the next read's first span must not overtake this read's last ring reads)
+      }
     }
 }
 
 }  // namespace
 
 int flx_cover_queue_launch(flx_ctx *ctx, const CoverArgs &args, bool has_prefilter, unsigned grid) {
-    if (has_prefilter)
-        hipLaunchKernelGGL((k_kmer_cover_q<true>), dim3(grid), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
-    else
-        hipLaunchKernelGGL((k_kmer_cover_q<false>), dim3(grid), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
+    if (!args.redo) return flx_fail(ctx, FLX_ERR_INVALID, "cover kernel: no room for the marks of reads with insertions / deletions");
+    FLX_HIP(ctx, hipMemsetAsync(args.redo, 0, args.n_reads, ctx->stream));
+    // every read; then the reads the first kernel handed over (marked on the device: no host round trip, a grid of resident
+    // workgroups walks the marks 64 at a time)
+    const unsigned grid2 = std::min(grid, 8u * 256u);
+    if (has_prefilter) {
+        hipLaunchKernelGGL((k_kmer_cover_q<true, false>), dim3(grid), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
+        hipLaunchKernelGGL((k_kmer_cover_q<true, true>), dim3(grid2), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
+    } else {
+        hipLaunchKernelGGL((k_kmer_cover_q<false, false>), dim3(grid), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
+        hipLaunchKernelGGL((k_kmer_cover_q<false, true>), dim3(grid2), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
+    }
     FLX_HIP(ctx, hipGetLastError());
     return FLX_OK;
 }

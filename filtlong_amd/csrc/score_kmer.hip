@@ -1512,7 +1512,7 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const char *fold_env0 = getenv("FLX_KMER_FOLD");
     const bool inline_children = want_children && !(params->split_set && params->split < 32) && !fold_env0;  // (the one-lane-per-child path)
-    const size_t small_bytes = 2 * up((n_reads + 1) * 8) + 3 * up(n_reads * 4) + up((n_reads + 1) * 4) + up(scan_ws) +
+    const size_t small_bytes = 2 * up((n_reads + 1) * 8) + 3 * up(n_reads * 4) + up((n_reads + 1) * 4) + up(scan_ws) + up(n_reads) +
                                (inline_children ? up(n_reads * (size_t)kInlineChildren * 8) + up(64) : 0);
     void *small = nullptr;
     FLX_CHECK(flx_workspace(ctx, 0, small_bytes, &small));
@@ -1525,6 +1525,7 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     int32_t *d_last_tmp = (int32_t *)carve(n_reads * 4);
     uint32_t *d_nchild = (uint32_t *)carve((n_reads + 1) * 4);
     void *d_scanws = carve(scan_ws);
+    uint8_t *d_redo = (uint8_t *)carve(n_reads);  // cover_queue.hip: marks of the reads handed to the kernel with a diagonal per lane
     int32_t *d_inline = inline_children ? (int32_t *)carve(n_reads * (size_t)kInlineChildren * 8) : nullptr;
     unsigned int *d_overflow = inline_children ? (unsigned int *)carve(64) : nullptr;
     int32_t *first = out->first ? out->first : d_first_tmp, *last = out->last ? out->last : d_last_tmp;
@@ -1556,7 +1557,7 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
             memset(&none, 0, sizeof none);
             ctx->last_kmer_locus = lp != nullptr;
             const uint8_t *pre11 = flx_kmerset_pre11(set);
-            CoverArgs ca = {d_plane, d_offsets, d_lengths, d_order, n_reads, flx_kmerset_exact15(set), pre11, lp ? *lp : none, (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first, last};
+            CoverArgs ca = {d_plane, d_offsets, d_lengths, d_order, n_reads, flx_kmerset_exact15(set), pre11, lp ? *lp : none, (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first, last, d_redo};
             ctx->last_kmer_cover = (lp && !wave_cover) ? "q" : "w";
             if (lp && !wave_cover) {
                 const int rc = flx_cover_queue_launch(ctx, ca, pre11 != nullptr, wgrid);

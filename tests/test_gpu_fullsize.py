@@ -390,7 +390,7 @@ def test_kmer_read_profiles_whole_population(profile):
         w = _oracle.score_plane_mt(plane, offsets, lengths, _oracle.make_params(**pkw), kmerset=oset)
         nc = w["n_children"]
         if profile == 2 and not pkw:
-            assert 0.25 * n < int((w["mean_q"] < 1.0).sum()) < 0.35 * n  # the unrelated reads share (next to) no 16-mer with the reference
+            assert 0.25 * n < int((w["mean_q"] < 15.0).sum()) < 0.35 * n  # the unrelated reads: a random 16-mer is a member once in 430 (5 Mbp), ~4 % of their bases are covered
         for cover in (None, "w", "v2"):
             if cover:
                 os.environ["FLX_KMER_COVER"] = cover
