@@ -598,7 +598,10 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                 bool again = have_diag;
                 for (int seeds_left = FLX_LOCUS_SEEDS; !indel_mode;) {
                     if (again) compare();
-                    const unsigned long long kn = __ballot(known != 0);
+                    // (a lane is ON the diagonal when it holds a known member — or when its 16 bases differ from the text in fewer than 6
+                    // places: substitutions, not a wrong diagonal.  Round 5 looked at known members only, and a read with 10 % substitutions
+                    // re-seeded in every span to find the diagonal it already had: a third of the kernel's seed lookups)
+                    const unsigned long long kn = __ballot(known != 0 || (again && mm_cnt < 6 && (valid16 >> 15) != 0));
                     const unsigned long long tail = kn ? whole & ~((2ull << (63 - __clzll(kn))) - 1ull) : whole;
                     if (seeds_left-- == 0 || __popcll(tail) < FLX_LOCUS_TAIL) break;
                     bool tries;
@@ -606,7 +609,8 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                         const unsigned long long t1 = tail & (tail - 1), t2 = t1 & (t1 - 1);  // without its first lane / first two lanes
                         tries = lane == __ffsll(t1) - 1 || lane == __ffsll(t2) - 1;
                     } else {
-                        tries = (lane & 7) == 3 && ((whole >> lane) & 1ull);
+                        // (two lanes at the first attempt, eight from the second on: half the reads' first seeds are exact)
+                        tries = (lane & (seeds_left == FLX_LOCUS_SEEDS - 1 ? 31 : 7)) == 3 && ((whole >> lane) & 1ull);
                     }
                     uint32_t tpos = kLocusEmpty;
                     if (tries) {
@@ -627,7 +631,13 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                         }
                     }
                     const unsigned long long found = __ballot(tpos != kLocusEmpty);
-                    if (!found) break;
+                    if (!found) {
+                        if (!kn && seeds_left == FLX_LOCUS_SEEDS - 1) {  // the two first lanes held no exact 16-mer: eight more
+                            again = false;
+                            continue;
+                        }
+                        break;
+                    }
                     const int src = __ffsll(found) - 1;
                     const long long nd = (long long)__builtin_amdgcn_readlane(tpos, src) - (long long)((sp << 10) + src * 16);
                     if (have_diag && nd == diag) break;  // the same locus: what is missing are mismatches, not the diagonal
