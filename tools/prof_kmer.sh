@@ -10,7 +10,13 @@ N=${1:-1000000}
 CFGS=${2:-"c3 c4"}
 LIGHT=${3:-}
 for cfg in $CFGS; do
-B="python $R/bench.py --config $cfg --reads $N --steps 1 --warmup 0 --no-cpu-baseline"
+# (c3_indels / c3_unrelated: C3 on the read profiles of round 6 — filtlong_amd/synth.py: seq_read, profile 1 / 2)
+case $cfg in
+  *_indels) BCFG="${cfg%_indels} --read-profile 1" ;;
+  *_unrelated) BCFG="${cfg%_unrelated} --read-profile 2" ;;
+  *) BCFG=$cfg ;;
+esac
+B="python $R/bench.py --config $BCFG --reads $N --steps 1 --warmup 0 --no-cpu-baseline"
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/f_$cfg -o p -- $B > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $OUT/t_$cfg -o p -- $B > /dev/null 2>&1
 if [ -z "$LIGHT" ]; then
