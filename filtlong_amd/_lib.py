@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "flx_pipeline_create", "flx_pipeline_reserve", "flx_pipeline_next_buffer", "flx_pipeline_submit", "flx_pipeline_finish", "flx_pipeline_destroy",
     "flx_comm_init", "flx_comm_destroy", "flx_comm_rank", "flx_comm_world", "flx_comm_sum_u64", "flx_kmerset_create", "flx_kmerset_destroy", "flx_kmerset_add_assembly",
     "flx_kmerset_add_short_reads", "flx_kmerset_finalize", "flx_kmerset_size", "flx_kmerset_contains",
-    "flx_last_phred_kernel", "flx_last_kmer_locus", "flx_last_kmer_fold_grid", "flx_last_kmer_cover", "flx_synth_qual_dev", "flx_synth_qual_profile_dev", "flx_synth_seq_dev", "flx_synth_seq_profile_dev",
+    "flx_last_phred_kernel", "flx_last_kmer_locus", "flx_last_kmer_fold_grid", "flx_last_kmer_cover", "flx_last_kmer_handed_over", "flx_synth_qual_dev", "flx_synth_qual_profile_dev", "flx_synth_seq_dev", "flx_synth_seq_profile_dev",
 ]
 
 
@@ -160,6 +160,8 @@ def load():
     L.flx_last_kmer_fold_grid.restype = i32
     L.flx_last_kmer_cover.argtypes = [vp]
     L.flx_last_kmer_cover.restype = C.c_char_p
+    L.flx_last_kmer_handed_over.argtypes = [vp]
+    L.flx_last_kmer_handed_over.restype = i64
     L.flx_synth_qual_dev.argtypes = [vp, u64, vp, u64, vp, vp, vp, u64]
     L.flx_synth_qual_profile_dev.argtypes = [vp, u64, C.c_int, vp, u64, vp, vp, vp, u64]
     L.flx_synth_seq_dev.argtypes = [vp, u64, vp, u64, vp, vp, vp, u64, vp, u64]

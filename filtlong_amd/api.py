@@ -358,6 +358,10 @@ class Context:
         """"q", "w" or "v2": the coverage kernel the last k-mer scoring call launched."""
         return self.L.flx_last_kmer_cover(self.h).decode()
 
+    def last_kmer_handed_over(self):
+        """Reads of the last k-mer scoring call that went to the kernel with a diagonal per lane (insertions / deletions)."""
+        return int(self.L.flx_last_kmer_handed_over(self.h))
+
     def last_kmer_locus(self):
         return bool(self.L.flx_last_kmer_locus(self.h))
 

@@ -4,6 +4,7 @@
 #include <numeric>
 
 #include "flx_internal.h"
+#include <vector>
 
 static std::string g_create_error;
 
@@ -31,6 +32,17 @@ extern "C" const char *flx_last_phred_kernel(const flx_ctx *ctx) { return ctx ? 
 extern "C" int flx_last_kmer_locus(const flx_ctx *ctx) { return ctx && ctx->last_kmer_locus ? 1 : 0; }
 extern "C" int flx_last_kmer_fold_grid(const flx_ctx *ctx) { return ctx && ctx->last_kmer_fold_grid ? 1 : 0; }
 extern "C" const char *flx_last_kmer_cover(const flx_ctx *ctx) { return ctx ? ctx->last_kmer_cover : ""; }
+extern "C" int64_t flx_last_kmer_handed_over(flx_ctx *ctx) {
+    if (!ctx) return -1;
+    if (!ctx->last_kmer_redo || !ctx->last_kmer_redo_n) return 0;
+    std::vector<uint8_t> marks(ctx->last_kmer_redo_n);
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(marks.data(), ctx->last_kmer_redo, marks.size(), hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    int64_t n = 0;
+    for (uint8_t m : marks) n += m != 0;
+    return n;
+}
 
 extern "C" const char *flx_last_error(const flx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 

@@ -27,6 +27,8 @@ struct flx_ctx {
     hipDeviceProp_t prop;
     std::string err;
     bool last_kmer_fold_grid = false;    // ... and its window folds on the integer grid (score_kmer.hip: GridTab)
+    const uint8_t *last_kmer_redo = nullptr;  // the marks of the last k_kmer_cover_q run (device, in workspace 0 until the next scoring call) ...
+    uint64_t last_kmer_redo_n = 0;            // ... and how many there are
     const char *last_kmer_cover = "";    // which coverage kernel the last k-mer scoring call ran: "q" (cover_queue.hip), "w", "v2"
     bool last_kmer_locus = false;        // the last k-mer scoring call ran with the assembly text (kmerset.h: flx_locus)
     const char *last_phred_kernel = "";  // which Phred kernel the last scoring call launched (flx_last_phred_kernel)

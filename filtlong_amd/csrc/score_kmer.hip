@@ -1549,6 +1549,8 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
         flx_time_scope tc(ctx, "flx_score_kmer_cover");
         ctx->last_kmer_locus = false;
         ctx->last_kmer_cover = "v2";
+        ctx->last_kmer_redo = nullptr;
+        ctx->last_kmer_redo_n = 0;
         if (!old_cover) {
             const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + FLX_COVER_THREADS / 64 - 1) / (FLX_COVER_THREADS / 64), 1u << 22);
             const char *locus_env = getenv("FLX_KMER_LOCUS");  // "0": without the assembly text (the round-3 kernel; tests, A/B)
@@ -1560,6 +1562,8 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
             CoverArgs ca = {d_plane, d_offsets, d_lengths, d_order, n_reads, flx_kmerset_exact15(set), pre11, lp ? *lp : none, (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first, last, d_redo};
             ctx->last_kmer_cover = (lp && !wave_cover) ? "q" : "w";
             if (lp && !wave_cover) {
+                ctx->last_kmer_redo = d_redo;
+                ctx->last_kmer_redo_n = n_reads;
                 const int rc = flx_cover_queue_launch(ctx, ca, pre11 != nullptr, wgrid);
                 if (rc != FLX_OK) return rc;
             } else if (pre11 && lp)

@@ -39,7 +39,7 @@ extern "C" {
  * set built from an assembly also keeps the assembly as a text + seed table (0.5 B per base + 10 B per distinct 16-mer of device
  * memory beside the 512 MiB bitmap, 1 GiB pair table and 2 + 2 MiB prefilters); when that memory cannot be had the set works without */
 /* 3 (round 5): + flx_last_kmer_fold_grid */
-/* 4 (round 6): + flx_last_kmer_cover, flx_synth_seq_profile_dev */
+/* 4 (round 6): + flx_last_kmer_cover, flx_last_kmer_handed_over, flx_synth_seq_profile_dev */
 #define FLX_ABI_VERSION 4
 
 enum flx_status {
@@ -108,6 +108,10 @@ int flx_last_kmer_fold_grid(const flx_ctx *ctx);
  * set with a text), "w" (the wave-level kernel of rounds 3-5: sets without a text, FLX_KMER_COVER=w) or "v2" (FLX_KMER_COVER=v2, sets
  * without the pair table).  Results are identical whichever runs. */
 const char *flx_last_kmer_cover(const flx_ctx *ctx);
+/* How many reads of the last k-mer-mode scoring call the first coverage kernel handed to the one in which every lane follows a
+ * diagonal of its own (reads with insertions / deletions; kernel "q" only, 0 otherwise; valid until the next scoring call of the
+ * context; a device-to-host copy of one byte per read: for tests and diagnostics).  -1 on error. */
+int64_t flx_last_kmer_handed_over(flx_ctx *ctx);
 int flx_timing_enable(flx_ctx *ctx, int on);
 int flx_timing_reset(flx_ctx *ctx);
 int flx_timing_get(flx_ctx *ctx, const char *prefix, double *total_ms, uint64_t *launches);

@@ -505,6 +505,43 @@ def test_locus_path_vs_oracle(ctx, be, synth, monkeypatch):
             r[at:at] = rnd(int(rng.randint(1, 4)))
     add("indels", r)
     add("deletion_37", c0[1000:3100] + c0[3137:6000])
+
+    # round 6: reads whose diagonal moves all the time (cover_queue.hip: the kernel with a diagonal per lane, reached through the
+    # hand-over of the first kernel) — an indel every ~25 bases like a nanopore read, on either strand, with substitutions on top,
+    # across two contigs, over N runs and repeats, of every size up to 20, tiny reads, reads that are clean in one half (the mode has
+    # to come and go), and a drift of more than the 16 bases a lane searches within one span
+    def indels(seq, every, max_size=3, sub=0.0):
+        r = bytearray(mutate(seq, sub) if sub else bytes(seq))
+        n_ev = max(1, len(r) // every)
+        for at in sorted(rng.randint(5, max(6, len(r) - 5), n_ev), reverse=True):
+            size = int(rng.randint(1, max_size + 1))
+            if rng.rand() < 0.5:
+                del r[at:at + size]
+            else:
+                r[at:at] = rnd(size)
+        return bytes(r)
+
+    add("indels_dense", indels(c0[2000:9000], 25, sub=0.03))
+    add("indels_dense_rev", indels(_cases.revcomp(c0[4000:12000]), 25, sub=0.03))
+    add("indels_very_dense", indels(c0[1000:5000], 12))
+    add("indels_sizes_to_20", indels(c0[3000:12000], 150, max_size=20))
+    add("indels_two_contigs", indels(c0[-2500:] + (contigs[1][:2500] if len(contigs[1]) >= 2500 else c_second), 30))
+    add("indels_n_runs", indels(c_n[300:3700], 30))
+    add("indels_repeats", indels(c_rep, 20))
+    add("indels_short", indels(c0[7000:7200], 20))
+    add("indels_tiny", indels(c0[7000:7040], 15))
+    add("indels_then_clean", indels(c0[1000:5000], 25) + c0[5000:9000])
+    add("clean_then_indels", c0[1000:5000] + indels(c0[5000:9000], 25))
+    add("indels_clean_indels_rev", _cases.revcomp(indels(c0[1000:3500], 25) + c0[3500:7000] + indels(c0[7000:9500], 25)))
+    r = bytearray(c0[2000:8000])
+    for k in range(12):  # twelve deletions of 3 bases inside 600 bases: the diagonal drifts 36 bases within one span
+        del r[2000 + 45 * k:2003 + 45 * k]
+    add("drift_36_in_a_span", r)
+    r = bytearray(c0[2000:8000])
+    for k in range(12):
+        r[2000 + 48 * k:2000 + 48 * k] = rnd(3)
+    add("drift_back_36_in_a_span", r)
+    add("indels_junk_indels", indels(c0[1000:4000], 25) + rnd(800) + indels(c0[4800:8000], 25))
     add("junk_first", rnd(2300) + c0[4000:8000])
     add("junk_middle", c0[1000:2500] + rnd(800) + c0[3300:6000])
     add("junk_only", rnd(5000))
@@ -555,6 +592,8 @@ def test_locus_path_vs_oracle(ctx, be, synth, monkeypatch):
     for pkw in (dict(), dict(trim=True, split=20), dict(trim=True, split=250, window_size=100)):
         got = be.score(reads, pkw, ks)
         assert ctx.last_kmer_locus() and ctx.last_kmer_cover() == "q"
+        # (the reads with indels reach the kernel with a diagonal per lane; a read that follows one diagonal never does)
+        assert 10 <= ctx.last_kmer_handed_over() < len(reads) - 20, ctx.last_kmer_handed_over()
         p = _oracle.make_params(**pkw)
         for (name, seq, q), o in zip(reads, got):
             wnt = _oracle.score_read(seq, q, p, orc, cap=65536)
