@@ -247,7 +247,6 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
         bool indel_mode = false;
         int c_dl = 0;
         bool handed_over = false;  // INDELS = false: a seed was found within 64 bases of the diagonal the wave had
-        int seed_fail = 0;         // spans in a row in which nothing was on the diagonal and no seed was found
         // the queue: q_head = slot of the oldest entry, q_n = entries; fin = the next span to turn into coverage
         int q_head = 0, q_n = 0, fin = 0;
 
@@ -605,9 +604,10 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     const unsigned long long kn = __ballot(known != 0 || (again && mm_cnt < 6 && (valid16 >> 15) != 0));
                     const unsigned long long tail = kn ? whole & ~((2ull << (63 - __clzll(kn))) - 1ull) : whole;
                     if (seeds_left-- == 0 || __popcll(tail) < FLX_LOCUS_TAIL) break;
-                    // (a read that has nothing to do with the text — a contaminant — fails every attempt: after two spans without a
-                    // seed only every fourth span tries again.  Ten seed lanes per span were 40 % of such a read's far requests)
-                    if (!kn && seed_fail >= 2 && (sp & 3) != 0) break;
+                    // (a read that has nothing to do with the text — a contaminant — fails every attempt: a read that has found no
+                    // diagonal in its first two spans tries again only in every fourth.  Ten seed lanes per span were 40 % of such a
+                    // read's far requests.  No counter of failures: one more scalar carried through the span loop cost C3 2 %, measured)
+                    if (!have_diag && sp >= 2 && (sp & 3) != 0) break;
                     bool tries;
                     if (kn) {
                         const unsigned long long t1 = tail & (tail - 1), t2 = t1 & (t1 - 1);  // without its first lane / first two lanes
@@ -640,10 +640,8 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                             again = false;
                             continue;
                         }
-                        if (!kn) ++seed_fail;
                         break;
                     }
-                    seed_fail = 0;
                     const int src = __ffsll(found) - 1;
                     const long long nd = (long long)__builtin_amdgcn_readlane(tpos, src) - (long long)((sp << 10) + src * 16);
                     if (have_diag && nd == diag) break;  // the same locus: what is missing are mismatches, not the diagonal
