@@ -513,7 +513,12 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     twl.y = flx_from_left(tw.y, tw0.y);
                     const uint32_t tsl = flx_from_left(ts, carry_ok ? c_ts : 0u);  // (not worth a load: lane 0 behind a new seed refutes its own window only, below)
                     const uint32_t t_own = __builtin_amdgcn_alignbit(twl.x, tw.x, 2 * (15 - e));
-                    const uint32_t b_own = (((twl.y & 0xffffu) >> (e + 1)) | (tw.y << (15 - e))) & 0xffffu;  // bit j: my base j is the first of a piece
+                    // (piece starts are rare — two per contig — and a span whose text words hold none, nor the carried word of the lane in
+                    // front, needs none of the masks that keep a window inside one piece: 25 of the comparison's ~100 instructions)
+                    const uint32_t mb0 = carry_ok ? c_mb : 0xffffffffu, us0 = carry_ok ? c_us : 0u;
+                    const bool any_start = (mb0 >> 16) != 0 || __any(((tw.y | twl.y) & 0xffffu) != 0);
+                    uint32_t b_own = 0;  // bit j: my base j is the first of a piece
+                    if (any_start) b_own = (((twl.y & 0xffffu) >> (e + 1)) | (tw.y << (15 - e))) & 0xffffu;
                     const uint32_t u_own = (((twl.y >> 16) >> (e + 1)) | ((tw.y >> 16) << (15 - e))) & 0xffffu;  // bit j: a unique 13-mer starts at my base j
                     const uint32_t s_own = ((tsl >> (e + 1)) | (ts << (15 - e))) & 0xffffu;  // bit j: the text's 16 bases from my base j on are S1
                     const uint32_t x = lo ^ t_own;
@@ -524,29 +529,33 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     m = (m | (m >> 8)) & 0xffffu;
                     const uint32_t mml = __brev(m) >> 16;  // bit j: my base j differs from the text
                     mm_cnt = __popc(mml);
-                    const uint32_t mb0 = carry_ok ? c_mb : 0xffffffffu, us0 = carry_ok ? c_us : 0u;
-                    const uint32_t mmh = flx_from_left(mml, mb0 & 0xffffu), bh = flx_from_left(b_own, mb0 >> 16);
+                    const uint32_t mmh = flx_from_left(mml, mb0 & 0xffffu);
+                    uint32_t bh = 0;
+                    if (any_start) bh = flx_from_left(b_own, mb0 >> 16);
                     const uint32_t uh = flx_from_left(u_own, us0 & 0xffffu), sh = flx_from_left(s_own, us0 >> 16);
                     const uint32_t z = ~(mmh | (mml << 16));  // bit i: base i of the window [p0 - 16, p0 + 16) matches
                     uint32_t r = z & (z >> 1);
                     r &= r >> 2;
                     r &= r >> 4;
                     r &= r >> 8;  // bit i: bases i .. i + 15 match
-                    uint32_t q = ~(bh | (b_own << 16)) >> 1;  // bit i: no piece starts at base i + 1
-                    q &= q >> 1;
-                    q &= q >> 2;
-                    q &= q >> 4;
-                    q &= q >> 7;  // bit i: none at i + 1 .. i + 15 — the 16 bases from i on lie in one piece of the text
+                    uint32_t q = 0xffffffffu, q12 = 0xffffffffu;  // (no piece start in sight: every window lies inside one piece)
+                    if (any_start) {
+                        q = ~(bh | (b_own << 16)) >> 1;  // bit i: no piece starts at base i + 1
+                        q &= q >> 1;
+                        q &= q >> 2;
+                        q &= q >> 4;
+                        q &= q >> 7;  // bit i: none at i + 1 .. i + 15 — the 16 bases from i on lie in one piece of the text
+                        q12 = ~(bh | (b_own << 16)) >> 1;
+                        q12 &= q12 >> 1;
+                        q12 &= q12 >> 2;
+                        q12 &= q12 >> 4;
+                        q12 &= q12 >> 3;  // bit i: no piece starts at i + 1 .. i + 11 (a piece has at least 16 bases: the 12-mer lies in one of its 16-mers)
+                    }
                     {
                         uint32_t m12 = z & (z >> 1);
                         m12 &= m12 >> 2;
                         m12 &= m12 >> 4;
                         m12 &= m12 >> 4;  // bit i: bases i .. i + 11 match
-                        uint32_t q12 = ~(bh | (b_own << 16)) >> 1;
-                        q12 &= q12 >> 1;
-                        q12 &= q12 >> 2;
-                        q12 &= q12 >> 4;
-                        q12 &= q12 >> 3;  // bit i: no piece starts at i + 1 .. i + 11 (a piece has at least 16 bases: the 12-mer lies in one of its 16-mers)
                         text12 |= ((m12 & q12) >> 5) & 0xffffu;  // the 12-mer ending at my position j starts at base j + 5
                     }
                     r &= q;

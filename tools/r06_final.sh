@@ -15,7 +15,7 @@ rm -rf $R/gpurun_out/prof_kmer; bash tools/prof_kmer.sh 10000000 "c3 c4" > $OUT/
 # ... and of C3 on the two read profiles of round 6 (the passes the request model is made of)
 bash tools/prof_kmer.sh 10000000 "c3_indels c3_unrelated" light > $OUT/prof_kmer_profiles.out 2>&1; grep -E "TCC_|cover" $OUT/prof_kmer_profiles.out | head -30
 python tools/make_profile_json.py r06 10000000 kmer-only
-/usr/bin/time -f "bench.py wall %e s" -o $OUT/bench_wall.txt timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_wall.txt; tail -c 900 $OUT/bench_default.json | head -c 600; echo
+t0=$SECONDS; timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "python bench.py (default flags, all extras): $((SECONDS - t0)) s wall" | tee $OUT/bench_wall.txt; tail -c 900 $OUT/bench_default.json | head -c 600; echo
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o c2 -- python $R/bench.py --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 python $R/tools/rocprof_summary.py $OUT/stats/c2_results.db > $OUT/c2_kernel_stats.txt 2>&1; head -8 $OUT/c2_kernel_stats.txt | cut -c1-140
