@@ -107,7 +107,10 @@ __device__ __attribute__((noinline)) LaneDiag lane_diagonals(LdsPtr Sp, int lane
         const int r = (int)(best & 63u);
         const int mine = matched ? ((r & 1) ? -((r + 1) >> 1) : (r >> 1)) : 0x7f;
         const int left = (int)flx_from_left((uint32_t)mine, (uint32_t)c_dl);
-        dl = matched ? mine : (left != 0x7f ? left : 0);  // (a lane without a diagonal of its own looks where its left neighbour does)
+        // (a lane without a diagonal of its own looks where its left neighbour does.  Looking further left — up to four lanes — changes
+        // nothing, counted: the 6.4 lanes per span that still find a text window with the exact table are pairs of neighbours with an
+        // indel each, whose common stretch lies on a diagonal neither of them has most of its bases on)
+        dl = matched ? mine : (left != 0x7f ? left : 0);
     }
     // my 32-base window against the text on the diagonal `diag + d`: adds to known / refuted / text12
     auto compare_at = [&](int d) {
@@ -502,7 +505,8 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
             uint32_t known = 0, refuted = 0;  // refuted: not a text match, but holds a text-matching 13-mer that occurs nowhere else (U13), or is one substitution away from a text window without such members (S1)
             uint32_t text12 = 0;              // bit j: the 12 bases ending at my position j match the text inside one piece: that 12-mer IS present
             {
-                int mm_cnt = 0;  // my bases that differ from the text on the wave's diagonal (last comparison)
+                int mm_cnt = 0;        // my bases that differ from the text on the wave's diagonal (last comparison)
+                uint32_t t_diag = 0;   // the text's 16 bases under mine on that diagonal
                 // my 16 bases against the text along `diag` (tw = the word that holds the last of them): adds to known / refuted
                 auto compare = [&]() {
                     const int e = (int)((diag + 15) & 15);  // index of my last base in my word (p0 is a multiple of 16: the same for every lane)
@@ -521,6 +525,7 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                     if (any_start) b_own = (((twl.y & 0xffffu) >> (e + 1)) | (tw.y << (15 - e))) & 0xffffu;
                     const uint32_t u_own = (((twl.y >> 16) >> (e + 1)) | ((tw.y >> 16) << (15 - e))) & 0xffffu;  // bit j: a unique 13-mer starts at my base j
                     const uint32_t s_own = ((tsl >> (e + 1)) | (ts << (15 - e))) & 0xffffu;  // bit j: the text's 16 bases from my base j on are S1
+                    t_diag = t_own;
                     const uint32_t x = lo ^ t_own;
                     uint32_t m = (x | (x >> 1)) & 0x55555555u;  // even bit 2k: the base k places from the END differs
                     m = (m | (m >> 1)) & 0x33333333u;
@@ -668,6 +673,21 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
                         ts_next = safe_word(diag, (sp << 10) + 1024);
                     }
                     again = true;
+                }
+
+                // INDELS = false: is this a read whose diagonal has just moved by a base or three?  Lanes that look nothing like the text
+                // on the wave's diagonal but like it one, two or three bases beside it (<= 4 differing bits of 32; the neighbours' aligned
+                // text by DPP) say so — without waiting for a seed to confirm it, which half the time takes a span of prefilter and exact
+                // table for nothing (a sixth of such a read's time went there).  Junk matches at no shift.
+                if (!INDELS && have_diag && !handed_over && __popcll(__ballot((valid16 >> 15) != 0 && mm_cnt >= 6)) >= 2) {
+                    const uint32_t tl = flx_from_left(t_diag, 0u), tr = flx_from_right(t_diag, 0u);
+                    uint32_t best = 32;
+#pragma unroll
+                    for (int k = 1; k <= 3; ++k) {
+                        best = min(best, (uint32_t)__popc(lo ^ __builtin_amdgcn_alignbit(tl, t_diag, 2 * k)));
+                        best = min(best, (uint32_t)__popc(lo ^ __builtin_amdgcn_alignbit(t_diag, tr, 32 - 2 * k)));
+                    }
+                    if (__popcll(__ballot((valid16 >> 15) != 0 && mm_cnt >= 6 && best <= 4u)) >= 2) handed_over = true;
                 }
 
                 // ---- reads with insertions and deletions: a diagonal per lane (round 6; the round-5 review's item 2).  One diagonal
