@@ -16,17 +16,22 @@
 //           vouches for), seeds.  A lane whose 17-position window leaves no candidate outside its confirmed members is done — its hits
 //           are the known ones.  Every other lane APPENDS its piece to the wave's queue: the 32 bases it needs, what the text knows
 //           about its 16 windows and about the 12-mers in front of it, whether the left neighbour's last 16-mer is a known member,
-//           and its position.  Entries are self-contained: nothing in phase B looks at a lane that is not in the queue.
+//           and its position.  An entry holds everything phase B needs: nothing there looks at a lane that is not in the queue.
 //   phase B (when 64 entries have gathered, or the oldest waits too long): prefilter in two rounds over the TEN pairs that hold the
 //           12-mers of the piece's own 16 windows (positions -4 .. 15; k_kmer_cover_w let the left neighbour fetch the first two
 //           pairs), candidates, the outermost-member search against exact15 — the same policy as before, but all 64 lanes carry a
-//           piece.  Pieces that are neighbours in the read are neighbours in the queue (the append keeps the order), so the left
-//           neighbour's answer still spares the bottom-up search where both are queued.
+//           piece.  Pieces that are neighbours in the read are neighbours in the queue (the append keeps the order): where both are
+//           queued the left one fetches the two pairs they share for both, and its answer still spares the bottom-up search.
 //   The hits of a span wait in a ring in LDS (kRing spans) until its queued pieces are through; then the 4-step OR-dilation, the
 //   counts and the row words as before.
 // A global queue between two kernels (the form the round-5 review sketched) was costed first: 32.5 entries of 20 bytes per span are
 // 1.3 kB of extra HBM traffic per 1 kB of plane, and the cover stage sits 15 % above the floor its requests set —
 // the queue must not leave the chip.
+//
+// The kernel exists twice (template parameter INDELS).  <false> serves every read and hands over, by a mark, the reads whose diagonal
+// moves by a base or three again and again — insertions and deletions —; <true> runs on the marked reads afterwards and lets every lane
+// SEARCH a diagonal of its own (lane_diagonals below).  What that gave, what it did not, and the forms that were measured and
+// rejected (a second queue for the search, the lane-diagonal code inside the one kernel): DESIGN.md §4.3, profiles/r06_microbench.txt.
 #include "flx_internal.h"
 #include "kmerset.h"
 #include "cover_common.h"
