@@ -79,4 +79,5 @@ struct CoverArgs {
 #define FLX_KARG_PTR(elem, field) ((FLX_GLOBAL_PTR(elem))(uint64_t)(uintptr_t)(a.field))
 
 // cover_queue.hip: the cover kernel of round 6 (sets with a text); returns a HIP launch error through the context
-int flx_cover_queue_launch(flx_ctx *ctx, const CoverArgs &args, bool has_prefilter, unsigned grid);
+// (every_read_to_second: FLX_KMER_COVER=q2, tests — every read goes straight to the kernel with a diagonal per lane)
+int flx_cover_queue_launch(flx_ctx *ctx, const CoverArgs &args, bool has_prefilter, unsigned grid, bool every_read_to_second);

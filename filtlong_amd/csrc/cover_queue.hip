@@ -831,17 +831,18 @@ __global__ void __launch_bounds__(FLX_COVER_THREADS) FLX_COVER_OCC k_kmer_cover_
 
 }  // namespace
 
-int flx_cover_queue_launch(flx_ctx *ctx, const CoverArgs &args, bool has_prefilter, unsigned grid) {
+int flx_cover_queue_launch(flx_ctx *ctx, const CoverArgs &args, bool has_prefilter, unsigned grid, bool every_read_to_second) {
     if (!args.redo) return flx_fail(ctx, FLX_ERR_INVALID, "cover kernel: no room for the marks of reads with insertions / deletions");
-    FLX_HIP(ctx, hipMemsetAsync(args.redo, 0, args.n_reads, ctx->stream));
+    FLX_HIP(ctx, hipMemsetAsync(args.redo, every_read_to_second ? 1 : 0, args.n_reads, ctx->stream));
     // every read; then the reads the first kernel handed over (marked on the device: no host round trip, a grid of resident
-    // workgroups walks the marks 64 at a time)
+    // workgroups walks the marks 64 at a time).  every_read_to_second (FLX_KMER_COVER=q2; tests): every read is marked beforehand and the
+    // first kernel does not run — the second one must give the same bits on ANY read, not only on those that are handed to it
     const unsigned grid2 = std::min(grid, 8u * 256u);
     if (has_prefilter) {
-        hipLaunchKernelGGL((k_kmer_cover_q<true, false>), dim3(grid), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
+        if (!every_read_to_second) hipLaunchKernelGGL((k_kmer_cover_q<true, false>), dim3(grid), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
         hipLaunchKernelGGL((k_kmer_cover_q<true, true>), dim3(grid2), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
     } else {
-        hipLaunchKernelGGL((k_kmer_cover_q<false, false>), dim3(grid), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
+        if (!every_read_to_second) hipLaunchKernelGGL((k_kmer_cover_q<false, false>), dim3(grid), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
         hipLaunchKernelGGL((k_kmer_cover_q<false, true>), dim3(grid2), dim3(FLX_COVER_THREADS), 0, ctx->stream, args);
     }
     FLX_HIP(ctx, hipGetLastError());

@@ -1542,10 +1542,12 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
     {
         const unsigned grid = (unsigned)std::min<uint64_t>(n_reads, 1u << 20);
         // FLX_KMER_COVER: "v2" = round 2's workgroup-per-read kernel, "w" = the wave-level kernel of rounds 3-5 for every set (second
-        // and third implementation; default: k_kmer_cover_q, cover_queue.hip, for a set with a text, k_kmer_cover_w for one without)
+        // and third implementation; default: k_kmer_cover_q, cover_queue.hip, for a set with a text, k_kmer_cover_w for one without),
+        // "q2" = k_kmer_cover_q with EVERY read in its second launch (a diagonal per lane: tests)
         const char *cover_env = getenv("FLX_KMER_COVER");
         const bool old_cover = (cover_env && strcmp(cover_env, "v2") == 0) || !flx_kmerset_exact15(set);  // (no pair table: finalize found no room for it)
         const bool wave_cover = cover_env && strcmp(cover_env, "w") == 0;
+        const bool second_only = cover_env && strcmp(cover_env, "q2") == 0;  // every read through the kernel with a diagonal per lane (tests)
         flx_time_scope tc(ctx, "flx_score_kmer_cover");
         ctx->last_kmer_locus = false;
         ctx->last_kmer_cover = "v2";
@@ -1560,11 +1562,11 @@ int flx_score_kmer_dev(flx_ctx *ctx, const flx_kmerset *set, const uint8_t *d_pl
             ctx->last_kmer_locus = lp != nullptr;
             const uint8_t *pre11 = flx_kmerset_pre11(set);
             CoverArgs ca = {d_plane, d_offsets, d_lengths, d_order, n_reads, flx_kmerset_exact15(set), pre11, lp ? *lp : none, (uint32_t *)d_cov, (const uint64_t *)d_covoff, d_cnt, first, last, d_redo};
-            ctx->last_kmer_cover = (lp && !wave_cover) ? "q" : "w";
+            ctx->last_kmer_cover = (lp && !wave_cover) ? (second_only ? "q2" : "q") : "w";
             if (lp && !wave_cover) {
                 ctx->last_kmer_redo = d_redo;
                 ctx->last_kmer_redo_n = n_reads;
-                const int rc = flx_cover_queue_launch(ctx, ca, pre11 != nullptr, wgrid);
+                const int rc = flx_cover_queue_launch(ctx, ca, pre11 != nullptr, wgrid, second_only);
                 if (rc != FLX_OK) return rc;
             } else if (pre11 && lp)
                 hipLaunchKernelGGL((k_kmer_cover_w<true, true>), dim3(wgrid), dim3(FLX_COVER_THREADS), 0, st, ca);

@@ -105,8 +105,8 @@ int flx_last_kmer_locus(const flx_ctx *ctx);
  * was taken in floating point.  Results are identical either way. */
 int flx_last_kmer_fold_grid(const flx_ctx *ctx);
 /* Which coverage kernel the last k-mer-mode scoring call launched: "q" (phases with a queue in LDS between them, the default for a
- * set with a text), "w" (the wave-level kernel of rounds 3-5: sets without a text, FLX_KMER_COVER=w) or "v2" (FLX_KMER_COVER=v2, sets
- * without the pair table).  Results are identical whichever runs. */
+ * set with a text), "q2" (FLX_KMER_COVER=q2: the same with every read in its second launch, tests), "w" (the wave-level kernel of rounds
+ * 3-5: sets without a text, FLX_KMER_COVER=w) or "v2" (FLX_KMER_COVER=v2, sets without the pair table).  Results are identical whichever runs. */
 const char *flx_last_kmer_cover(const flx_ctx *ctx);
 /* How many reads of the last k-mer-mode scoring call the first coverage kernel handed to the one in which every lane follows a
  * diagonal of its own (reads with insertions / deletions; kernel "q" only, 0 otherwise; valid until the next scoring call of the

@@ -224,7 +224,7 @@ def test_kmer_mode_properties(short_reads, size):
     wave_level = {k: v.clone() for k, v in t.items()}
     n_wave = int(s.n_children)
     assert ctx.last_kmer_cover() == "q"  # (round 6: the default is the kernel with the queue in LDS, cover_queue.hip)
-    for other in ("w", "v2"):  # the wave-level kernel of rounds 3-5, round 2's kernel
+    for other in ("w", "v2", "q2"):  # the wave-level kernel of rounds 3-5, round 2's kernel, every read in the launch with a diagonal per lane
         os.environ["FLX_KMER_COVER"] = other
         try:
             for v in t.values():
@@ -391,7 +391,7 @@ def test_kmer_read_profiles_whole_population(profile):
         nc = w["n_children"]
         if profile == 2 and not pkw:
             assert 0.25 * n < int((w["mean_q"] < 15.0).sum()) < 0.35 * n  # the unrelated reads: a random 16-mer is a member once in 430 (5 Mbp), ~4 % of their bases are covered
-        for cover in (None, "w", "v2"):
+        for cover in (None, "w", "v2", "q2"):  # q2: every read in the launch with a diagonal per lane
             if cover:
                 os.environ["FLX_KMER_COVER"] = cover
             try:

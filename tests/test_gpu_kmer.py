@@ -612,11 +612,15 @@ def test_locus_path_vs_oracle(ctx, be, synth, monkeypatch):
         monkeypatch.setenv("FLX_KMER_COVER", "w")
         wv = be.score(reads, pkw, ks)
         assert ctx.last_kmer_cover() == "w" and ctx.last_kmer_locus()
+        monkeypatch.setenv("FLX_KMER_COVER", "q2")  # EVERY read through the kernel with a diagonal per lane, not only those handed to it
+        q2 = be.score(reads, pkw, ks)
+        assert ctx.last_kmer_cover() == "q2" and ctx.last_kmer_handed_over() == len(reads)
         monkeypatch.delenv("FLX_KMER_COVER")
-        for (name, _s, _q), a, b, c, d in zip(reads, got, plain, v2, wv):
+        for (name, _s, _q), a, b, c, d, e2 in zip(reads, got, plain, v2, wv, q2):
             assert bits(a) == bits(b), (name, pkw, "FLX_KMER_LOCUS=0")
             assert bits(a) == bits(c), (name, pkw, "v2")
             assert bits(a) == bits(d), (name, pkw, "w")
+            assert bits(a) == bits(e2), (name, pkw, "q2")
     # the same set built without S1: nothing may differ
     monkeypatch.setenv("FLX_KMER_SAFE1", "0")
     ks_plain = be.kmers(assembly=contigs)
@@ -731,11 +735,14 @@ def test_path_text_of_short_read_sets_vs_oracle(ctx, be, monkeypatch):
             v2 = be.score(reads, pkw, kset)
             monkeypatch.setenv("FLX_KMER_COVER", "w")
             wv = be.score(reads, pkw, kset)
+            monkeypatch.setenv("FLX_KMER_COVER", "q2")
+            q2 = be.score(reads, pkw, kset)
             monkeypatch.delenv("FLX_KMER_COVER")
-            for (name, _s, _q), a, b, c, d in zip(reads, got, plain, v2, wv):
+            for (name, _s, _q), a, b, c, d, e2 in zip(reads, got, plain, v2, wv, q2):
                 assert bits(a) == bits(b), (name, pkw, "FLX_KMER_LOCUS=0")
                 assert bits(a) == bits(c), (name, pkw, "v2")
                 assert bits(a) == bits(d), (name, pkw, "w")
+                assert bits(a) == bits(e2), (name, pkw, "q2")
 
 
 def test_set_without_room_for_the_pair_table(ctx, be, synth, monkeypatch):
